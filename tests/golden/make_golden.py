@@ -1,0 +1,188 @@
+"""Generate the committed golden fixtures by importing the REFERENCE VQ-VAE
+(/root/reference/code) in the build container.  The reference never travels to the
+GPU box; only the small .npz files written here do.  Weights are not stored: both
+sides regenerate them from dimx.prng (seed below).
+
+Run:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/code"
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import dimx  # noqa: E402
+from dimx import prng, weights  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+
+SEED = 20260928
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def load_reference():
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from base import config as ref_config
+        from models import get_model
+        cfg = ref_config.load_cfg_from_cfg_file("./config.yaml")
+        models = {}
+        for which in ("listener_vq.", "speaker_vq."):
+            m = get_model(cfg).eval()
+            sd = weights.synth_state_dict(weights.vq_spec(prefix=which), SEED, strip_prefix=which)
+            ref_keys = set(m.state_dict().keys())
+            assert ref_keys == set(sd.keys()), (ref_keys ^ set(sd.keys()))
+            for k, v in m.state_dict().items():
+                assert tuple(v.shape) == tuple(sd[k].shape), k
+            # the computed pe buffer must equal the reference's own buffer bit for bit
+            assert torch.equal(m.state_dict()["encoder.encoder_pos_embedding.pe"],
+                               sd["encoder.encoder_pos_embedding.pe"])
+            m.load_state_dict(sd, strict=True)
+            models[which] = m
+        return cfg, models, ref_config
+    finally:
+        os.chdir(cwd)
+
+
+def main():
+    cfg, models, ref_config = load_reference()
+    lst = models["listener_vq."]
+    spk = models["speaker_vq."]
+    full_sd = weights.synth_state_dict(weights.vq_spec(prefix="listener_vq.") +
+                                       weights.vq_spec(prefix="speaker_vq."), SEED)
+    report = {}
+
+    # ---- config surface -------------------------------------------------
+    my_cfg = dimx.config.load_cfg_from_cfg_file(dimx.config.DEFAULT_CONFIG)
+    ref_cfg = dict(cfg)
+    shared = {k: ref_cfg[k] for k in my_cfg if k in ref_cfg}
+    assert all(my_cfg[k] == shared[k] for k in shared), "config.yaml deviates from the reference"
+    with open(os.path.join(HERE, "cfg_roundtrip.json"), "w") as f:
+        json.dump({"reference_flat_cfg": {k: ref_cfg[k] for k in sorted(ref_cfg)
+                                          if isinstance(ref_cfg[k], (int, float, str, bool, type(None)))}},
+                  f, indent=1, sort_keys=True)
+
+    # ---- encode fixtures -------------------------------------------------
+    for T in (5, 27, 300, 1500):
+        x = torch.from_numpy(prng.normal(SEED, "golden.enc.x.T%d" % T, (1, T, 56)))
+        quant, _, info = lst.encode(x)
+        idx = info[2].view(-1)
+        o_idx, o_z, o_d = ref_cpu.vq_encode(full_sd, x, "listener_vq.", return_all=True)
+        margin = ref_cpu.vq_margins(o_d)
+        h = lst.encoder(x)                      # reference pre-quant features
+        assert torch.equal(idx, o_idx.view(-1)), "oracle indices differ from reference at T=%d" % T
+        zerr = (h - o_z).abs().max().item()
+        assert zerr < 2e-5, zerr
+        assert margin.min().item() >= 1e-4, ("reseed: min top-2 margin", margin.min().item())
+        np.savez_compressed(os.path.join(HERE, "vq_encode_T%d.npz" % T),
+                            x=x.numpy(), idx=idx.numpy().astype(np.int16),
+                            margin=margin.numpy().astype(np.float32),
+                            z=h[0].numpy().astype(np.float32) if T <= 300 else np.zeros((0,), np.float32))
+        report["encode_T%d" % T] = {"min_margin": margin.min().item(), "z_err_oracle_vs_ref": zerr}
+
+    # ---- decode fixtures (PE batch-row quirk for B=3) ---------------------
+    E = lst.quantize.embedding.weight
+    for B, L in ((1, 26), (3, 26), (1, 299), (3, 299)):
+        idx = torch.from_numpy(prng.integers(SEED, "golden.dec.idx.B%d.L%d" % (B, L), (B, L), 0, 512))
+        out = lst.decode(E[idx].permute(0, 2, 1))
+        o_out = ref_cpu.vq_decode(full_sd, idx, "listener_vq.")
+        err = (out - o_out).abs().max().item()
+        assert err < 1e-5, err
+        np.savez_compressed(os.path.join(HERE, "vq_decode_B%d_L%d.npz" % (B, L)),
+                            idx=idx.numpy().astype(np.int16), out=out.numpy().astype(np.float32))
+        report["decode_B%d_L%d" % (B, L)] = {"err_oracle_vs_ref": err}
+
+    # ---- forward_vq ragged re-enactment (code/seq2seq_pretrain.py:480-494) -----
+    B, T = 4, 40
+    lens = [40, 33, 12, 5]
+    v_s = torch.from_numpy(prng.normal(SEED, "golden.fvq.vs", (B, T, 56)))
+    v_l = torch.from_numpy(prng.normal(SEED, "golden.fvq.vl", (B, T, 56)))
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    for j, n in enumerate(lens):
+        mask[j, :n] = True
+    zs, zl = [], []
+    import torch.nn.functional as F
+    for i in range(B):
+        sf = spk.encode(v_s[i][mask[i]].unsqueeze(0))[2][2].squeeze()
+        zs.append(F.pad(sf, (0, T - sf.shape[-1]), value=0))
+        lf = lst.encode(v_l[i][mask[i]].unsqueeze(0))[2][2].squeeze()
+        zl.append(F.pad(lf, (0, T - lf.shape[-1]), value=-100))
+    zs, zl = torch.stack(zs), torch.stack(zl)
+    o_zs, o_zl = ref_cpu.forward_vq(full_sd, v_s, v_l, mask)
+    assert torch.equal(zs, o_zs) and torch.equal(zl, o_zl)
+    np.savez_compressed(os.path.join(HERE, "vq_forward_vq_ragged.npz"), v_speaker=v_s.numpy(),
+                        v_listener=v_l.numpy(), lens=np.array(lens, np.int32),
+                        z_speaker=zs.numpy().astype(np.int16), z_listener=zl.numpy().astype(np.int16))
+
+    # ---- C1 round trip (VQAutoEncoder.forward, stage1_BIWI.py:49-55) -------
+    x = torch.from_numpy(prng.normal(SEED, "golden.c1.x", (1, 300, 56)))
+    dec, _, info = lst(x)
+    idx = info[2].view(1, -1)
+    o_idx = ref_cpu.vq_encode(full_sd, x, "listener_vq.")
+    o_dec = ref_cpu.vq_decode(full_sd, o_idx, "listener_vq.")
+    assert torch.equal(idx, o_idx)
+    err = (dec - o_dec).abs().max().item()
+    assert err < 1e-5, err
+    np.savez_compressed(os.path.join(HERE, "vq_roundtrip_C1.npz"), x=x.numpy(),
+                        idx=idx.numpy().astype(np.int16), xhat=dec.numpy().astype(np.float32))
+    report["roundtrip_C1"] = {"err_oracle_vs_ref": err}
+
+    # ---- batched encode with the PE batch-row quirk (public encode API, B=3) ----
+    x = torch.from_numpy(prng.normal(SEED, "golden.encB3.x", (3, 27, 56)))
+    idx = lst.encode(x)[2][2].view(3, 27)
+    o_idx, _, o_d = ref_cpu.vq_encode(full_sd, x, "listener_vq.", return_all=True)
+    assert torch.equal(idx, o_idx)
+    np.savez_compressed(os.path.join(HERE, "vq_encode_B3_T27.npz"), x=x.numpy(),
+                        idx=idx.numpy().astype(np.int16),
+                        margin=ref_cpu.vq_margins(o_d).numpy().astype(np.float32))
+
+    # ---- sampler primitive: torch.multinomial == argmax(p / q) on CPU --------
+    g = torch.Generator().manual_seed(1234)
+    logits = torch.randn(16, 512, generator=g) * 3
+    probs = torch.softmax(ref_cpu.top_k_filter(logits, 52), -1)
+    g1 = torch.Generator().manual_seed(99)
+    ids = torch.multinomial(probs, 1, generator=g1).view(-1)
+    g2 = torch.Generator().manual_seed(99)
+    q = torch.empty_like(probs).exponential_(1, generator=g2)
+    ids2 = (probs / q).argmax(-1)
+    assert torch.equal(ids, ids2), "multinomial != argmax(p/q) on this torch build"
+    np.savez_compressed(os.path.join(HERE, "sampler_multinomial.npz"), logits=logits.numpy(),
+                        probs=probs.numpy(), noise=q.numpy(), ids=ids.numpy().astype(np.int16))
+
+    # ---- metrics (code/metrics/eval_utils.py) --------------------------------
+    sys.path.insert(0, REF)
+    cwd = os.getcwd(); os.chdir(REF)
+    from metrics import eval_utils as ref_metrics
+    os.chdir(cwd)
+    rng = np.random.RandomState(7)
+    gts = [rng.randn(n, 56).astype(np.float32) for n in (40, 55, 70)]
+    prs = [g + 0.3 * rng.randn(*g.shape).astype(np.float32) for g in gts]
+    fds, vars_, stss = [], [], []
+    for gt, pr in zip(gts, prs):
+        m1, s1 = ref_metrics.calculate_activation_statistics(gt)
+        m2, s2 = ref_metrics.calculate_activation_statistics(pr)
+        fds.append(ref_metrics.calculate_frechet_distance(m1, s1, m2, s2))
+        vars_.append(ref_metrics.calculate_variance(pr))
+        stss.append(ref_metrics.sts(gt, pr))
+    np.savez_compressed(os.path.join(HERE, "metrics_small.npz"),
+                        **{"gt%d" % i: g for i, g in enumerate(gts)},
+                        **{"pr%d" % i: p for i, p in enumerate(prs)},
+                        fd=np.array(fds, np.float64), var=np.array(vars_, np.float64),
+                        sts=np.array(stss, np.float64))
+
+    with open(os.path.join(HERE, "golden_report.json"), "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+    print(json.dumps(report, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
