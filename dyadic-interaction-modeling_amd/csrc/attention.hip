@@ -1,0 +1,274 @@
+// attention.hip -- flash-style softmax(Q K^T * scale + mask) V for the parallel (non-autoregressive)
+// attention blocks of the path:
+//   * VQ-VAE blocks, 8 heads x 48, scale hidden^-0.5, keys limited to the clip length
+//     (reference code/models/lib/base_models.py:125-146);
+//   * x-transformers encoder self-attention (causal + key padding mask), teacher-forced decoder
+//     self-attention (causal + random key mask) and cross-attention over the speaker context
+//     (12 heads x 64, scale 64^-0.5; ctor sites code/seq2seq_pretrain.py:388-418).
+// Masked scores take a large negative finite value exactly like x-transformers' -finfo.max fill, so a
+// row with at least one visible key gives identical probabilities.
+//
+// Everything is computed in the "swapped" form so that softmax statistics are lane-local:
+//   S^T[key][query] = K . Q^T   (MFMA A = K tile rows from LDS, B = Q fragment kept in registers)
+//   O^T[d][query]   = V^T . P^T (MFMA A = V^T tile rows from LDS, B = P straight from the S registers)
+// A lane owns one query (lane & 31) and, per 32-key tile, the 16 keys (r&3) + 8*(r>>2) + 4*(lane>>5);
+// the same key order is used for the V^T operand, so P never moves between lanes.  The V operand is
+// consumed transposed ([B,H,D,Lk]), which is how the QKV GEMM epilogue writes it.
+// One wave = 32 queries, NW waves per block share the K / V^T tiles (64 keys) staged in LDS.
+#include "common.hpp"
+
+namespace dimx {
+
+namespace {
+
+template <typename T> struct MmaT;
+template <> struct MmaT<bf16> {
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct MmaT<float> {
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+        const float4 fa = __builtin_bit_cast(float4, a), fb = __builtin_bit_cast(float4, b);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    }
+};
+
+constexpr float kNeg = -3.0e38f;
+
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
+    constexpr int ES = sizeof(T);
+    constexpr int EPC = 16 / ES;    // elements per 16-byte chunk
+    constexpr int ROWB = 64 * ES;   // bytes per LDS row (64 elements)
+    constexpr int CPR = ROWB / 16;  // 16-byte chunks per row: 8 (bf16) / 16 (f32)
+    constexpr int NKS = ROWB / 32;  // 32-byte k-steps over the head dim: 4 / 8
+    constexpr int NT = NW * 64;
+    constexpr int UB = 4 * ES;      // bytes of a 4-key unit in the V^T tile
+    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * ROWB];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qblk0 = blockIdx.x * (32 * NW);
+    const int qi = qblk0 + wave * 32 + l31;
+    const int qc = qi < a.Lq ? qi : a.Lq - 1;
+
+    const T* __restrict__ Q = (const T*)a.q + (size_t)b * a.q_sb + (size_t)h * a.q_sh;
+    const T* __restrict__ K = (const T*)a.k + (size_t)b * a.k_sb + (size_t)h * a.k_sh;
+    const T* __restrict__ Vt = (const T*)a.vt + (size_t)b * a.v_sb + (size_t)h * a.v_sh;
+
+    // Q fragment: chunk 2*ks + half of row qc, zero beyond D
+    uint4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int c = 2 * ks + half;
+        qf[ks] = (c * EPC < a.D) ? *(const uint4*)(Q + (size_t)qc * a.q_st + c * EPC) : make_uint4(0, 0, 0, 0);
+    }
+
+    int kmax = a.Lk;
+    const int len_b = a.lens ? a.lens[b] : a.Lk;
+    kmax = len_b < kmax ? len_b : kmax;
+    if (a.causal) {
+        int last = qblk0 + 32 * NW - 1;
+        last = last < a.Lq - 1 ? last : a.Lq - 1;
+        kmax = (last + 1) < kmax ? (last + 1) : kmax;
+    }
+    const int ntiles = (kmax + 63) / 64;
+
+    float m_run = kNeg, l_run = 0.f;
+    f32x16_t ot[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+    const float scale2 = a.scale * 1.4426950408889634f;
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int j0 = tile * 64;
+        __syncthreads();
+        // ---- stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]
+#pragma unroll
+        for (int i = 0; i < 64 * CPR / NT; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx / CPR, c = idx % CPR;
+            {
+                int key = j0 + row;
+                key = key < a.Lk ? key : a.Lk - 1;
+                const uint4 v = (c * EPC < a.D) ? *(const uint4*)(K + (size_t)key * a.k_st + c * EPC)
+                                                : make_uint4(0, 0, 0, 0);
+                const int sw = (CPR == 8) ? ((row >> 1) & 7) : (row & 15);
+                *(uint4*)(sK + row * ROWB + ((c ^ sw) << 4)) = v;
+            }
+            {
+                const int d = row;
+                const int jj = j0 + c * EPC;
+                int nvalid = a.Lk - jj;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (d < a.D && nvalid > 0) {
+                    v = *(const uint4*)(Vt + (size_t)d * a.v_sd + jj);
+                    if (nvalid < EPC) {  // zero the keys beyond Lk: 0 * garbage must stay 0
+                        if (ES == 2) {
+                            uint16_t e[8];
+                            *(uint4*)e = v;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) e[q] = q < nvalid ? e[q] : (uint16_t)0;
+                            v = *(uint4*)e;
+                        } else {
+                            uint32_t e[4];
+                            *(uint4*)e = v;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) e[q] = q < nvalid ? e[q] : 0u;
+                            v = *(uint4*)e;
+                        }
+                    }
+                }
+                if (ES == 2) {
+                    const int f = (d >> 1) & 15;
+                    if (f & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+                    *(uint4*)(sV + d * ROWB + ((c ^ (f >> 1)) << 4)) = v;
+                } else {
+                    *(uint4*)(sV + d * ROWB + ((c ^ (d & 15)) << 4)) = v;
+                }
+            }
+        }
+        // ---- key validity bits of this tile (wave-uniform 64-bit mask)
+        const int jl = j0 + lane;
+        bool kv = jl < a.Lk && jl < len_b;
+        if (a.kmask && jl < a.Lk) kv = kv && a.kmask[(size_t)b * a.kmask_ld + jl] != 0;
+        const unsigned long long kbits = __ballot(kv);
+        __syncthreads();
+
+        // ---- S^T = K . Q^T
+        f32x16_t st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+            const int row = 32 * kt + l31;
+            const int sw = (CPR == 8) ? ((row >> 1) & 7) : (row & 15);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int c = 2 * ks + half;
+                const uint4 kf = *(const uint4*)(sK + row * ROWB + ((c ^ sw) << 4));
+                MmaT<T>::run(st[kt], kf, qf[ks]);
+            }
+        }
+        // ---- mask, online softmax (lane-local: this lane's query, 32 of the tile's 64 keys)
+        float mx = kNeg;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                bool ok = (kbits >> kl) & 1ull;
+                if (a.causal) ok = ok && (j0 + kl) <= qi;
+                const float s = ok ? st[kt][r] * scale2 : kNeg;
+                st[kt][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(st[kt][r] - m_new);
+                st[kt][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int d = 32 * blk + l31;
+            const unsigned char* vrow = sV + d * ROWB;
+            if (ES == 2) {
+                const int f = (d >> 1) & 15;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int u0 = 8 * kt + 4 * s + half, u1 = u0 + 2;
+                        const uint2 v0 = *(const uint2*)(vrow + ((u0 ^ f) * UB));
+                        const uint2 v1 = *(const uint2*)(vrow + ((u1 ^ f) * UB));
+                        const uint4 va = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                        uint4 pb;
+                        pb.x = pack_bf16x2(st[kt][8 * s + 0], st[kt][8 * s + 1]);
+                        pb.y = pack_bf16x2(st[kt][8 * s + 2], st[kt][8 * s + 3]);
+                        pb.z = pack_bf16x2(st[kt][8 * s + 4], st[kt][8 * s + 5]);
+                        pb.w = pack_bf16x2(st[kt][8 * s + 6], st[kt][8 * s + 7]);
+                        MmaT<T>::run(ot[blk], va, pb);
+                    }
+            } else {
+                const int f = d & 15;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int u = 8 * kt + 2 * q + half;
+                        const uint4 va = *(const uint4*)(vrow + ((u ^ f) * UB));
+                        const float4 pf = make_float4(st[kt][4 * q], st[kt][4 * q + 1], st[kt][4 * q + 2],
+                                                      st[kt][4 * q + 3]);
+                        MmaT<T>::run(ot[blk], va, __builtin_bit_cast(uint4, pf));
+                    }
+            }
+        }
+    }
+
+    // ---- finish: combine the two lane halves' row sums, normalise, store O[q][d]
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < a.Lq) {
+        T* orow = (T*)a.o + (size_t)b * a.o_sb + (size_t)qi * a.o_st + (size_t)h * a.o_sh;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * blk + 8 * g + 4 * half;
+                if (d0 < a.D) {
+                    const float o0 = ot[blk][4 * g] * inv, o1 = ot[blk][4 * g + 1] * inv;
+                    const float o2 = ot[blk][4 * g + 2] * inv, o3 = ot[blk][4 * g + 3] * inv;
+                    if (ES == 2) {
+                        *(uint2*)(orow + d0) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                    } else {
+                        *(float4*)(orow + d0) = make_float4(o0, o1, o2, o3);
+                    }
+                }
+            }
+    }
+}
+
+}  // namespace
+
+int launch_attention(const AttnArgs& a, hipStream_t s) {
+    DIMX_REQUIRE(a.q && a.k && a.vt && a.o, DIMX_ERR_ARG, "attention: null operand");
+    DIMX_REQUIRE(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, DIMX_ERR_ARG, "attention: empty shape");
+    DIMX_REQUIRE(a.D == 48 || a.D == 64, DIMX_ERR_ARG, "attention: head dim %d not in {48,64}", a.D);
+    const int epc = a.dtype == DIMX_BF16 ? 8 : 4;
+    DIMX_REQUIRE(a.v_sd % epc == 0 && a.v_sd >= a.Lk && a.q_st % epc == 0 && a.k_st % epc == 0 && a.o_st % 4 == 0,
+                 DIMX_ERR_ARG, "attention: strides must keep 16-byte alignment (v_sd=%ld)", a.v_sd);
+    constexpr int NW = 2;
+    dim3 grid(ceil_div(a.Lq, 32 * NW), a.H, a.B), block(NW * 64);
+    if (a.dtype == DIMX_BF16)
+        hipLaunchKernelGGL((attn_kernel<bf16, NW>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((attn_kernel<float, NW>), grid, block, 0, s, a);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+}  // namespace dimx

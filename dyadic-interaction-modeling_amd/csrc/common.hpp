@@ -1,0 +1,225 @@
+// common.hpp -- shared host/device helpers for libdimx_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/dimx.h"
+
+namespace dimx {
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define DIMX_HIP(expr)                                                                       \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            dimx::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return DIMX_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+#define DIMX_REQUIRE(cond, code, ...)       \
+    do {                                    \
+        if (!(cond)) {                      \
+            dimx::set_error(__VA_ARGS__);   \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+#define DIMX_TRY(expr)            \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != DIMX_OK) return _s; \
+    } while (0)
+
+// ---------------------------------------------------------------- element types
+struct bf16 {
+    uint16_t x;
+};
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
+    static constexpr int kId = DIMX_F32;
+};
+template <> struct Elem<bf16> {
+    static constexpr int kPerChunk = 8;
+    static constexpr int kId = DIMX_BF16;
+};
+
+inline size_t dtype_size(int dt) { return dt == DIMX_BF16 ? 2 : 4; }
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t u) {
+    return __builtin_bit_cast(float, (uint32_t)u << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+inline uint16_t host_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
+template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_as_f32<bf16>(const bf16* p) { return bf16_to_f32(p->x); }
+
+template <typename T> __device__ __forceinline__ void store_from_f32(T* p, float v);
+template <> __device__ __forceinline__ void store_from_f32<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_from_f32<bf16>(bf16* p, float v) { p->x = f32_to_bf16(v); }
+
+// ---------------------------------------------------------------- activations
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GELU_TANH = 2, ACT_GELU_ERF = 3 };
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_LEAKY: return x > 0.f ? x : 0.2f * x;
+        case ACT_GELU_TANH: {
+            // reference code/utils/base_model_util.py:81-94
+            const float c = 0.7978845608028654f;
+            float inner = c * (x + 0.044715f * (x * x * x));
+            return x * (0.5f * (1.0f + tanhf(inner)));
+        }
+        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- GEMM launcher
+struct OutSeg {
+    void* ptr;
+    long sb, sh, st, sd;  // element strides for (batch row, head, time, channel)
+    int D;                // channels per head inside the segment
+};
+
+struct GemmArgs {
+    int in_dtype, out_dtype;
+    const void* A;
+    int lda;
+    const void* W;
+    int ldw;  // = padded K
+    int M, N, K;
+    // temporal k=5 convolution gather on A (conv_T > 0)
+    int conv_T;
+    const int32_t* conv_lens;
+    int conv_C;
+    // epilogue
+    const float* bias;
+    int act;
+    const float* residual;
+    int ldr;
+    const float* rowadd;  // [rows, ld_rowadd] table added after the activation
+    int rowadd_mode;      // 0 none, 1 row t, 2 row b + rowadd_off, 3 fixed row rowadd_off
+    float rowadd_scale;
+    int rowadd_off, ld_rowadd;
+    // rows decompose as m = b*rowT + t (rowT = 1 -> b = m, t = 0); used by rowadd and the output map
+    int rowT;
+    // output: N columns split into nseg equal segments of seg_width columns; element (m, n) of
+    // segment s goes to seg[s].ptr + b*sb + t*st + (nn / D)*sh + (nn % D)*sd, nn = n - s*seg_width
+    OutSeg seg[3];
+    int nseg, seg_width;
+};
+
+void gemm_args_init(GemmArgs& a);
+// plain row-major output helper
+void gemm_set_plain_out(GemmArgs& a, void* C, int ldc);
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- other launchers
+int launch_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta, int M,
+                     int C, hipStream_t s);
+int launch_instnorm(int out_dtype, const float* x, void* y, const int32_t* lens, int B, int T, int C,
+                    hipStream_t s);
+
+struct AttnArgs {
+    int dtype;
+    const void *q, *k, *vt;
+    void* o;
+    long q_sb, q_st, q_sh;  // q element (b,i,h,d) at q + b*q_sb + i*q_st + h*q_sh + d
+    long k_sb, k_st, k_sh;
+    long v_sb, v_sh, v_sd;  // vt element (b,h,d,j) at vt + b*v_sb + h*v_sh + d*v_sd + j
+    long o_sb, o_st, o_sh;
+    int B, H, Lq, Lk, D;
+    float scale;
+    int causal;
+    const int32_t* lens;   // [B] optional
+    const uint8_t* kmask;  // [B, kmask_ld] optional
+    int kmask_ld;
+};
+int launch_attention(const AttnArgs& a, hipStream_t s);
+
+struct DecodeAttnArgs {
+    int dtype;             // storage type of q / caches / out
+    const void* q;         // [B, q_ld] : head h at h*64
+    int q_ld;
+    const void* knew;      // self-attn: this step's k/v rows [B, *] (nullptr for cross attention)
+    const void* vnew;
+    int kv_ld;
+    void* kcache;          // [B,H,Tmax,64]
+    void* vcache;
+    int Tmax;
+    void* out;             // [B, o_ld]
+    int o_ld;
+    int B, H;
+    const int32_t* step;   // device scalar: self -> number of cached keys before this step
+    int n_keys;            // cross: number of keys (T); self: ignored
+    const uint8_t* kmask;  // cross: [B, kmask_ld] optional
+    int kmask_ld;
+    float scale;
+};
+int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s);
+
+int launch_vq_argmin(const float* z, int N, const float* Et /*[128][512]*/, const float* ee /*[512]*/,
+                     int32_t* idx, float* best_d, float* margin, hipStream_t s);
+
+// elementwise helpers (elementwise.hip)
+int launch_cast_pad(int out_dtype, const float* x, int ldx, const float* coladd, void* y, int ldy, int M, int K,
+                    hipStream_t s);
+int launch_gather_rows(int out_dtype, const float* table, int ld_table, int rows, const int32_t* idx, void* y,
+                       int ldy, int M, int C, hipStream_t s);
+int launch_context_concat(int out_dtype, const float* x_s, const float* patch, const float* audio, void* ctx,
+                          int M, int dim, int dim_a, hipStream_t s);
+int launch_finalize_idx(int32_t* idx, const int32_t* lens, int B, int T, int32_t pad_value, hipStream_t s);
+int launch_shift_tokens(const int32_t* z, int32_t* inp, int32_t* tgt, int B, int T, hipStream_t s);
+int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss, int32_t* argmax_tok, int R,
+                     int V, hipStream_t s);
+int launch_sample(const float* logits, int ld_logits, int R, int top_k, float temperature, const float* noise,
+                  uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
+                  int tok_col_from_step, hipStream_t s);
+int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
+                      const int32_t* step_dev, float* x, int B, hipStream_t s);
+int launch_step_inc(int32_t* step_dev, hipStream_t s);
+int launch_copy_rows_step(const float* src, float* dst, int B, int V, int n, const int32_t* step_dev, hipStream_t s);
+int launch_mask_and(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, hipStream_t s);
+
+}  // namespace dimx

@@ -1,0 +1,355 @@
+// elementwise.hip -- the small HBM-bound kernels that glue the dense stages together: input cast/pad,
+// embedding gathers, context assembly, token bookkeeping, cross-entropy/argmax over the 512-entry
+// vocabulary and the top-k / softmax / noise-argmax sampler of the autoregressive loop.
+#include "common.hpp"
+
+namespace dimx {
+namespace {
+
+// y[m, 0:ldy) = x[m, 0:K) (+ coladd) zero-padded; x is f32 [M, ldx]
+template <typename OutT>
+__global__ void cast_pad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ coladd,
+                                OutT* __restrict__ y, int ldy, int M, int K) {
+    const long total = (long)M * ldy;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ldy), k = (int)(i - (long)m * ldy);
+        float v = 0.f;
+        if (k < K) {
+            v = x[(size_t)m * ldx + k];
+            if (coladd) v += coladd[k];
+        }
+        store_from_f32<OutT>(y + i, v);
+    }
+}
+
+// y[m, :] = table[idx[m], :]   (codebook lookup = the one-hot matmul of
+// code/seq2seq_pretrain.py:457-459; token embedding of the teacher-forced decoder)
+template <typename OutT>
+__global__ void gather_rows_kernel(const float* __restrict__ table, int ld_table, int rows,
+                                   const int32_t* __restrict__ idx, OutT* __restrict__ y, int ldy, int M, int C) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C), c = (int)(i - (long)m * C);
+        int r = idx[m];
+        r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+        store_from_f32<OutT>(y + (size_t)m * ldy + c, table[(size_t)r * ld_table + c]);
+    }
+}
+
+// ctx[m] = cat(x_s[m] + patch_embed_dec_s, audio[m])   (code/seq2seq_pretrain.py:445-446)
+template <typename OutT>
+__global__ void context_concat_kernel(const float* __restrict__ x_s, const float* __restrict__ patch,
+                                      const float* __restrict__ audio, OutT* __restrict__ ctx, int M, int dim,
+                                      int dim_a) {
+    const int W = dim + dim_a;
+    const long total = (long)M * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / W), c = (int)(i - (long)m * W);
+        const float v = c < dim ? x_s[(size_t)m * dim + c] + patch[c] : audio[(size_t)m * dim_a + (c - dim)];
+        store_from_f32<OutT>(ctx + i, v);
+    }
+}
+
+__global__ void finalize_idx_kernel(int32_t* idx, const int32_t* lens, int B, int T, int32_t pad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i - b * T;
+    if (lens && t >= lens[b]) idx[i] = pad;
+}
+
+// AutoregressiveWrapper.forward: inp = z[:, :-1] with ignore_index -> pad_value 0, target = z[:, 1:]
+__global__ void shift_tokens_kernel(const int32_t* z, int32_t* inp, int32_t* tgt, int B, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = T - 1;
+    if (i >= B * n) return;
+    const int b = i / n, t = i - b * n;
+    const int32_t v = z[b * T + t];
+    inp[i] = v == -100 ? 0 : v;
+    tgt[i] = z[b * T + t + 1];
+}
+
+// one wave per row of V = 512 logits: cross entropy against target (0 where target < 0) and argmax
+__global__ __launch_bounds__(256) void ce_argmax_kernel(const float* __restrict__ logits,
+                                                        const int32_t* __restrict__ target,
+                                                        float* __restrict__ row_loss,
+                                                        int32_t* __restrict__ argmax_tok, int R) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* lr = logits + (size_t)row * 512;
+    float v[8];
+    float mx = -3.0e38f;
+    int mi = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        v[c] = lr[lane + 64 * c];
+        if (v[c] > mx) {
+            mx = v[c];
+            mi = lane + 64 * c;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float om = __shfl_xor(mx, o);
+        const int oi = __shfl_xor(mi, o);
+        if (om > mx || (om == mx && oi < mi)) {
+            mx = om;
+            mi = oi;
+        }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) se += expf(v[c] - mx);
+    se = wave_sum(se);
+    if (lane == 0) {
+        if (argmax_tok) argmax_tok[row] = mi;
+        if (row_loss) {
+            const int t = target ? target[row] : -100;
+            row_loss[row] = (t >= 0 && t < 512) ? (mx + logf(se)) - lr[t] : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ uint64_t splitmix(uint64_t key, uint64_t ctr) {
+    uint64_t z = key + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Sampler of AutoregressiveWrapper.generate: top-k filter (k = 52), softmax(T), multinomial.
+// torch.multinomial(p, 1) == argmax(p / q), q ~ Exp(1) (tests/golden/sampler_multinomial.npz), so the
+// noise is an input: injected (parity) or drawn from a counter-based splitmix64 stream (production).
+// One wave per row; the k-th largest logit is found by a 32-step bitwise search on the order-preserving
+// integer image of the floats, counting with ballots.
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int ld, int R, int top_k,
+                                                     float temperature, const float* __restrict__ noise,
+                                                     uint64_t seed, const int32_t* __restrict__ step_dev,
+                                                     uint64_t step_host, int32_t* __restrict__ tokens, int tok_ld,
+                                                     int tok_col_from_step) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const uint64_t step = step_dev ? (uint64_t)*step_dev : step_host;
+    const float* lr = logits + (size_t)row * ld;
+    float v[8];
+    float mx = -3.0e38f;
+    int mi = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        v[c] = lr[lane + 64 * c];
+        if (v[c] > mx) {
+            mx = v[c];
+            mi = lane + 64 * c;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float om = __shfl_xor(mx, o);
+        const int oi = __shfl_xor(mi, o);
+        if (om > mx || (om == mx && oi < mi)) {
+            mx = om;
+            mi = oi;
+        }
+    }
+    const bool greedy = temperature <= 0.f || (noise == nullptr && seed == 0);
+    int tok = mi;
+    if (!greedy) {
+        uint32_t key[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) key[c] = f32_order_key(v[c]);
+        uint32_t thr = 0;
+        if (top_k > 0 && top_k < 512) {
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = thr | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cnt += __popcll(__ballot(key[c] >= cand));
+                if (cnt >= top_k) thr = cand;
+            }
+        }
+        const float inv_t = 1.0f / temperature;
+        float p[8];
+        float zsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            p[c] = key[c] >= thr ? expf((v[c] - mx) * inv_t) : 0.f;
+            zsum += p[c];
+        }
+        zsum = wave_sum(zsum);
+        float best = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int i = lane + 64 * c;
+            float q;
+            if (noise) {
+                q = noise[((size_t)step * R + row) * 512 + i];
+            } else {
+                const uint64_t r = splitmix(seed, ((uint64_t)step * R + row) * 512 + i);
+                const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+                q = fmaxf(-log1pf(-u), 9.313225746154785e-10f);
+            }
+            const float sc = (p[c] / zsum) / q;
+            if (sc > best || (sc == best && i < bi)) {
+                best = sc;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        tok = bi;
+    }
+    if (lane == 0) tokens[(size_t)row * tok_ld + (tok_col_from_step ? (int)step : 0)] = tok;
+}
+
+// x[b, :] = token_emb[tok_b], tok_b = start[b] at step 0 else the token sampled at the previous step
+__global__ __launch_bounds__(256) void embed_step_kernel(const float* __restrict__ table, int C,
+                                                         const int32_t* __restrict__ start,
+                                                         const int32_t* __restrict__ tokens, int tok_ld,
+                                                         const int32_t* __restrict__ step_dev, float* __restrict__ x,
+                                                         int rows) {
+    const int b = blockIdx.x;
+    const int step = *step_dev;
+    int tok = step == 0 ? start[b] : tokens[(size_t)b * tok_ld + step - 1];
+    tok = tok < 0 ? 0 : (tok >= rows ? rows - 1 : tok);
+    const float4* src = (const float4*)(table + (size_t)tok * C);
+    float4* dst = (float4*)(x + (size_t)b * C);
+    for (int i = threadIdx.x; i < C / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ void step_inc_kernel(int32_t* step) { *step += 1; }
+
+// dst[b, step, :] = src[b, :]  (optional per-step logits dump of generate)
+__global__ void copy_rows_step_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int V, int n,
+                                      const int32_t* __restrict__ step_dev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * V) return;
+    const int b = i / V, c = i - b * V;
+    dst[((size_t)b * n + *step_dev) * V + c] = src[i];
+}
+
+__global__ void mask_and_kernel(const uint8_t* a, const uint8_t* b, uint8_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t va = a ? a[i] : 1, vb = b ? b[i] : 1;
+    out[i] = (va && vb) ? 1 : 0;
+}
+
+inline int ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+int launch_cast_pad(int out_dtype, const float* x, int ldx, const float* coladd, void* y, int ldy, int M, int K,
+                    hipStream_t s) {
+    DIMX_REQUIRE(x && y && M > 0 && K > 0 && ldy >= K, DIMX_ERR_ARG, "cast_pad: bad arguments");
+    const int g = ew_blocks((long)M * ldy);
+    if (out_dtype == DIMX_BF16)
+        hipLaunchKernelGGL(cast_pad_kernel<bf16>, dim3(g), dim3(256), 0, s, x, ldx, coladd, (bf16*)y, ldy, M, K);
+    else
+        hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(g), dim3(256), 0, s, x, ldx, coladd, (float*)y, ldy, M, K);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_gather_rows(int out_dtype, const float* table, int ld_table, int rows, const int32_t* idx, void* y,
+                       int ldy, int M, int C, hipStream_t s) {
+    DIMX_REQUIRE(table && idx && y && M > 0 && C > 0, DIMX_ERR_ARG, "gather_rows: bad arguments");
+    const int g = ew_blocks((long)M * C);
+    if (out_dtype == DIMX_BF16)
+        hipLaunchKernelGGL(gather_rows_kernel<bf16>, dim3(g), dim3(256), 0, s, table, ld_table, rows, idx, (bf16*)y,
+                           ldy, M, C);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(g), dim3(256), 0, s, table, ld_table, rows, idx,
+                           (float*)y, ldy, M, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_context_concat(int out_dtype, const float* x_s, const float* patch, const float* audio, void* ctx, int M,
+                          int dim, int dim_a, hipStream_t s) {
+    DIMX_REQUIRE(x_s && patch && audio && ctx && M > 0, DIMX_ERR_ARG, "context_concat: bad arguments");
+    const int g = ew_blocks((long)M * (dim + dim_a));
+    if (out_dtype == DIMX_BF16)
+        hipLaunchKernelGGL(context_concat_kernel<bf16>, dim3(g), dim3(256), 0, s, x_s, patch, audio, (bf16*)ctx, M,
+                           dim, dim_a);
+    else
+        hipLaunchKernelGGL(context_concat_kernel<float>, dim3(g), dim3(256), 0, s, x_s, patch, audio, (float*)ctx, M,
+                           dim, dim_a);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_finalize_idx(int32_t* idx, const int32_t* lens, int B, int T, int32_t pad_value, hipStream_t s) {
+    if (!lens) return DIMX_OK;
+    hipLaunchKernelGGL(finalize_idx_kernel, dim3(ceil_div(B * T, 256)), dim3(256), 0, s, idx, lens, B, T, pad_value);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_shift_tokens(const int32_t* z, int32_t* inp, int32_t* tgt, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(shift_tokens_kernel, dim3(ceil_div(B * (T - 1), 256)), dim3(256), 0, s, z, inp, tgt, B, T);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss, int32_t* argmax_tok, int R, int V,
+                     hipStream_t s) {
+    DIMX_REQUIRE(V == 512, DIMX_ERR_ARG, "ce_argmax: vocabulary %d != 512", V);
+    hipLaunchKernelGGL(ce_argmax_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, logits, target, row_loss, argmax_tok,
+                       R);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_sample(const float* logits, int ld_logits, int R, int top_k, float temperature, const float* noise,
+                  uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
+                  int tok_col_from_step, hipStream_t s) {
+    DIMX_REQUIRE(logits && tokens && R > 0, DIMX_ERR_ARG, "sample: bad arguments");
+    hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, logits, ld_logits, R, top_k,
+                       temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
+                      const int32_t* step_dev, float* x, int B, hipStream_t s) {
+    DIMX_REQUIRE(C % 4 == 0, DIMX_ERR_ARG, "embed_step: C %% 4");
+    hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, table, C, start, tokens, tok_ld, step_dev, x,
+                       rows);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_step_inc(int32_t* step_dev, hipStream_t s) {
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step_dev);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_copy_rows_step(const float* src, float* dst, int B, int V, int n, const int32_t* step_dev, hipStream_t s) {
+    hipLaunchKernelGGL(copy_rows_step_kernel, dim3(ceil_div(B * V, 256)), dim3(256), 0, s, src, dst, B, V, n, step_dev);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_mask_and(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(mask_and_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, a, b, out, n);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+}  // namespace dimx

@@ -1,0 +1,279 @@
+// gemm.hip -- C = epilogue(A[M,K] . W[N,K]^T) on the gfx950 matrix cores.
+//
+// One kernel template serves every dense op of the path (reference: nn.Linear / nn.Conv1d calls in
+// code/models/stage1_BIWI.py:258-393, code/models/lib/base_models.py:43-146 and the x-transformers
+// Attention/FeedForward projections constructed at code/seq2seq_pretrain.py:388-418):
+//   * T = bf16  -> v_mfma_f32_32x32x16_bf16 (perf mode), T = float -> v_mfma_f32_32x32x2_f32
+//     (parity mode: exact f32 products, f32 accumulate).
+//   * A and W tiles are staged global -> registers -> LDS as 16-byte chunks; an LDS row holds 128 bytes
+//     of K (64 bf16 / 32 f32) and chunk c of row r is stored at slot c ^ ((r>>1)&7) so that the
+//     ds_read_b128 fragment reads (32 different rows, same chunk) are bank-conflict free.
+//   * a lane's 16-byte fragment feeds 1 bf16 MFMA (K=16) or 4 f32 MFMAs (K=2 each; the two lane halves
+//     hold k and k+4 -- a k-permutation that leaves the sum unchanged).
+//   * double-buffered LDS, next tile's global loads are issued before the MFMAs of the current tile.
+//   * CONV: the A operand is gathered on the fly for the k=5 replicate-padded temporal convolution
+//     (K = 5*C, W repacked tap-major), rows clamp inside their own clip [0, len_b).
+//   * epilogue: bias, LeakyReLU / GELU, positional row add, f32 residual, and a strided scatter that
+//     can write row-major activations, head-major K/V caches or the transposed V^T the attention
+//     kernel consumes.
+#include "common.hpp"
+
+namespace dimx {
+
+void gemm_args_init(GemmArgs& a) {
+    memset(&a, 0, sizeof(a));
+    a.in_dtype = DIMX_F32;
+    a.out_dtype = DIMX_F32;
+    a.rowadd_scale = 1.f;
+    a.nseg = 1;
+    a.rowT = 1;
+}
+
+void gemm_set_plain_out(GemmArgs& a, void* C, int ldc) {
+    a.nseg = 1;
+    a.seg_width = a.N;
+    a.seg[0].ptr = C;
+    a.seg[0].sb = (long)ldc * a.rowT;
+    a.seg[0].st = ldc;
+    a.seg[0].sh = 0;
+    a.seg[0].sd = 1;
+    a.seg[0].D = a.N > 0 ? a.N : 1;
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+        const float4 fa = __builtin_bit_cast(float4, a), fb = __builtin_bit_cast(float4, b);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + (((kc ^ (row >> 1)) & 7) << 4); }
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs a) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int BK = 8 * EPC;
+    constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * 128];
+
+    const int tid = threadIdx.x;
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const T* __restrict__ A = (const T*)a.A;
+    const T* __restrict__ W = (const T*)a.W;
+
+    // ---- per-thread chunk descriptors
+    int a_lds[CA], w_lds[CB];
+    size_t a_base[CA], w_base[CB];
+    bool a_ok[CA], w_ok[CB];
+    int a_kc[CA];
+    int a_b[CA], a_t[CA], a_len[CA];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        const int c = tid + i * NT, row = c >> 3, kc = c & 7;
+        const int m = m0 + row;
+        a_ok[i] = m < a.M;
+        const int mc = a_ok[i] ? m : a.M - 1;
+        a_kc[i] = kc * EPC;
+        a_lds[i] = lds_off(row, kc);
+        if (CONV) {
+            a_b[i] = mc / a.conv_T;
+            a_t[i] = mc - a_b[i] * a.conv_T;
+            int len = a.conv_lens ? a.conv_lens[a_b[i]] : a.conv_T;
+            a_len[i] = len < 1 ? 1 : (len > a.conv_T ? a.conv_T : len);
+            a_base[i] = 0;
+        } else {
+            a_base[i] = (size_t)mc * a.lda + kc * EPC;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int c = tid + i * NT, row = c >> 3, kc = c & 7;
+        const int n = n0 + row;
+        w_ok[i] = n < a.N;
+        w_base[i] = (size_t)(w_ok[i] ? n : a.N - 1) * a.ldw + kc * EPC;
+        w_lds[i] = BM * 128 + lds_off(row, kc);
+    }
+
+    uint4 ra[CA], rw[CB];
+    auto gload = [&](int k0) {
+        int tap = 0, cbase = k0;
+        if (CONV) {
+            tap = k0 / a.conv_C;
+            cbase = k0 - tap * a.conv_C;
+        }
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const bool ok = a_ok[i] && (k0 + a_kc[i] < a.K);
+            const T* p;
+            if (CONV) {
+                int tt = a_t[i] + tap - 2;
+                tt = tt < 0 ? 0 : (tt > a_len[i] - 1 ? a_len[i] - 1 : tt);
+                p = A + ((size_t)a_b[i] * a.conv_T + tt) * a.lda + cbase + a_kc[i];
+            } else {
+                p = A + a_base[i] + k0;
+            }
+            ra[i] = ok ? *(const uint4*)p : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            rw[i] = w_ok[i] ? *(const uint4*)(W + w_base[i] + k0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) *(uint4*)(&smem[buf][a_lds[i]]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < CB; ++i) *(uint4*)(&smem[buf][w_lds[i]]) = rw[i];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    f32x16_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.ldw / BK;  // W is padded to a multiple of BK
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const unsigned char* sA = &smem[cur][0];
+        const unsigned char* sW = &smem[cur][BM * 128];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kc = 2 * ks + half;
+            uint4 fa[MI], fw[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *(const uint4*)(sA + lds_off(wm * MI * 32 + i * 32 + l31, kc));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fw[j] = *(const uint4*)(sW + lds_off(wn * NI * 32 + j * 32 + l31, kc));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], fa[i], fw[j]);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const int rowT = a.rowT;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * NI * 32 + j * 32 + l31;
+        if (n >= a.N) continue;
+        const float bias_v = a.bias ? a.bias[n] : 0.f;
+        int s = 0, nn = n;
+        if (a.nseg > 1) {
+            s = n / a.seg_width;
+            nn = n - s * a.seg_width;
+        }
+        const OutSeg sg = a.seg[s];
+        const int hh = nn / sg.D, dd = nn - hh * sg.D;
+        OutT* obase = (OutT*)sg.ptr + (long)hh * sg.sh + (long)dd * sg.sd;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mb = m0 + wm * MI * 32 + i * 32 + 4 * half;
+            int b0, t0;
+            if (rowT == 1) {
+                b0 = mb;
+                t0 = 0;
+            } else {
+                b0 = mb / rowT;
+                t0 = mb - b0 * rowT;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                const int m = mb + off;
+                if (m >= a.M) continue;
+                int b = b0, t = t0;
+                if (rowT == 1) {
+                    b = m;
+                } else {
+                    t += off;
+                    while (t >= rowT) {
+                        t -= rowT;
+                        ++b;
+                    }
+                }
+                float v = apply_act(acc[i][j][r] + bias_v, a.act);
+                if (a.rowadd_mode) {
+                    const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b + a.rowadd_off : a.rowadd_off);
+                    v += a.rowadd[(size_t)ri * a.ld_rowadd + n] * a.rowadd_scale;
+                }
+                if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
+                store_from_f32<OutT>(obase + (long)b * sg.sb + (long)t * sg.st, v);
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmArgs& a, hipStream_t s) {
+    const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
+    dim3 grid(tiles), block(WM * WN * 64);
+    if (a.conv_T > 0)
+        hipLaunchKernelGGL((gemm_kernel<T, OutT, BM, BN, WM, WN, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_kernel<T, OutT, BM, BN, WM, WN, false>), grid, block, 0, s, a);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+template <typename T, typename OutT> static int launch_typed(const GemmArgs& a, hipStream_t s) {
+    // large-M (prefill / teacher-forced / VQ stacks): 128x128 tiles; small M (decode steps): 64x64.
+    const long tiles128 = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
+    if (tiles128 >= 256) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
+    return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t s) {
+    const int epc = a.in_dtype == DIMX_BF16 ? 8 : 4;
+    const int bk = 8 * epc;
+    const size_t es = dtype_size(a.in_dtype);
+    DIMX_REQUIRE(a.A && a.W && a.M > 0 && a.N > 0 && a.K > 0, DIMX_ERR_ARG, "gemm: null operand or empty shape");
+    DIMX_REQUIRE(a.ldw % bk == 0 && a.ldw >= a.K, DIMX_ERR_ARG, "gemm: W must be K-padded to %d (ldw=%d K=%d)", bk,
+                 a.ldw, a.K);
+    DIMX_REQUIRE((a.lda * es) % 16 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, DIMX_ERR_ARG,
+                 "gemm: A/W rows must be 16-byte aligned (lda=%d)", a.lda);
+    DIMX_REQUIRE(a.K % epc == 0, DIMX_ERR_ARG, "gemm: K=%d must be a multiple of %d", a.K, epc);
+    DIMX_REQUIRE(a.rowT >= 1 && a.nseg >= 1 && a.nseg <= 3 && a.seg_width > 0, DIMX_ERR_ARG, "gemm: bad output map");
+    if (a.conv_T > 0) {
+        DIMX_REQUIRE(a.conv_C % bk == 0 && a.K == 5 * a.conv_C && a.M % a.conv_T == 0, DIMX_ERR_ARG,
+                     "gemm(conv5): C=%d must be a multiple of %d, K=5C, M %% T == 0", a.conv_C, bk);
+    }
+    for (int i = 0; i < a.nseg; ++i)
+        DIMX_REQUIRE(a.seg[i].ptr && a.seg[i].D > 0, DIMX_ERR_ARG, "gemm: output segment %d unset", i);
+    if (a.in_dtype == DIMX_BF16) {
+        if (a.out_dtype == DIMX_BF16) return launch_typed<bf16, bf16>(a, s);
+        return launch_typed<bf16, float>(a, s);
+    }
+    DIMX_REQUIRE(a.out_dtype == DIMX_F32, DIMX_ERR_ARG, "gemm: f32 inputs produce f32 outputs");
+    return launch_typed<float, float>(a, s);
+}
+
+}  // namespace dimx

@@ -1,0 +1,1198 @@
+// model.hip -- handle, weight packing and the stage-level entry points of libdimx_hip.
+//
+// Stage <-> reference map (paths relative to /root/reference):
+//   vq_encode   : SLMFT.forward_vq / VQAutoEncoder.encode      code/seq2seq_pretrain.py:480-494,
+//                                                               code/models/stage1_BIWI.py:22-27,307-317
+//   vq_decode   : forward_vq_decoder / VQAutoEncoder.decode     code/seq2seq_pretrain.py:454-464,
+//                                                               code/models/stage1_BIWI.py:29-37,376-393
+//   encode_ctx  : forward_encoder + context concat              code/seq2seq_pretrain.py:431-446
+//   decode_tf   : AutoregressiveWrapper.forward                 code/seq2seq_pretrain.py:448
+//   generate    : AutoregressiveWrapper.generate                code/seq2seq_pretrain.py:450
+// The per-sample Python loop of forward_vq becomes one batched launch sequence over ragged clips
+// (per-clip length vectors instead of batch-1 calls); the one-hot matmul of forward_vq_decoder becomes
+// a gather; the T-1 sequential decoder steps are one captured hipGraph replayed T-1 times with a
+// device-resident step counter.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "model.hpp"
+
+namespace dimx {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ------------------------------------------------------------------ key names
+static std::string vq_prefix(int which) { return which == 0 ? "speaker_vq." : "listener_vq."; }
+
+struct KeySpec {
+    std::string name;
+    std::vector<int64_t> shape;
+};
+
+static void vq_keys(const dimx_dims& d, int which, std::vector<KeySpec>& out) {
+    const int64_t H = d.vq_hidden, I = d.vq_inter;
+    const std::string p = vq_prefix(which);
+    auto stack = [&](const std::string& pre) {
+        for (int i = 0; i < d.vq_layers; ++i) {
+            const std::string a = pre + "net." + std::to_string(2 * i) + ".fn.";
+            out.push_back({a + "norm.weight", {H}});
+            out.push_back({a + "norm.bias", {H}});
+            out.push_back({a + "fn.to_qkv.weight", {3 * H, H}});
+            out.push_back({a + "fn.to_out.weight", {H, H}});
+            out.push_back({a + "fn.to_out.bias", {H}});
+            const std::string m = pre + "net." + std::to_string(2 * i + 1) + ".fn.";
+            out.push_back({m + "norm.weight", {H}});
+            out.push_back({m + "norm.bias", {H}});
+            out.push_back({m + "fn.l1.weight", {I, H}});
+            out.push_back({m + "fn.l1.bias", {I}});
+            out.push_back({m + "fn.l2.weight", {H, I}});
+            out.push_back({m + "fn.l2.bias", {H}});
+        }
+    };
+    const std::string e = p + "encoder.", c = p + "decoder.";
+    out.push_back({e + "vertice_mapping.0.weight", {H, d.vq_in_dim}});
+    out.push_back({e + "vertice_mapping.0.bias", {H}});
+    out.push_back({e + "squasher.0.0.weight", {H, H, 5}});
+    out.push_back({e + "squasher.0.0.bias", {H}});
+    stack(e + "encoder_transformer.");
+    out.push_back({e + "encoder_pos_embedding.pe", {5000, 1, H}});
+    out.push_back({e + "encoder_linear_embedding.net.weight", {H, H}});
+    out.push_back({e + "encoder_linear_embedding.net.bias", {H}});
+    out.push_back({e + "encoder_linear_embedding_post.net.weight", {d.vq_zdim, H}});
+    out.push_back({e + "encoder_linear_embedding_post.net.bias", {d.vq_zdim}});
+    out.push_back({c + "expander.0.0.weight", {H, H, 5}});
+    out.push_back({c + "expander.0.0.bias", {H}});
+    stack(c + "decoder_transformer.");
+    out.push_back({c + "decoder_pos_embedding.pe", {5000, 1, H}});
+    out.push_back({c + "decoder_linear_embedding.net.weight", {H, H}});
+    out.push_back({c + "decoder_linear_embedding.net.bias", {H}});
+    out.push_back({c + "decoder_linear_embedding_pre.net.weight", {H, d.vq_zdim}});
+    out.push_back({c + "decoder_linear_embedding_pre.net.bias", {H}});
+    out.push_back({c + "vertice_map_reverse.weight", {d.vq_in_dim, H}});
+    out.push_back({p + "quantize.embedding.weight", {d.vq_n_embed, d.vq_zdim}});
+}
+
+static std::string xl(const std::string& pre, int li) { return pre + "attn_layers.layers." + std::to_string(li) + "."; }
+
+static void xattn_keys(const std::string& p, int64_t dim, int64_t inner, std::vector<KeySpec>& out) {
+    out.push_back({p + "0.0.weight", {dim}});
+    out.push_back({p + "1.to_q.weight", {inner, dim}});
+    out.push_back({p + "1.to_k.weight", {inner, dim}});
+    out.push_back({p + "1.to_v.weight", {inner, dim}});
+    out.push_back({p + "1.to_out.weight", {dim, inner}});
+}
+static void xff_keys(const std::string& p, int64_t dim, int64_t mult, std::vector<KeySpec>& out) {
+    out.push_back({p + "0.0.weight", {dim}});
+    out.push_back({p + "1.ff.0.0.weight", {dim * mult, dim}});
+    out.push_back({p + "1.ff.0.0.bias", {dim * mult}});
+    out.push_back({p + "1.ff.2.weight", {dim, dim * mult}});
+    out.push_back({p + "1.ff.2.bias", {dim}});
+}
+static void xenc_keys(const dimx_dims& d, const std::string& pre, int64_t dim_in, std::vector<KeySpec>& out) {
+    const int64_t inner = (int64_t)d.heads * d.dim_head;
+    out.push_back({pre + "project_in.weight", {d.dim, dim_in}});
+    out.push_back({pre + "pos_emb.emb.weight", {d.max_seq_len, d.dim}});
+    for (int i = 0; i < d.enc_depth; ++i) {
+        xattn_keys(xl(pre, 2 * i), d.dim, inner, out);
+        xff_keys(xl(pre, 2 * i + 1), d.dim, d.ff_mult, out);
+    }
+    out.push_back({pre + "attn_layers.final_norm.weight", {d.dim}});
+}
+static void xdec_keys(const dimx_dims& d, const std::string& pre, std::vector<KeySpec>& out) {
+    const int64_t D = d.dim + d.dim_a, inner = (int64_t)d.heads * d.dim_head;
+    out.push_back({pre + "token_emb.emb.weight", {d.num_tokens, D}});
+    for (int i = 0; i < d.dec_depth; ++i) {
+        xattn_keys(xl(pre, 3 * i), D, inner, out);
+        xattn_keys(xl(pre, 3 * i + 1), D, inner, out);
+        xff_keys(xl(pre, 3 * i + 2), D, d.ff_mult, out);
+    }
+    out.push_back({pre + "attn_layers.final_norm.weight", {D}});
+    out.push_back({pre + "to_logits.weight", {d.num_tokens, D}});
+}
+
+static std::vector<KeySpec> all_keys(const dimx_dims& d) {
+    std::vector<KeySpec> k;
+    vq_keys(d, 0, k);
+    vq_keys(d, 1, k);
+    xenc_keys(d, "encoder_s.", d.dim_in, k);
+    xenc_keys(d, "encoder_joint.", d.dim, k);
+    xdec_keys(d, "decoder_joint.net.", k);
+    k.push_back({"patch_embed_s", {1, 1, d.dim_in}});
+    k.push_back({"patch_embed_dec_s", {1, 1, d.dim}});
+    k.push_back({"norm_s.weight", {d.dim}});
+    k.push_back({"norm_s.bias", {d.dim}});
+    return k;
+}
+
+static bool ignorable_key(const std::string& n) {
+    static const char* pre[] = {"encoder_l.", "norm_l.", "norm.", "patch_embed_l", "patch_embed_dec_l"};
+    for (const char* p : pre)
+        if (n.rfind(p, 0) == 0) return true;
+    const std::string suf = ".project_out.weight";
+    return n.size() >= suf.size() && n.compare(n.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+// ------------------------------------------------------------------ packing
+static int dev_upload(dimx_ctx* c, const void* src, size_t bytes, void** out) {
+    void* p = nullptr;
+    DIMX_HIP(hipMalloc(&p, bytes < 16 ? 16 : bytes));
+    c->dev_allocs.push_back(p);
+    DIMX_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *out = p;
+    return DIMX_OK;
+}
+
+static int upload_f32(dimx_ctx* c, const std::string& name, const float** out) {
+    auto it = c->host.find(name);
+    DIMX_REQUIRE(it != c->host.end(), DIMX_ERR_WEIGHT, "missing weight %s", name.c_str());
+    void* p;
+    DIMX_TRY(dev_upload(c, it->second.data.data(), it->second.data.size() * 4, &p));
+    *out = (const float*)p;
+    return DIMX_OK;
+}
+
+// rows of `parts` concatenated; conv = true permutes [N][C][5] -> [N][5][C]
+static int pack_linear(dimx_ctx* c, const std::vector<std::string>& parts, const std::string& bias, bool conv,
+                       Linear* out) {
+    const int bk = c->at == DIMX_BF16 ? 64 : 32;
+    int N = 0, K = -1;
+    for (const auto& n : parts) {
+        auto it = c->host.find(n);
+        DIMX_REQUIRE(it != c->host.end(), DIMX_ERR_WEIGHT, "missing weight %s", n.c_str());
+        const auto& sh = it->second.shape;
+        const int k = conv ? (int)(sh[1] * sh[2]) : (int)sh[1];
+        DIMX_REQUIRE(K < 0 || K == k, DIMX_ERR_WEIGHT, "fused parts of %s disagree on K", n.c_str());
+        K = k;
+        N += (int)sh[0];
+    }
+    const int Kp = (K + bk - 1) / bk * bk;
+    std::vector<float> w((size_t)N * Kp, 0.f);
+    int row = 0;
+    for (const auto& n : parts) {
+        const HostTensor& t = c->host[n];
+        const int rows = (int)t.shape[0];
+        if (conv) {
+            const int C = (int)t.shape[1];
+            for (int r = 0; r < rows; ++r)
+                for (int ci = 0; ci < C; ++ci)
+                    for (int j = 0; j < 5; ++j)
+                        w[(size_t)(row + r) * Kp + j * C + ci] = t.data[((size_t)r * C + ci) * 5 + j];
+        } else {
+            for (int r = 0; r < rows; ++r)
+                memcpy(&w[(size_t)(row + r) * Kp], &t.data[(size_t)r * K], (size_t)K * 4);
+        }
+        row += rows;
+    }
+    void* p;
+    if (c->at == DIMX_BF16) {
+        std::vector<uint16_t> wb(w.size());
+        for (size_t i = 0; i < w.size(); ++i) wb[i] = host_f32_to_bf16(w[i]);
+        DIMX_TRY(dev_upload(c, wb.data(), wb.size() * 2, &p));
+    } else {
+        DIMX_TRY(dev_upload(c, w.data(), w.size() * 4, &p));
+    }
+    out->w = p;
+    out->N = N;
+    out->K = K;
+    out->Kp = Kp;
+    out->bias = nullptr;
+    if (!bias.empty()) DIMX_TRY(upload_f32(c, bias, &out->bias));
+    return DIMX_OK;
+}
+
+static int pack_vq(dimx_ctx* c, int which) {
+    VQNet& v = c->vq[which];
+    const std::string p = vq_prefix(which), e = p + "encoder.", d = p + "decoder.";
+    DIMX_TRY(pack_linear(c, {e + "vertice_mapping.0.weight"}, e + "vertice_mapping.0.bias", false, &v.vm));
+    DIMX_TRY(pack_linear(c, {e + "squasher.0.0.weight"}, e + "squasher.0.0.bias", true, &v.conv));
+    DIMX_TRY(pack_linear(c, {e + "encoder_linear_embedding.net.weight"}, e + "encoder_linear_embedding.net.bias", false, &v.le));
+    DIMX_TRY(pack_linear(c, {e + "encoder_linear_embedding_post.net.weight"}, e + "encoder_linear_embedding_post.net.bias", false, &v.post));
+    DIMX_TRY(pack_linear(c, {d + "decoder_linear_embedding_pre.net.weight"}, d + "decoder_linear_embedding_pre.net.bias", false, &v.pre));
+    DIMX_TRY(pack_linear(c, {d + "expander.0.0.weight"}, d + "expander.0.0.bias", true, &v.dconv));
+    DIMX_TRY(pack_linear(c, {d + "decoder_linear_embedding.net.weight"}, d + "decoder_linear_embedding.net.bias", false, &v.dle));
+    DIMX_TRY(pack_linear(c, {d + "vertice_map_reverse.weight"}, "", false, &v.rev));
+    for (int s = 0; s < 2; ++s) {
+        const std::string pre = s == 0 ? e + "encoder_transformer." : d + "decoder_transformer.";
+        VQBlock* blk = s == 0 ? v.enc : v.dec;
+        for (int i = 0; i < c->d.vq_layers; ++i) {
+            const std::string a = pre + "net." + std::to_string(2 * i) + ".fn.";
+            const std::string m = pre + "net." + std::to_string(2 * i + 1) + ".fn.";
+            DIMX_TRY(upload_f32(c, a + "norm.weight", &blk[i].ln1_g));
+            DIMX_TRY(upload_f32(c, a + "norm.bias", &blk[i].ln1_b));
+            DIMX_TRY(pack_linear(c, {a + "fn.to_qkv.weight"}, "", false, &blk[i].qkv));
+            DIMX_TRY(pack_linear(c, {a + "fn.to_out.weight"}, a + "fn.to_out.bias", false, &blk[i].out));
+            DIMX_TRY(upload_f32(c, m + "norm.weight", &blk[i].ln2_g));
+            DIMX_TRY(upload_f32(c, m + "norm.bias", &blk[i].ln2_b));
+            DIMX_TRY(pack_linear(c, {m + "fn.l1.weight"}, m + "fn.l1.bias", false, &blk[i].l1));
+            DIMX_TRY(pack_linear(c, {m + "fn.l2.weight"}, m + "fn.l2.bias", false, &blk[i].l2));
+        }
+    }
+    DIMX_TRY(upload_f32(c, e + "encoder_pos_embedding.pe", &v.pe_enc));
+    DIMX_TRY(upload_f32(c, d + "decoder_pos_embedding.pe", &v.pe_dec));
+    DIMX_TRY(upload_f32(c, p + "quantize.embedding.weight", &v.E));
+    // k-major codebook + squared norms (k-ascending fmaf chain, mirrored by oracle/vq_argmin.c)
+    const HostTensor& E = c->host[p + "quantize.embedding.weight"];
+    const int ne = c->d.vq_n_embed, zd = c->d.vq_zdim;
+    std::vector<float> Et((size_t)zd * ne), ee(ne);
+    for (int j = 0; j < ne; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < zd; ++k) {
+            const float x = E.data[(size_t)j * zd + k];
+            Et[(size_t)k * ne + j] = x;
+            s = fmaf(x, x, s);
+        }
+        ee[j] = s;
+    }
+    void* pp;
+    DIMX_TRY(dev_upload(c, Et.data(), Et.size() * 4, &pp));
+    v.Et = (const float*)pp;
+    DIMX_TRY(dev_upload(c, ee.data(), ee.size() * 4, &pp));
+    v.ee = (const float*)pp;
+    return DIMX_OK;
+}
+
+static int pack_xattn(dimx_ctx* c, const std::string& p, bool cross, XAttn* a) {
+    DIMX_TRY(upload_f32(c, p + "0.0.weight", &a->ln_g));
+    if (cross) {
+        DIMX_TRY(pack_linear(c, {p + "1.to_q.weight"}, "", false, &a->qkv));
+        DIMX_TRY(pack_linear(c, {p + "1.to_k.weight", p + "1.to_v.weight"}, "", false, &a->kv));
+    } else {
+        DIMX_TRY(pack_linear(c, {p + "1.to_q.weight", p + "1.to_k.weight", p + "1.to_v.weight"}, "", false, &a->qkv));
+    }
+    DIMX_TRY(pack_linear(c, {p + "1.to_out.weight"}, "", false, &a->out));
+    return DIMX_OK;
+}
+static int pack_xff(dimx_ctx* c, const std::string& p, XFF* f) {
+    DIMX_TRY(upload_f32(c, p + "0.0.weight", &f->ln_g));
+    DIMX_TRY(pack_linear(c, {p + "1.ff.0.0.weight"}, p + "1.ff.0.0.bias", false, &f->f1));
+    DIMX_TRY(pack_linear(c, {p + "1.ff.2.weight"}, p + "1.ff.2.bias", false, &f->f2));
+    return DIMX_OK;
+}
+static int pack_xenc(dimx_ctx* c, const std::string& pre, XEnc* e) {
+    DIMX_TRY(pack_linear(c, {pre + "project_in.weight"}, "", false, &e->proj_in));
+    DIMX_TRY(upload_f32(c, pre + "pos_emb.emb.weight", &e->pos_emb));
+    for (int i = 0; i < c->d.enc_depth; ++i) {
+        DIMX_TRY(pack_xattn(c, xl(pre, 2 * i), false, &e->attn[i]));
+        DIMX_TRY(pack_xff(c, xl(pre, 2 * i + 1), &e->ff[i]));
+    }
+    DIMX_TRY(upload_f32(c, pre + "attn_layers.final_norm.weight", &e->final_g));
+    return DIMX_OK;
+}
+
+static void free_packed(dimx_ctx* c) {
+    for (void* p : c->dev_allocs) (void)hipFree(p);
+    c->dev_allocs.clear();
+    c->packed = false;
+}
+
+static int ensure_packed(dimx_ctx* c) {
+    if (c->packed) return DIMX_OK;
+    int missing = 0;
+    std::string first;
+    for (const auto& k : c->required)
+        if (!c->host.count(k)) {
+            if (!missing) first = k;
+            ++missing;
+        }
+    DIMX_REQUIRE(missing == 0, DIMX_ERR_WEIGHT, "%d hot-path weights not loaded (first: %s)", missing, first.c_str());
+    DIMX_HIP(hipSetDevice(c->device));
+    free_packed(c);
+    DIMX_TRY(pack_vq(c, 0));
+    DIMX_TRY(pack_vq(c, 1));
+    DIMX_TRY(pack_xenc(c, "encoder_s.", &c->enc_s));
+    DIMX_TRY(pack_xenc(c, "encoder_joint.", &c->enc_joint));
+    const std::string dp = "decoder_joint.net.";
+    DIMX_TRY(upload_f32(c, dp + "token_emb.emb.weight", &c->dec.tok_emb));
+    for (int i = 0; i < c->d.dec_depth; ++i) {
+        DIMX_TRY(pack_xattn(c, xl(dp, 3 * i), false, &c->dec.self_[i]));
+        DIMX_TRY(pack_xattn(c, xl(dp, 3 * i + 1), true, &c->dec.cross[i]));
+        DIMX_TRY(pack_xff(c, xl(dp, 3 * i + 2), &c->dec.ff[i]));
+    }
+    DIMX_TRY(upload_f32(c, dp + "attn_layers.final_norm.weight", &c->dec.final_g));
+    DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, "", false, &c->dec.logits));
+    DIMX_TRY(upload_f32(c, "patch_embed_s", &c->patch_s));
+    DIMX_TRY(upload_f32(c, "patch_embed_dec_s", &c->patch_dec_s));
+    DIMX_TRY(upload_f32(c, "norm_s.weight", &c->norm_s_g));
+    DIMX_TRY(upload_f32(c, "norm_s.bias", &c->norm_s_b));
+    c->packed = true;
+    c->graph_valid = false;
+    return DIMX_OK;
+}
+
+// ------------------------------------------------------------------ small helpers
+static inline size_t es_of(const dimx_ctx* c) { return dtype_size(c->at); }
+static inline int tpad(int T) { return (T + 7) / 8 * 8; }
+
+static int gemm_lin(const dimx_ctx* c, const void* A, int lda, const Linear& L, int M, GemmArgs& g) {
+    gemm_args_init(g);
+    g.in_dtype = c->at;
+    g.A = A;
+    g.lda = lda;
+    g.W = L.w;
+    g.ldw = L.Kp;
+    g.M = M;
+    g.N = L.N;
+    g.K = L.K;
+    g.bias = L.bias;
+    return DIMX_OK;
+}
+
+// q / k row-major [M, segw], v transposed [B,H,D,Tp]
+static void set_qkv_out(GemmArgs& g, void* q, void* k, void* vt, int T, int H, int D, int Tp) {
+    const int segw = H * D;
+    g.rowT = T;
+    g.nseg = 3;
+    g.seg_width = segw;
+    for (int i = 0; i < 2; ++i) {
+        g.seg[i].ptr = i == 0 ? q : k;
+        g.seg[i].sb = (long)T * segw;
+        g.seg[i].st = segw;
+        g.seg[i].sh = D;
+        g.seg[i].sd = 1;
+        g.seg[i].D = D;
+    }
+    g.seg[2].ptr = vt;
+    g.seg[2].sb = (long)H * D * Tp;
+    g.seg[2].sh = (long)D * Tp;
+    g.seg[2].sd = Tp;
+    g.seg[2].st = 1;
+    g.seg[2].D = D;
+}
+
+static void set_attn_packed(AttnArgs& a, int dtype, const void* q, const void* k, const void* vt, void* o, int B,
+                            int H, int Lq, int Lk, int D, int Tp_k) {
+    memset(&a, 0, sizeof(a));
+    const int segw = H * D;
+    a.dtype = dtype;
+    a.q = q;
+    a.k = k;
+    a.vt = vt;
+    a.o = o;
+    a.q_sb = (long)Lq * segw;
+    a.q_st = segw;
+    a.q_sh = D;
+    a.k_sb = (long)Lk * segw;
+    a.k_st = segw;
+    a.k_sh = D;
+    a.v_sb = (long)H * D * Tp_k;
+    a.v_sh = (long)D * Tp_k;
+    a.v_sd = Tp_k;
+    a.o_sb = (long)Lq * segw;
+    a.o_st = segw;
+    a.o_sh = D;
+    a.B = B;
+    a.H = H;
+    a.Lq = Lq;
+    a.Lk = Lk;
+    a.D = D;
+}
+
+// ------------------------------------------------------------------ VQ-VAE stacks
+struct VQScratch {
+    void *xa, *h1, *y, *q, *k, *vt, *o, *f;
+    float *conv, *h, *z;
+    int32_t* idx_tmp;
+};
+
+static void plan_vq(const dimx_ctx* c, Arena& ar, int B, int T, VQScratch& s) {
+    const size_t M = (size_t)B * T, es = es_of(c);
+    const int H = c->d.vq_hidden, I = c->d.vq_inter, Tp = tpad(T);
+    s.xa = ar.take(M * 128 * es);  // padded input (56 -> 64) or codebook rows (128)
+    s.h1 = ar.take(M * H * es);
+    s.conv = (float*)ar.take(M * H * 4);
+    s.y = ar.take(M * H * es);
+    s.h = (float*)ar.take(M * H * 4);
+    s.q = ar.take(M * H * es);
+    s.k = ar.take(M * H * es);
+    s.vt = ar.take((size_t)B * H * Tp * es);
+    s.o = ar.take(M * H * es);
+    s.f = ar.take(M * I * es);
+    s.z = (float*)ar.take(M * c->d.vq_zdim * 4);
+    s.idx_tmp = (int32_t*)ar.take(M * 4);
+}
+
+static int run_vq_blocks(const dimx_ctx* c, const VQBlock* blk, VQScratch& s, int B, int T, const int32_t* lens,
+                         hipStream_t st) {
+    const int M = B * T, Hd = c->d.vq_hidden, heads = c->d.vq_heads, D = Hd / heads, Tp = tpad(T);
+    const float scale = 1.0f / sqrtf((float)Hd);  // hidden^-0.5 (code/models/lib/base_models.py:116)
+    for (int l = 0; l < c->d.vq_layers; ++l) {
+        const VQBlock& b = blk[l];
+        GemmArgs g;
+        DIMX_TRY(launch_layernorm(c->at, s.h, s.y, b.ln1_g, b.ln1_b, M, Hd, st));
+        gemm_lin(c, s.y, Hd, b.qkv, M, g);
+        g.out_dtype = c->at;
+        set_qkv_out(g, s.q, s.k, s.vt, T, heads, D, Tp);
+        DIMX_TRY(launch_gemm(g, st));
+        AttnArgs a;
+        set_attn_packed(a, c->at, s.q, s.k, s.vt, s.o, B, heads, T, T, D, Tp);
+        a.scale = scale;
+        a.lens = lens;
+        DIMX_TRY(launch_attention(a, st));
+        gemm_lin(c, s.o, Hd, b.out, M, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.h;
+        g.ldr = Hd;
+        gemm_set_plain_out(g, s.h, Hd);
+        DIMX_TRY(launch_gemm(g, st));
+        DIMX_TRY(launch_layernorm(c->at, s.h, s.y, b.ln2_g, b.ln2_b, M, Hd, st));
+        gemm_lin(c, s.y, Hd, b.l1, M, g);
+        g.out_dtype = c->at;
+        g.act = ACT_GELU_TANH;
+        gemm_set_plain_out(g, s.f, c->d.vq_inter);
+        DIMX_TRY(launch_gemm(g, st));
+        gemm_lin(c, s.f, c->d.vq_inter, b.l2, M, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.h;
+        g.ldr = Hd;
+        gemm_set_plain_out(g, s.h, Hd);
+        DIMX_TRY(launch_gemm(g, st));
+    }
+    return DIMX_OK;
+}
+
+// conv(k5, replicate) + LeakyReLU -> InstanceNorm -> Linear + bias + positional row -> s.h
+static int run_vq_front(const dimx_ctx* c, const void* x_in, int ld_in, const Linear& conv, const Linear& le,
+                        const float* pe, int pe_mode, int row_off, VQScratch& s, int B, int T, const int32_t* lens,
+                        hipStream_t st) {
+    const int M = B * T, Hd = c->d.vq_hidden;
+    GemmArgs g;
+    gemm_lin(c, x_in, ld_in, conv, M, g);
+    g.conv_T = T;
+    g.conv_lens = lens;
+    g.conv_C = Hd;
+    g.act = ACT_LEAKY;
+    g.out_dtype = DIMX_F32;
+    gemm_set_plain_out(g, s.conv, Hd);
+    DIMX_TRY(launch_gemm(g, st));
+    DIMX_TRY(launch_instnorm(c->at, s.conv, s.y, lens, B, T, Hd, st));
+    gemm_lin(c, s.y, Hd, le, M, g);
+    g.out_dtype = DIMX_F32;
+    g.rowT = T;
+    g.rowadd = pe;
+    g.ld_rowadd = Hd;
+    g.rowadd_mode = pe_mode == 0 ? 3 : 2;
+    g.rowadd_off = pe_mode == 0 ? 0 : row_off;
+    gemm_set_plain_out(g, s.h, Hd);
+    DIMX_TRY(launch_gemm(g, st));
+    return DIMX_OK;
+}
+
+}  // namespace dimx
+
+using namespace dimx;
+
+// ====================================================================== C-ABI
+extern "C" {
+
+int dimx_version(void) { return 100; }
+const char* dimx_last_error(void) { return get_error(); }
+
+void dimx_default_dims(dimx_dims* d) {
+    if (!d) return;
+    d->vq_in_dim = 56; d->vq_hidden = 384; d->vq_layers = 6; d->vq_heads = 8; d->vq_inter = 1536;
+    d->vq_n_embed = 512; d->vq_zdim = 128;
+    d->dim_in = 56; d->dim = 384; d->dim_a = 768; d->enc_depth = 4; d->dec_depth = 4; d->heads = 12;
+    d->dim_head = 64; d->num_tokens = 512; d->max_seq_len = 2048; d->ff_mult = 4;
+}
+
+int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeric_mode) {
+    DIMX_REQUIRE(h, DIMX_ERR_ARG, "dimx_create: null handle pointer");
+    DIMX_REQUIRE(numeric_mode == DIMX_MODE_PARITY_F32 || numeric_mode == DIMX_MODE_PERF_BF16, DIMX_ERR_ARG,
+                 "dimx_create: numeric_mode %d", numeric_mode);
+    dimx_dims d;
+    dimx_default_dims(&d);
+    if (dims) d = *dims;
+    DIMX_REQUIRE(d.vq_hidden == 384 && d.vq_heads == 8 && d.vq_zdim == 128 && d.vq_n_embed == 512 && d.vq_in_dim == 56,
+                 DIMX_ERR_ARG, "dimx_create: only the DIM-Listener VQ geometry (56/384/8/128/512) is built");
+    DIMX_REQUIRE(d.dim == 384 && d.dim_a == 768 && d.dim_head == 64 && d.heads == 12 && d.num_tokens == 512 &&
+                     d.vq_layers <= 8 && d.enc_depth <= 8 && d.dec_depth <= 8 && d.max_seq_len <= 2048,
+                 DIMX_ERR_ARG, "dimx_create: only the SLMFT geometry (384+768, 12x64, 512 tokens) is built");
+    int ndev = 0;
+    DIMX_HIP(hipGetDeviceCount(&ndev));
+    DIMX_REQUIRE(device_id >= 0 && device_id < ndev, DIMX_ERR_ARG, "dimx_create: device %d of %d", device_id, ndev);
+    DIMX_HIP(hipSetDevice(device_id));
+    dimx_ctx* c = new dimx_ctx();
+    c->device = device_id;
+    c->d = d;
+    c->mode = numeric_mode;
+    c->at = numeric_mode == DIMX_MODE_PERF_BF16 ? DIMX_BF16 : DIMX_F32;
+    for (const auto& k : all_keys(d)) c->required.push_back(k.name);
+    const char* ng = getenv("DIMX_NO_GRAPH");
+    c->use_graph = (ng && ng[0] == '1') ? 0 : 1;
+    *h = c;
+    return DIMX_OK;
+}
+
+int dimx_destroy(dimx_handle h) {
+    if (!h) return DIMX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    free_packed(h);
+    delete h;
+    return DIMX_OK;
+}
+
+int dimx_numeric_mode(dimx_handle h) { return h ? h->mode : DIMX_ERR_ARG; }
+
+int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n) {
+    DIMX_REQUIRE(h && descs && n >= 0, DIMX_ERR_ARG, "dimx_load_weights: null argument");
+    static thread_local std::map<std::string, std::vector<int64_t>> spec;
+    spec.clear();
+    for (const auto& k : all_keys(h->d)) spec[k.name] = k.shape;
+    for (int i = 0; i < n; ++i) {
+        const dimx_weight_desc& w = descs[i];
+        DIMX_REQUIRE(w.name && w.data && w.ndim >= 1 && w.ndim <= 4, DIMX_ERR_ARG, "dimx_load_weights: bad desc %d", i);
+        const std::string name(w.name);
+        auto it = spec.find(name);
+        if (it == spec.end()) {
+            DIMX_REQUIRE(ignorable_key(name), DIMX_ERR_WEIGHT, "unknown weight key %s", w.name);
+            continue;
+        }
+        DIMX_REQUIRE((int)it->second.size() == w.ndim, DIMX_ERR_WEIGHT, "%s: rank %d, expected %d", w.name, w.ndim,
+                     (int)it->second.size());
+        size_t cnt = 1;
+        for (int k = 0; k < w.ndim; ++k) {
+            DIMX_REQUIRE(it->second[k] == w.shape[k], DIMX_ERR_WEIGHT, "%s: dim %d is %lld, expected %lld", w.name, k,
+                         (long long)w.shape[k], (long long)it->second[k]);
+            cnt *= (size_t)w.shape[k];
+        }
+        HostTensor& t = h->host[name];
+        t.shape.assign(w.shape, w.shape + w.ndim);
+        t.data.assign(w.data, w.data + cnt);
+        h->packed = false;
+    }
+    return DIMX_OK;
+}
+
+int dimx_missing_weights(dimx_handle h) {
+    if (!h) return DIMX_ERR_ARG;
+    int m = 0;
+    for (const auto& k : h->required) m += h->host.count(k) ? 0 : 1;
+    return m;
+}
+
+}  // extern "C"
+
+// ====================================================================== stages
+namespace dimx {
+
+struct EncScratch {
+    void *xa, *y, *q, *k, *vt, *o, *f;
+    float *h, *tmp;
+};
+struct CtxPersist {
+    void* ck[8];
+    void* cv[8];
+};
+struct DecScratch {
+    void *y, *q, *k, *vt, *o, *f;
+    float* h;
+    int32_t *inp, *tgt;
+    uint8_t* kvm;
+};
+struct GenScratch {
+    void* sk[8];
+    void* sv[8];
+    float *x, *logits;
+    void *y, *qkv, *o, *f;
+    int32_t* step;
+};
+
+static void plan_persist(const dimx_ctx* c, Arena& ar, int B, int T, CtxPersist& p) {
+    const size_t es = es_of(c);
+    const size_t per = (size_t)B * c->d.heads * c->d.dim_head * tpad(T) * es;
+    for (int l = 0; l < c->d.dec_depth; ++l) {
+        p.ck[l] = ar.take(per);
+        p.cv[l] = ar.take(per);
+    }
+}
+static void plan_enc(const dimx_ctx* c, Arena& ar, int B, int T, EncScratch& s) {
+    const size_t M = (size_t)B * T, es = es_of(c);
+    const int dim = c->d.dim, inner = c->d.heads * c->d.dim_head, Tp = tpad(T);
+    s.xa = ar.take(M * (c->d.dim + c->d.dim_a) * es);  // padded input, later the 1152-wide context
+    s.h = (float*)ar.take(M * dim * 4);
+    s.tmp = (float*)ar.take(M * dim * 4);
+    s.y = ar.take(M * dim * es);
+    s.q = ar.take(M * inner * es);
+    s.k = ar.take(M * inner * es);
+    s.vt = ar.take((size_t)B * inner * Tp * es);
+    s.o = ar.take(M * inner * es);
+    s.f = ar.take(M * dim * c->d.ff_mult * es);
+}
+static void plan_dec(const dimx_ctx* c, Arena& ar, int B, int T, DecScratch& s) {
+    const int n = T - 1;
+    const size_t M = (size_t)B * n, es = es_of(c);
+    const int D = c->d.dim + c->d.dim_a, inner = c->d.heads * c->d.dim_head, np = tpad(n);
+    s.h = (float*)ar.take(M * D * 4);
+    s.y = ar.take(M * D * es);
+    s.q = ar.take(M * inner * es);
+    s.k = ar.take(M * inner * es);
+    s.vt = ar.take((size_t)B * inner * np * es);
+    s.o = ar.take(M * inner * es);
+    s.f = ar.take(M * D * c->d.ff_mult * es);
+    s.inp = (int32_t*)ar.take(M * 4);
+    s.tgt = (int32_t*)ar.take(M * 4);
+    s.kvm = (uint8_t*)ar.take(M);
+}
+static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) {
+    const size_t es = es_of(c);
+    const int D = c->d.dim + c->d.dim_a, inner = c->d.heads * c->d.dim_head;
+    const size_t per = (size_t)B * inner * T * es;
+    for (int l = 0; l < c->d.dec_depth; ++l) {
+        s.sk[l] = ar.take(per);
+        s.sv[l] = ar.take(per);
+    }
+    s.x = (float*)ar.take((size_t)B * D * 4);
+    s.y = ar.take((size_t)B * D * es);
+    s.qkv = ar.take((size_t)B * 3 * inner * es);
+    s.o = ar.take((size_t)B * inner * es);
+    s.f = ar.take((size_t)B * D * c->d.ff_mult * es);
+    s.logits = (float*)ar.take((size_t)B * c->d.num_tokens * 4);
+    s.step = (int32_t*)ar.take(256);
+}
+
+static size_t workspace_bytes(const dimx_ctx* c, int B, int T) {
+    Arena p(nullptr, 0);
+    CtxPersist cp;
+    plan_persist(c, p, B, T, cp);
+    const size_t persist = align_up(p.off, 256);
+    size_t scratch = 0;
+    {
+        Arena a(nullptr, 0);
+        VQScratch s;
+        plan_vq(c, a, B, T, s);
+        scratch = a.off > scratch ? a.off : scratch;
+    }
+    {
+        Arena a(nullptr, 0);
+        EncScratch s;
+        plan_enc(c, a, B, T, s);
+        scratch = a.off > scratch ? a.off : scratch;
+    }
+    if (T >= 2) {
+        Arena a(nullptr, 0);
+        DecScratch s;
+        plan_dec(c, a, B, T, s);
+        scratch = a.off > scratch ? a.off : scratch;
+        Arena g(nullptr, 0);
+        GenScratch gs;
+        plan_gen(c, g, B, T, gs);
+        scratch = g.off > scratch ? g.off : scratch;
+    }
+    return persist + align_up(scratch, 256) + 4096;
+}
+
+// x-transformers encoder stack (ContinuousTransformerWrapper, return_embeddings=True)
+static int run_xenc(const dimx_ctx* c, const XEnc& e, const void* x_in, int ld_in, EncScratch& s, int B, int T,
+                    const uint8_t* mask, int out_dtype, void* out, hipStream_t st) {
+    const int M = B * T, dim = c->d.dim, heads = c->d.heads, D = c->d.dim_head, inner = heads * D, Tp = tpad(T);
+    GemmArgs g;
+    gemm_lin(c, x_in, ld_in, e.proj_in, M, g);
+    g.out_dtype = DIMX_F32;
+    g.rowT = T;
+    g.rowadd = e.pos_emb;
+    g.ld_rowadd = dim;
+    g.rowadd_mode = 1;
+    g.rowadd_scale = 1.0f / sqrtf((float)dim);
+    gemm_set_plain_out(g, s.h, dim);
+    DIMX_TRY(launch_gemm(g, st));
+    for (int l = 0; l < c->d.enc_depth; ++l) {
+        DIMX_TRY(launch_layernorm(c->at, s.h, s.y, e.attn[l].ln_g, nullptr, M, dim, st));
+        gemm_lin(c, s.y, dim, e.attn[l].qkv, M, g);
+        g.out_dtype = c->at;
+        set_qkv_out(g, s.q, s.k, s.vt, T, heads, D, Tp);
+        DIMX_TRY(launch_gemm(g, st));
+        AttnArgs a;
+        set_attn_packed(a, c->at, s.q, s.k, s.vt, s.o, B, heads, T, T, D, Tp);
+        a.scale = 1.0f / sqrtf((float)D);
+        a.causal = 1;
+        a.kmask = mask;
+        a.kmask_ld = T;
+        DIMX_TRY(launch_attention(a, st));
+        gemm_lin(c, s.o, inner, e.attn[l].out, M, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.h;
+        g.ldr = dim;
+        gemm_set_plain_out(g, s.h, dim);
+        DIMX_TRY(launch_gemm(g, st));
+        DIMX_TRY(launch_layernorm(c->at, s.h, s.y, e.ff[l].ln_g, nullptr, M, dim, st));
+        gemm_lin(c, s.y, dim, e.ff[l].f1, M, g);
+        g.out_dtype = c->at;
+        g.act = ACT_GELU_ERF;
+        gemm_set_plain_out(g, s.f, dim * c->d.ff_mult);
+        DIMX_TRY(launch_gemm(g, st));
+        gemm_lin(c, s.f, dim * c->d.ff_mult, e.ff[l].f2, M, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.h;
+        g.ldr = dim;
+        gemm_set_plain_out(g, s.h, dim);
+        DIMX_TRY(launch_gemm(g, st));
+    }
+    DIMX_TRY(launch_layernorm(out_dtype, s.h, out, e.final_g, nullptr, M, dim, st));
+    return DIMX_OK;
+}
+
+static int check_common(dimx_handle h, int B, int T, void* ws, size_t ws_bytes) {
+    DIMX_REQUIRE(h, DIMX_ERR_ARG, "null handle");
+    DIMX_REQUIRE(B >= 1 && T >= 1 && T <= h->d.max_seq_len, DIMX_ERR_ARG, "B=%d T=%d out of range (T <= %d)", B, T,
+                 h->d.max_seq_len);
+    DIMX_REQUIRE(ws && ((uintptr_t)ws % 256) == 0, DIMX_ERR_ARG, "workspace must be 256-byte aligned");
+    const size_t need = workspace_bytes(h, B, T);
+    DIMX_REQUIRE(ws_bytes >= need, DIMX_ERR_WORKSPACE, "workspace %zu < required %zu", ws_bytes, need);
+    DIMX_HIP(hipSetDevice(h->device));
+    DIMX_TRY(ensure_packed(h));
+    return DIMX_OK;
+}
+
+static Arena scratch_arena(const dimx_ctx* c, void* ws, size_t ws_bytes, int B, int T, CtxPersist* cp) {
+    Arena p(ws, ws_bytes);
+    CtxPersist tmp;
+    plan_persist(c, p, B, T, cp ? *cp : tmp);
+    const size_t persist = align_up(p.off, 256);
+    return Arena((unsigned char*)ws + persist, ws_bytes - persist);
+}
+
+}  // namespace dimx
+
+extern "C" {
+
+size_t dimx_workspace_bytes(dimx_handle h, int B, int T) {
+    if (!h || B < 1 || T < 1) return 0;
+    return workspace_bytes(h, B, T);
+}
+
+int dimx_vq_argmin(dimx_handle h, int which, const float* z, int N, int32_t* idx, float* best_d, float* margin,
+                   void* stream) {
+    DIMX_REQUIRE(h && (which == 0 || which == 1), DIMX_ERR_ARG, "vq_argmin: bad handle/which");
+    DIMX_HIP(hipSetDevice(h->device));
+    DIMX_TRY(ensure_packed(h));
+    return launch_vq_argmin(z, N, h->vq[which].Et, h->vq[which].ee, idx, best_d, margin, (hipStream_t)stream);
+}
+
+int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens, int B, int T, int pe_mode,
+                   int batch_row_offset, int32_t pad_value, int32_t* idx, float* z_out, void* ws, size_t ws_bytes,
+                   void* stream) {
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes));
+    DIMX_REQUIRE(x && idx && (which == 0 || which == 1), DIMX_ERR_ARG, "vq_encode: null argument");
+    DIMX_REQUIRE(pe_mode == 0 || B + batch_row_offset <= 5000, DIMX_ERR_ARG, "vq_encode: positional row out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const VQNet& v = h->vq[which];
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, T, nullptr);
+    VQScratch s;
+    plan_vq(h, ar, B, T, s);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_encode: workspace overflow");
+    const int M = B * T, Hd = h->d.vq_hidden;
+    DIMX_TRY(launch_cast_pad(h->at, x, h->d.vq_in_dim, nullptr, s.xa, 64, M, h->d.vq_in_dim, st));
+    GemmArgs g;
+    gemm_lin(h, s.xa, 64, v.vm, M, g);
+    g.out_dtype = h->at;
+    g.act = ACT_LEAKY;
+    gemm_set_plain_out(g, s.h1, Hd);
+    DIMX_TRY(launch_gemm(g, st));
+    DIMX_TRY(run_vq_front(h, s.h1, Hd, v.conv, v.le, v.pe_enc, pe_mode, batch_row_offset, s, B, T, lens, st));
+    DIMX_TRY(run_vq_blocks(h, v.enc, s, B, T, lens, st));
+    // post projection consumes the f32 residual stream directly (no final norm in this stack)
+    DIMX_TRY(launch_cast_pad(h->at, s.h, Hd, nullptr, s.y, Hd, M, Hd, st));
+    gemm_lin(h, s.y, Hd, v.post, M, g);
+    g.out_dtype = DIMX_F32;
+    float* z = z_out ? z_out : s.z;
+    gemm_set_plain_out(g, z, h->d.vq_zdim);
+    DIMX_TRY(launch_gemm(g, st));
+    DIMX_TRY(launch_vq_argmin(z, M, v.Et, v.ee, idx, nullptr, nullptr, st));
+    DIMX_TRY(launch_finalize_idx(idx, lens, B, T, pad_value, st));
+    return DIMX_OK;
+}
+
+int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset, float* out,
+                   void* ws, size_t ws_bytes, void* stream) {
+    DIMX_TRY(check_common(h, B, L, ws, ws_bytes));
+    DIMX_REQUIRE(idx && out && (which == 0 || which == 1), DIMX_ERR_ARG, "vq_decode: null argument");
+    DIMX_REQUIRE(B + batch_row_offset <= 5000 && batch_row_offset >= 0, DIMX_ERR_ARG,
+                 "vq_decode: positional row %d out of range", B + batch_row_offset);
+    hipStream_t st = (hipStream_t)stream;
+    const VQNet& v = h->vq[which];
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, L, nullptr);
+    VQScratch s;
+    plan_vq(h, ar, B, L, s);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_decode: workspace overflow");
+    const int M = B * L, Hd = h->d.vq_hidden, zd = h->d.vq_zdim;
+    DIMX_TRY(launch_gather_rows(h->at, v.E, zd, h->d.vq_n_embed, idx, s.xa, zd, M, zd, st));
+    GemmArgs g;
+    gemm_lin(h, s.xa, zd, v.pre, M, g);
+    g.out_dtype = h->at;
+    gemm_set_plain_out(g, s.h1, Hd);
+    DIMX_TRY(launch_gemm(g, st));
+    DIMX_TRY(run_vq_front(h, s.h1, Hd, v.dconv, v.dle, v.pe_dec, 1, batch_row_offset, s, B, L, nullptr, st));
+    DIMX_TRY(run_vq_blocks(h, v.dec, s, B, L, nullptr, st));
+    DIMX_TRY(launch_cast_pad(h->at, s.h, Hd, nullptr, s.y, Hd, M, Hd, st));
+    gemm_lin(h, s.y, Hd, v.rev, M, g);
+    g.out_dtype = DIMX_F32;
+    gemm_set_plain_out(g, out, h->d.vq_in_dim);
+    DIMX_TRY(launch_gemm(g, st));
+    return DIMX_OK;
+}
+
+int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio, const uint8_t* mask, int B, int T,
+                    int for_generate, float* x_s_out, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes));
+    DIMX_REQUIRE(v_speaker && v_audio && mask, DIMX_ERR_ARG, "encode_ctx: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    CtxPersist cp;
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, T, &cp);
+    EncScratch s;
+    plan_enc(h, ar, B, T, s);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "encode_ctx: workspace overflow");
+    const int M = B * T, dim = h->d.dim, dim_a = h->d.dim_a, D = h->d.dim_head, heads = h->d.heads, Tp = tpad(T);
+    // v_speaker + patch_embed_s, padded 56 -> 64
+    DIMX_TRY(launch_cast_pad(h->at, v_speaker, h->d.dim_in, h->patch_s, s.xa, 64, M, h->d.dim_in, st));
+    DIMX_TRY(run_xenc(h, h->enc_s, s.xa, 64, s, B, T, mask, h->at, s.xa, st));  // encoder_s output reuses xa
+    DIMX_TRY(run_xenc(h, h->enc_joint, s.xa, dim, s, B, T, mask, DIMX_F32, s.tmp, st));
+    float* x_s = x_s_out ? x_s_out : s.tmp;
+    // norm_s = nn.LayerNorm(dim) with bias (code/seq2seq_pretrain.py:411,441); in place when no copy is wanted
+    {
+        float* dst = x_s_out ? x_s_out : (float*)s.h;
+        DIMX_TRY(launch_layernorm(DIMX_F32, s.tmp, dst, h->norm_s_g, h->norm_s_b, M, dim, st));
+        x_s = dst;
+    }
+    DIMX_TRY(launch_context_concat(h->at, x_s, h->patch_dec_s, v_audio, s.xa, M, dim, dim_a, st));
+    for (int l = 0; l < h->d.dec_depth; ++l) {
+        GemmArgs g;
+        gemm_lin(h, s.xa, dim + dim_a, h->dec.cross[l].kv, M, g);
+        g.out_dtype = h->at;
+        g.rowT = T;
+        g.nseg = 2;
+        g.seg_width = heads * D;
+        if (for_generate) {  // K and V both [B,H,T(p),64]
+            for (int i = 0; i < 2; ++i) {
+                g.seg[i].ptr = i == 0 ? cp.ck[l] : cp.cv[l];
+                g.seg[i].sb = (long)heads * Tp * D;
+                g.seg[i].sh = (long)Tp * D;
+                g.seg[i].st = D;
+                g.seg[i].sd = 1;
+                g.seg[i].D = D;
+            }
+        } else {  // K row-major [B,T,768]; V transposed [B,H,64,Tp]
+            g.seg[0].ptr = cp.ck[l];
+            g.seg[0].sb = (long)T * heads * D;
+            g.seg[0].st = heads * D;
+            g.seg[0].sh = D;
+            g.seg[0].sd = 1;
+            g.seg[0].D = D;
+            g.seg[1].ptr = cp.cv[l];
+            g.seg[1].sb = (long)heads * D * Tp;
+            g.seg[1].sh = (long)D * Tp;
+            g.seg[1].sd = Tp;
+            g.seg[1].st = 1;
+            g.seg[1].D = D;
+        }
+        DIMX_TRY(launch_gemm(g, st));
+    }
+    h->ctx_ready = true;
+    h->ctx_B = B;
+    h->ctx_T = T;
+    h->ctx_for_generate = for_generate ? 1 : 0;
+    h->ctx_ws = ws;
+    return DIMX_OK;
+}
+
+int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, const uint8_t* kv_mask, int B, int T,
+                   float* logits, float* row_loss, int32_t* argmax_tok, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes));
+    DIMX_REQUIRE(z_l && ctx_mask && logits && T >= 2, DIMX_ERR_ARG, "decode_tf: null argument or T < 2");
+    DIMX_REQUIRE(h->ctx_ready && h->ctx_B == B && h->ctx_T == T && h->ctx_ws == ws && !h->ctx_for_generate,
+                 DIMX_ERR_STATE, "decode_tf: call dimx_encode_ctx(for_generate=0) with the same B, T, ws first");
+    hipStream_t st = (hipStream_t)stream;
+    CtxPersist cp;
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, T, &cp);
+    DecScratch s;
+    plan_dec(h, ar, B, T, s);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "decode_tf: workspace overflow");
+    const int n = T - 1, M = B * n, DD = h->d.dim + h->d.dim_a, heads = h->d.heads, D = h->d.dim_head;
+    const int inner = heads * D, np = tpad(n), Tp = tpad(T), V = h->d.num_tokens;
+    DIMX_TRY(launch_shift_tokens(z_l, s.inp, s.tgt, B, T, st));
+    DIMX_TRY(launch_gather_rows(DIMX_F32, h->dec.tok_emb, DD, V, s.inp, s.h, DD, M, DD, st));
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int l = 0; l < h->d.dec_depth; ++l) {
+        GemmArgs g;
+        AttnArgs a;
+        // causal self attention (+ AutoregressiveWrapper's random key mask)
+        DIMX_TRY(launch_layernorm(h->at, s.h, s.y, h->dec.self_[l].ln_g, nullptr, M, DD, st));
+        gemm_lin(h, s.y, DD, h->dec.self_[l].qkv, M, g);
+        g.out_dtype = h->at;
+        set_qkv_out(g, s.q, s.k, s.vt, n, heads, D, np);
+        DIMX_TRY(launch_gemm(g, st));
+        set_attn_packed(a, h->at, s.q, s.k, s.vt, s.o, B, heads, n, n, D, np);
+        a.scale = scale;
+        a.causal = 1;
+        a.kmask = kv_mask;
+        a.kmask_ld = n;
+        DIMX_TRY(launch_attention(a, st));
+        gemm_lin(h, s.o, inner, h->dec.self_[l].out, M, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.h;
+        g.ldr = DD;
+        gemm_set_plain_out(g, s.h, DD);
+        DIMX_TRY(launch_gemm(g, st));
+        // cross attention over the speaker context
+        DIMX_TRY(launch_layernorm(h->at, s.h, s.y, h->dec.cross[l].ln_g, nullptr, M, DD, st));
+        gemm_lin(h, s.y, DD, h->dec.cross[l].qkv, M, g);
+        g.out_dtype = h->at;
+        gemm_set_plain_out(g, s.q, inner);
+        DIMX_TRY(launch_gemm(g, st));
+        set_attn_packed(a, h->at, s.q, cp.ck[l], cp.cv[l], s.o, B, heads, n, T, D, Tp);
+        a.scale = scale;
+        a.kmask = ctx_mask;
+        a.kmask_ld = T;
+        DIMX_TRY(launch_attention(a, st));
+        gemm_lin(h, s.o, inner, h->dec.cross[l].out, M, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.h;
+        g.ldr = DD;
+        gemm_set_plain_out(g, s.h, DD);
+        DIMX_TRY(launch_gemm(g, st));
+        // feed forward
+        DIMX_TRY(launch_layernorm(h->at, s.h, s.y, h->dec.ff[l].ln_g, nullptr, M, DD, st));
+        gemm_lin(h, s.y, DD, h->dec.ff[l].f1, M, g);
+        g.out_dtype = h->at;
+        g.act = ACT_GELU_ERF;
+        gemm_set_plain_out(g, s.f, DD * h->d.ff_mult);
+        DIMX_TRY(launch_gemm(g, st));
+        gemm_lin(h, s.f, DD * h->d.ff_mult, h->dec.ff[l].f2, M, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.h;
+        g.ldr = DD;
+        gemm_set_plain_out(g, s.h, DD);
+        DIMX_TRY(launch_gemm(g, st));
+    }
+    DIMX_TRY(launch_layernorm(h->at, s.h, s.y, h->dec.final_g, nullptr, M, DD, st));
+    GemmArgs g;
+    gemm_lin(h, s.y, DD, h->dec.logits, M, g);
+    g.out_dtype = DIMX_F32;
+    gemm_set_plain_out(g, logits, V);
+    DIMX_TRY(launch_gemm(g, st));
+    if (row_loss || argmax_tok) DIMX_TRY(launch_ce_argmax(logits, s.tgt, row_loss, argmax_tok, M, V, st));
+    return DIMX_OK;
+}
+
+}  // extern "C"
+
+namespace dimx {
+
+// one decoder step: x = emb(token) -> 4 x {self, cross, ff} -> logits -> sample -> step += 1
+static int gen_step(dimx_handle h, const CtxPersist& cp, GenScratch& s, const int32_t* start, const uint8_t* ctx_mask,
+                    int B, int T, float temperature, int top_k, const float* noise, uint64_t seed, int32_t* tokens,
+                    float* logits_out, hipStream_t st) {
+    const int DD = h->d.dim + h->d.dim_a, heads = h->d.heads, D = h->d.dim_head, inner = heads * D;
+    const int V = h->d.num_tokens, n = T - 1, Tp = tpad(T);
+    const size_t es = es_of(h);
+    const float scale = 1.0f / sqrtf((float)D);
+    DIMX_TRY(launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, st));
+    for (int l = 0; l < h->d.dec_depth; ++l) {
+        GemmArgs g;
+        DecodeAttnArgs a;
+        DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.self_[l].ln_g, nullptr, B, DD, st));
+        gemm_lin(h, s.y, DD, h->dec.self_[l].qkv, B, g);
+        g.out_dtype = h->at;
+        gemm_set_plain_out(g, s.qkv, 3 * inner);
+        DIMX_TRY(launch_gemm(g, st));
+        memset(&a, 0, sizeof(a));
+        a.dtype = h->at;
+        a.q = s.qkv;
+        a.q_ld = 3 * inner;
+        a.knew = (const unsigned char*)s.qkv + (size_t)inner * es;
+        a.vnew = (const unsigned char*)s.qkv + (size_t)2 * inner * es;
+        a.kv_ld = 3 * inner;
+        a.kcache = s.sk[l];
+        a.vcache = s.sv[l];
+        a.Tmax = T;
+        a.out = s.o;
+        a.o_ld = inner;
+        a.B = B;
+        a.H = heads;
+        a.step = s.step;
+        a.scale = scale;
+        DIMX_TRY(launch_decode_attn(a, st));
+        gemm_lin(h, s.o, inner, h->dec.self_[l].out, B, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.x;
+        g.ldr = DD;
+        gemm_set_plain_out(g, s.x, DD);
+        DIMX_TRY(launch_gemm(g, st));
+
+        DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.cross[l].ln_g, nullptr, B, DD, st));
+        gemm_lin(h, s.y, DD, h->dec.cross[l].qkv, B, g);
+        g.out_dtype = h->at;
+        gemm_set_plain_out(g, s.qkv, inner);
+        DIMX_TRY(launch_gemm(g, st));
+        memset(&a, 0, sizeof(a));
+        a.dtype = h->at;
+        a.q = s.qkv;
+        a.q_ld = inner;
+        a.kcache = cp.ck[l];
+        a.vcache = cp.cv[l];
+        a.Tmax = Tp;
+        a.out = s.o;
+        a.o_ld = inner;
+        a.B = B;
+        a.H = heads;
+        a.n_keys = T;
+        a.kmask = ctx_mask;
+        a.kmask_ld = T;
+        a.scale = scale;
+        DIMX_TRY(launch_decode_attn(a, st));
+        gemm_lin(h, s.o, inner, h->dec.cross[l].out, B, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.x;
+        g.ldr = DD;
+        gemm_set_plain_out(g, s.x, DD);
+        DIMX_TRY(launch_gemm(g, st));
+
+        DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.ff[l].ln_g, nullptr, B, DD, st));
+        gemm_lin(h, s.y, DD, h->dec.ff[l].f1, B, g);
+        g.out_dtype = h->at;
+        g.act = ACT_GELU_ERF;
+        gemm_set_plain_out(g, s.f, DD * h->d.ff_mult);
+        DIMX_TRY(launch_gemm(g, st));
+        gemm_lin(h, s.f, DD * h->d.ff_mult, h->dec.ff[l].f2, B, g);
+        g.out_dtype = DIMX_F32;
+        g.residual = s.x;
+        g.ldr = DD;
+        gemm_set_plain_out(g, s.x, DD);
+        DIMX_TRY(launch_gemm(g, st));
+    }
+    DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.final_g, nullptr, B, DD, st));
+    GemmArgs g;
+    gemm_lin(h, s.y, DD, h->dec.logits, B, g);
+    g.out_dtype = DIMX_F32;
+    gemm_set_plain_out(g, s.logits, V);
+    DIMX_TRY(launch_gemm(g, st));
+    if (logits_out) DIMX_TRY(launch_copy_rows_step(s.logits, logits_out, B, V, n, s.step, st));
+    DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, st));
+    DIMX_TRY(launch_step_inc(s.step, st));
+    return DIMX_OK;
+}
+
+}  // namespace dimx
+
+extern "C" {
+
+int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T, float temperature,
+                  int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens, float* logits_out, void* ws,
+                  size_t ws_bytes, void* stream) {
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes));
+    DIMX_REQUIRE(start && ctx_mask && tokens && T >= 2, DIMX_ERR_ARG, "generate: null argument or T < 2");
+    DIMX_REQUIRE(h->ctx_ready && h->ctx_B == B && h->ctx_T == T && h->ctx_ws == ws && h->ctx_for_generate,
+                 DIMX_ERR_STATE, "generate: call dimx_encode_ctx(for_generate=1) with the same B, T, ws first");
+    hipStream_t st = (hipStream_t)stream;
+    CtxPersist cp;
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, T, &cp);
+    GenScratch s;
+    plan_gen(h, ar, B, T, s);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "generate: workspace overflow");
+    const int n = T - 1;
+    DIMX_HIP(hipMemsetAsync(s.step, 0, 4, st));
+    if (!h->use_graph) {
+        for (int t = 0; t < n; ++t)
+            DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, B, T, temperature, top_k, exp_noise, seed, tokens, logits_out, st));
+        return DIMX_OK;
+    }
+    GraphKey key{ws, B, T, top_k, temperature, exp_noise, seed, start, ctx_mask, tokens, logits_out};
+    if (!(h->graph_valid && h->graph_key == key)) {
+        if (h->graph_exec) {
+            (void)hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
+        h->graph_valid = false;
+        hipGraph_t graph = nullptr;
+        if (!h->cap_stream) DIMX_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+        DIMX_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = gen_step(h, cp, s, start, ctx_mask, B, T, temperature, top_k, exp_noise, seed, tokens, logits_out,
+                                h->cap_stream);
+        const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+        if (rc != DIMX_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        DIMX_HIP(ce);
+        DIMX_HIP(hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        h->graph_key = key;
+        h->graph_valid = true;
+    }
+    for (int t = 0; t < n; ++t) DIMX_HIP(hipGraphLaunch(h->graph_exec, st));
+    return DIMX_OK;
+}
+
+// ---------------------------------------------------------------- kernel-level entry points
+int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M,
+                 int N, int K, const float* bias, int act, const float* residual, int ldr, int conv_T,
+                 const int32_t* conv_lens, void* stream) {
+    GemmArgs g;
+    gemm_args_init(g);
+    g.in_dtype = in_dtype;
+    g.out_dtype = out_dtype;
+    g.A = A;
+    g.lda = lda;
+    g.W = W;
+    g.ldw = ldw;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.bias = bias;
+    g.act = act;
+    g.residual = residual;
+    g.ldr = ldr;
+    if (conv_T > 0) {
+        g.conv_T = conv_T;
+        g.conv_lens = conv_lens;
+        g.conv_C = K / 5;
+    }
+    gemm_set_plain_out(g, C, ldc);
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+int dimx_op_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta, int M, int C,
+                      void* stream) {
+    return launch_layernorm(out_dtype, x, y, gamma, beta, M, C, (hipStream_t)stream);
+}
+
+int dimx_op_instnorm(int out_dtype, const float* x, void* y, const int32_t* lens, int B, int T, int C, void* stream) {
+    return launch_instnorm(out_dtype, x, y, lens, B, T, C, (hipStream_t)stream);
+}
+
+int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int H, int Lq, int Lk,
+                      int D, int ldq, int ldk, int ld_vt, int ldo, float scale, int causal, const int32_t* lens,
+                      const uint8_t* kmask, void* stream) {
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = dtype;
+    a.q = q; a.k = k; a.vt = vt; a.o = out;
+    a.q_sb = (long)Lq * ldq; a.q_st = ldq; a.q_sh = D;
+    a.k_sb = (long)Lk * ldk; a.k_st = ldk; a.k_sh = D;
+    a.v_sb = (long)H * D * ld_vt; a.v_sh = (long)D * ld_vt; a.v_sd = ld_vt;
+    a.o_sb = (long)Lq * ldo; a.o_st = ldo; a.o_sh = D;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D;
+    a.scale = scale;
+    a.causal = causal;
+    a.lens = lens;
+    a.kmask = kmask;
+    a.kmask_ld = Lk;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise, uint64_t seed,
+                   uint64_t step, int32_t* tokens, void* stream) {
+    // exp_noise here is the [R,512] slice of this step (step only salts the on-device generator)
+    return launch_sample(logits, 512, R, top_k, temperature, exp_noise, seed, nullptr, exp_noise ? 0 : step, tokens, 1,
+                         0, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// model.hpp -- handle layout of libdimx_hip: packed device weights + stage planners.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace dimx {
+
+struct Linear {
+    void* w = nullptr;  // [N][Kp] in the handle's operand type (bf16 / f32)
+    const float* bias = nullptr;
+    int N = 0, K = 0, Kp = 0;
+};
+
+struct VQBlock {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    Linear qkv, out, l1, l2;
+};
+
+struct VQNet {
+    Linear vm, conv, le, post;      // encoder
+    VQBlock enc[8];
+    Linear pre, dconv, dle, rev;    // decoder
+    VQBlock dec[8];
+    const float* pe_enc = nullptr;  // [5000][hidden]
+    const float* pe_dec = nullptr;
+    const float* E = nullptr;       // [n_embed][zdim]
+    const float* Et = nullptr;      // [zdim][n_embed]
+    const float* ee = nullptr;      // [n_embed]
+};
+
+struct XAttn {
+    const float* ln_g;
+    Linear qkv;  // self: fused [3*inner][dim]; cross: q only [inner][dim]
+    Linear kv;   // cross: fused [2*inner][dim]
+    Linear out;
+};
+struct XFF {
+    const float* ln_g;
+    Linear f1, f2;
+};
+struct XEnc {
+    Linear proj_in;
+    const float* pos_emb = nullptr;  // [max_seq_len][dim]
+    XAttn attn[8];
+    XFF ff[8];
+    const float* final_g = nullptr;
+};
+struct XDec {
+    const float* tok_emb = nullptr;  // [num_tokens][dec_dim]
+    XAttn self_[8], cross[8];
+    XFF ff[8];
+    const float* final_g = nullptr;
+    Linear logits;
+};
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+// simple bump planner over the caller's workspace; base == nullptr -> dry run (size only)
+struct Arena {
+    unsigned char* base;
+    size_t off;
+    size_t cap;
+    bool overflow;
+    Arena(void* b, size_t c) : base((unsigned char*)b), off(0), cap(c), overflow(false) {}
+    void* take(size_t bytes) {
+        off = align_up(off, 256);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        if (base && off > cap) overflow = true;
+        return p;
+    }
+};
+
+struct GraphKey {
+    void* ws;
+    int B, T, top_k;
+    float temperature;
+    const void* noise;
+    uint64_t seed;
+    const void *start, *mask, *tokens, *logits_out;
+    bool operator==(const GraphKey& o) const {
+        return ws == o.ws && B == o.B && T == o.T && top_k == o.top_k && temperature == o.temperature &&
+               noise == o.noise && seed == o.seed && start == o.start && mask == o.mask && tokens == o.tokens &&
+               logits_out == o.logits_out;
+    }
+};
+
+}  // namespace dimx
+
+struct dimx_ctx {
+    int device = 0;
+    dimx_dims d;
+    int mode = 0;
+    int at = DIMX_F32;  // operand storage type of GEMM/attention inputs
+    std::map<std::string, dimx::HostTensor> host;
+    std::vector<std::string> required;
+    bool packed = false;
+    std::vector<void*> dev_allocs;
+    dimx::VQNet vq[2];  // 0 speaker, 1 listener
+    dimx::XEnc enc_s, enc_joint;
+    dimx::XDec dec;
+    const float *patch_s = nullptr, *patch_dec_s = nullptr, *norm_s_g = nullptr, *norm_s_b = nullptr;
+    // encode_ctx -> decode hand-off
+    bool ctx_ready = false;
+    int ctx_B = 0, ctx_T = 0, ctx_for_generate = 0;
+    void* ctx_ws = nullptr;
+    // generate step graph
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the null stream)
+    dimx::GraphKey graph_key{};
+    bool graph_valid = false;
+    int use_graph = 1;
+};

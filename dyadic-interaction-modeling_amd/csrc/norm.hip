@@ -1,0 +1,121 @@
+// norm.hip -- LayerNorm (rows of 384 / 1152 f32) and InstanceNorm1d over time.
+//
+// LayerNorm: reference nn.LayerNorm(eps=1e-5) in code/models/lib/base_models.py:13 (VQ blocks, with
+// bias) and x-transformers' bias-free LayerNorm (pre-norms / final_norm of every encoder/decoder
+// layer) plus SLMFT.norm_s (code/seq2seq_pretrain.py:411).  One wave per row, the row lives in
+// registers, mean and variance are two exact passes (mean of squared deviations, like torch).
+//
+// InstanceNorm: nn.InstanceNorm1d(affine=False) of code/models/stage1_BIWI.py:266,333 applied to a
+// [B,L,C] activation: per (clip, channel) statistics over the first len_b frames, biased variance.
+#include "common.hpp"
+
+namespace dimx {
+
+template <typename OutT, int C>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, OutT* __restrict__ y,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int M) {
+    constexpr int PER = C / 64;  // elements per lane (6 or 18), read as float2
+    constexpr int NV = PER / 2;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float2* xr = (const float2*)(x + (size_t)row * C);
+    float2 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[lane + 64 * i];
+        s += v[i].x + v[i].y;
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean;
+        q += a * a + b * b;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+    const float2* g2 = (const float2*)gamma;
+    const float2* b2 = (const float2*)beta;
+    OutT* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c2 = lane + 64 * i;
+        const float2 g = g2[c2];
+        float o0 = (v[i].x - mean) * rstd * g.x, o1 = (v[i].y - mean) * rstd * g.y;
+        if (beta) {
+            const float2 bb = b2[c2];
+            o0 += bb.x;
+            o1 += bb.y;
+        }
+        store_from_f32<OutT>(yr + 2 * c2, o0);
+        store_from_f32<OutT>(yr + 2 * c2 + 1, o1);
+    }
+}
+
+int launch_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta, int M, int C,
+                     hipStream_t s) {
+    DIMX_REQUIRE(x && y && gamma && M > 0, DIMX_ERR_ARG, "layernorm: null operand");
+    DIMX_REQUIRE(C == 384 || C == 1152, DIMX_ERR_ARG, "layernorm: C=%d not in {384,1152}", C);
+    dim3 grid(ceil_div(M, 4)), block(256);
+#define LN_LAUNCH(OT, CC) hipLaunchKernelGGL((layernorm_kernel<OT, CC>), grid, block, 0, s, x, (OT*)y, gamma, beta, M)
+    if (out_dtype == DIMX_BF16) {
+        if (C == 384) LN_LAUNCH(bf16, 384); else LN_LAUNCH(bf16, 1152);
+    } else {
+        if (C == 384) LN_LAUNCH(float, 384); else LN_LAUNCH(float, 1152);
+    }
+#undef LN_LAUNCH
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+// block = 64 channels x 8 time lanes; grid = (C/64, B)
+template <typename OutT>
+__global__ __launch_bounds__(512) void instnorm_kernel(const float* __restrict__ x, OutT* __restrict__ y,
+                                                       const int32_t* __restrict__ lens, int T, int C) {
+    __shared__ float red[8][64];
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = threadIdx.x >> 6;
+    int len = lens ? lens[b] : T;
+    len = len < 1 ? 1 : (len > T ? T : len);
+    const float* xb = x + (size_t)b * T * C + c;
+    float s = 0.f;
+    for (int t = ty; t < len; t += 8) s += xb[(size_t)t * C];
+    red[ty][threadIdx.x & 63] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += red[i][threadIdx.x & 63];
+    const float mean = tot / (float)len;
+    __syncthreads();
+    float q = 0.f;
+    for (int t = ty; t < len; t += 8) {
+        const float d = xb[(size_t)t * C] - mean;
+        q += d * d;
+    }
+    red[ty][threadIdx.x & 63] = q;
+    __syncthreads();
+    float qt = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qt += red[i][threadIdx.x & 63];
+    const float rstd = rsqrtf(qt / (float)len + 1e-5f);
+    OutT* yb = y + (size_t)b * T * C + c;
+    // frames beyond len get the same affine map: finite, never consumed by valid rows
+    for (int t = ty; t < T; t += 8) store_from_f32<OutT>(yb + (size_t)t * C, (xb[(size_t)t * C] - mean) * rstd);
+}
+
+int launch_instnorm(int out_dtype, const float* x, void* y, const int32_t* lens, int B, int T, int C, hipStream_t s) {
+    DIMX_REQUIRE(x && y && B > 0 && T > 0, DIMX_ERR_ARG, "instnorm: null operand");
+    DIMX_REQUIRE(C % 64 == 0, DIMX_ERR_ARG, "instnorm: C=%d must be a multiple of 64", C);
+    dim3 grid(C / 64, B), block(512);
+    if (out_dtype == DIMX_BF16)
+        hipLaunchKernelGGL((instnorm_kernel<bf16>), grid, block, 0, s, x, (bf16*)y, lens, T, C);
+    else
+        hipLaunchKernelGGL((instnorm_kernel<float>), grid, block, 0, s, x, (float*)y, lens, T, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+}  // namespace dimx

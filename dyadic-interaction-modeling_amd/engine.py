@@ -1,0 +1,236 @@
+"""Engine: one libdimx_hip handle on one GPU + its device workspace.
+
+This is the thin host layer above the C-ABI: it owns the handle, uploads a reference-shaped
+state dict, sizes the workspace with ``dimx_workspace_bytes`` and forwards torch CUDA tensors
+as raw pointers on the current HIP stream.  All arithmetic happens in the HIP library.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+class Engine:
+    def __init__(self, device=None, mode=L.MODE_PARITY_F32):
+        if not torch.cuda.is_available():
+            raise L.DimxError("dimx needs a ROCm GPU (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = L.load()
+        self.mode = mode
+        self.dims = L.default_dims()
+        h = ctypes.c_void_p()
+        L.check(self.lib.dimx_create(ctypes.byref(h), self.device.index, ctypes.byref(self.dims), mode),
+                "dimx_create")
+        self.h = h
+        self._ws = None
+        self._ws_bytes = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dimx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd):
+        """Upload every tensor of a reference-shaped state dict (extra reference keys that
+        are not on the hot path are ignored by the library)."""
+        keep, descs = [], []
+        for name, t in sd.items():
+            a = t.detach().to("cpu", torch.float32).contiguous().numpy()
+            keep.append(a)
+            d = L.WeightDesc()
+            d.name = name.encode()
+            d.data = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            d.ndim = a.ndim
+            for i, s in enumerate(a.shape):
+                d.shape[i] = s
+            descs.append(d)
+        arr = (L.WeightDesc * len(descs))(*descs)
+        L.check(self.lib.dimx_load_weights(self.h, arr, len(descs)), "dimx_load_weights")
+
+    def missing_weights(self):
+        return self.lib.dimx_missing_weights(self.h)
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B, T):
+        need = self.lib.dimx_workspace_bytes(self.h, B, T)
+        if need == 0:
+            raise L.DimxError("dimx_workspace_bytes(%d,%d) = 0" % (B, T))
+        if self._ws is None or self._ws_bytes < need:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        base = self._ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        return ctypes.c_void_p(aligned), self._ws_bytes - (aligned - base) + 256
+
+    def _s(self):
+        return L.stream_ptr(self.device)
+
+    def _chk(self, *ts):
+        for t in ts:
+            if t is not None:
+                assert t.device == self.device and t.is_contiguous(), "tensor must be contiguous on %s" % self.device
+
+    # ------------------------------------------------------------------ stages
+    def vq_encode(self, which, x, lens=None, pe_mode=0, row_offset=0, pad_value=-100, return_z=False):
+        B, T, _ = x.shape
+        x = x.to(torch.float32).contiguous()
+        self._chk(x, lens)
+        idx = torch.empty(B, T, dtype=torch.int32, device=self.device)
+        z = torch.empty(B, T, self.dims.vq_zdim, dtype=torch.float32, device=self.device) if return_z else None
+        ws, wsb = self.workspace(B, T)
+        L.check(self.lib.dimx_vq_encode(self.h, which, L.ptr(x), L.ptr(lens), B, T, pe_mode, row_offset,
+                                        pad_value, L.ptr(idx), L.ptr(z), ws, wsb, self._s()), "dimx_vq_encode")
+        return (idx, z) if return_z else idx
+
+    def vq_argmin(self, which, z, with_stats=False):
+        z = z.to(torch.float32).contiguous()
+        N = z.shape[0]
+        idx = torch.empty(N, dtype=torch.int32, device=self.device)
+        bd = torch.empty(N, dtype=torch.float32, device=self.device) if with_stats else None
+        mg = torch.empty(N, dtype=torch.float32, device=self.device) if with_stats else None
+        L.check(self.lib.dimx_vq_argmin(self.h, which, L.ptr(z), N, L.ptr(idx), L.ptr(bd), L.ptr(mg), self._s()),
+                "dimx_vq_argmin")
+        return (idx, bd, mg) if with_stats else idx
+
+    def vq_decode(self, which, idx, row_offset=0):
+        B, Lq = idx.shape
+        idx = idx.to(torch.int32).contiguous()
+        self._chk(idx)
+        out = torch.empty(B, Lq, self.dims.vq_in_dim, dtype=torch.float32, device=self.device)
+        ws, wsb = self.workspace(B, Lq)
+        L.check(self.lib.dimx_vq_decode(self.h, which, L.ptr(idx), B, Lq, row_offset, L.ptr(out), ws, wsb,
+                                        self._s()), "dimx_vq_decode")
+        return out
+
+    def encode_ctx(self, v_speaker, v_audio, mask_u8, for_generate, return_x_s=False):
+        B, T, _ = v_speaker.shape
+        v_speaker = v_speaker.to(torch.float32).contiguous()
+        v_audio = v_audio.to(torch.float32).contiguous()
+        self._chk(v_speaker, v_audio, mask_u8)
+        x_s = torch.empty(B, T, self.dims.dim, dtype=torch.float32, device=self.device) if return_x_s else None
+        ws, wsb = self.workspace(B, T)
+        L.check(self.lib.dimx_encode_ctx(self.h, L.ptr(v_speaker), L.ptr(v_audio), L.ptr(mask_u8), B, T,
+                                         1 if for_generate else 0, L.ptr(x_s), ws, wsb, self._s()),
+                "dimx_encode_ctx")
+        return x_s
+
+    def decode_tf(self, z_l, mask_u8, kv_mask_u8=None):
+        B, T = z_l.shape
+        z_l = z_l.to(torch.int32).contiguous()
+        self._chk(z_l, mask_u8, kv_mask_u8)
+        n = T - 1
+        logits = torch.empty(B, n, self.dims.num_tokens, dtype=torch.float32, device=self.device)
+        row_loss = torch.empty(B, n, dtype=torch.float32, device=self.device)
+        amax = torch.empty(B, n, dtype=torch.int32, device=self.device)
+        ws, wsb = self.workspace(B, T)
+        L.check(self.lib.dimx_decode_tf(self.h, L.ptr(z_l), L.ptr(mask_u8), L.ptr(kv_mask_u8), B, T, L.ptr(logits),
+                                        L.ptr(row_loss), L.ptr(amax), ws, wsb, self._s()), "dimx_decode_tf")
+        return logits, row_loss, amax
+
+    def generate(self, start, mask_u8, T, temperature=1.0, top_k=52, noise=None, seed=0, return_logits=False):
+        B = start.shape[0]
+        start = start.to(torch.int32).contiguous()
+        if noise is not None:
+            noise = noise.to(torch.float32).contiguous()
+            assert tuple(noise.shape) == (T - 1, B, self.dims.num_tokens)
+        self._chk(start, mask_u8, noise)
+        tokens = torch.empty(B, T - 1, dtype=torch.int32, device=self.device)
+        lg = torch.empty(B, T - 1, self.dims.num_tokens, dtype=torch.float32, device=self.device) \
+            if return_logits else None
+        ws, wsb = self.workspace(B, T)
+        L.check(self.lib.dimx_generate(self.h, L.ptr(start), L.ptr(mask_u8), B, T, float(temperature), int(top_k),
+                                       L.ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF, L.ptr(tokens), L.ptr(lg), ws,
+                                       wsb, self._s()), "dimx_generate")
+        return (tokens, lg) if return_logits else tokens
+
+
+# ---------------------------------------------------------------------- kernel-level wrappers (tests)
+def _pad_k(w, mult):
+    N, K = w.shape
+    Kp = (K + mult - 1) // mult * mult
+    if Kp == K:
+        return w.contiguous()
+    out = torch.zeros(N, Kp, dtype=w.dtype, device=w.device)
+    out[:, :K] = w
+    return out
+
+
+def op_gemm(a, w, bias=None, act=0, residual=None, bf16=False, out_bf16=False, conv_T=0, conv_lens=None):
+    """epilogue(a[M,K] @ w[N,K]^T); conv_T > 0: a is [B*conv_T, C], w is [N, C, 5]."""
+    lib = L.load()
+    dev = a.device
+    if conv_T > 0:
+        N, C, _ = w.shape
+        wk = w.permute(0, 2, 1).reshape(N, 5 * C)
+        K = 5 * C
+    else:
+        wk, K = w, w.shape[1]
+        N = w.shape[0]
+    dt = torch.bfloat16 if bf16 else torch.float32
+    a_ = a.to(dt).contiguous()
+    w_ = _pad_k(wk.to(dt), 64 if bf16 else 32)
+    M = a_.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=dev)
+    L.check(lib.dimx_op_gemm(L.BF16 if bf16 else L.F32, L.BF16 if out_bf16 else L.F32, L.ptr(a_), a_.shape[1],
+                             L.ptr(w_), w_.shape[1], L.ptr(out), N, M, N, K, L.ptr(bias), act, L.ptr(residual),
+                             residual.shape[1] if residual is not None else 0, conv_T, L.ptr(conv_lens),
+                             L.stream_ptr(dev)), "dimx_op_gemm")
+    return out
+
+
+def op_layernorm(x, gamma, beta=None, out_bf16=False):
+    lib = L.load()
+    M, C = x.shape
+    y = torch.empty(M, C, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    L.check(lib.dimx_op_layernorm(L.BF16 if out_bf16 else L.F32, L.ptr(x.contiguous()), L.ptr(y), L.ptr(gamma),
+                                  L.ptr(beta), M, C, L.stream_ptr(x.device)), "dimx_op_layernorm")
+    return y
+
+
+def op_instnorm(x, lens=None, out_bf16=False):
+    lib = L.load()
+    B, T, C = x.shape
+    y = torch.empty(B, T, C, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    L.check(lib.dimx_op_instnorm(L.BF16 if out_bf16 else L.F32, L.ptr(x.contiguous()), L.ptr(y), L.ptr(lens), B, T,
+                                 C, L.stream_ptr(x.device)), "dimx_op_instnorm")
+    return y
+
+
+def op_attention(q, k, v, scale, causal=False, lens=None, kmask=None, bf16=False):
+    """q [B,Lq,H,D], k/v [B,Lk,H,D] -> [B,Lq,H,D]; v is transposed to [B,H,D,Lk_pad] here."""
+    lib = L.load()
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    dt = torch.bfloat16 if bf16 else torch.float32
+    Lp = (Lk + 7) // 8 * 8
+    q_ = q.to(dt).reshape(B, Lq, H * D).contiguous()
+    k_ = k.to(dt).reshape(B, Lk, H * D).contiguous()
+    vt = torch.full((B, H, D, Lp), float("nan"), dtype=dt, device=q.device)   # padding must be ignored
+    vt[..., :Lk] = v.to(dt).permute(0, 2, 3, 1)
+    out = torch.empty(B, Lq, H * D, dtype=dt, device=q.device)
+    L.check(lib.dimx_op_attention(L.BF16 if bf16 else L.F32, L.ptr(q_), L.ptr(k_), L.ptr(vt), L.ptr(out), B, H, Lq,
+                                  Lk, D, H * D, H * D, Lp, H * D, float(scale), 1 if causal else 0, L.ptr(lens),
+                                  L.ptr(kmask), L.stream_ptr(q.device)), "dimx_op_attention")
+    return out.view(B, Lq, H, D)
+
+
+def op_sample(logits, top_k=52, temperature=1.0, noise=None, seed=0, step=0):
+    lib = L.load()
+    R = logits.shape[0]
+    tok = torch.empty(R, dtype=torch.int32, device=logits.device)
+    L.check(lib.dimx_op_sample(L.ptr(logits.contiguous()), R, top_k, float(temperature), L.ptr(noise), int(seed),
+                               int(step), L.ptr(tok), L.stream_ptr(logits.device)), "dimx_op_sample")
+    return tok

@@ -1,0 +1,115 @@
+"""ctypes binding of libdimx_hip.so (the C-ABI of include/dimx.h).
+
+torch is used only for device memory and streams: tensors are handed to the library as
+raw ``data_ptr()`` values plus the current HIP stream.  There is NO fallback: if the
+shared library is missing, cannot be built, or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64,
+                    c_void_p)
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdimx_hip.so")
+
+MODE_PARITY_F32 = 0
+MODE_PERF_BF16 = 1
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_GELU_TANH, ACT_GELU_ERF = 0, 1, 2, 3
+
+
+class DimxError(RuntimeError):
+    pass
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in (
+        "vq_in_dim", "vq_hidden", "vq_layers", "vq_heads", "vq_inter", "vq_n_embed", "vq_zdim",
+        "dim_in", "dim", "dim_a", "enc_depth", "dec_depth", "heads", "dim_head", "num_tokens",
+        "max_seq_len", "ff_mult")]
+
+
+class WeightDesc(ctypes.Structure):
+    _fields_ = [("name", c_char_p), ("data", POINTER(c_float)), ("ndim", c_int), ("shape", c_int64 * 4)]
+
+
+# every symbol include/dimx.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "dimx_version": (c_int, []),
+    "dimx_last_error": (c_char_p, []),
+    "dimx_default_dims": (None, [POINTER(Dims)]),
+    "dimx_create": (c_int, [POINTER(c_void_p), c_int, POINTER(Dims), c_int]),
+    "dimx_destroy": (c_int, [c_void_p]),
+    "dimx_numeric_mode": (c_int, [c_void_p]),
+    "dimx_load_weights": (c_int, [c_void_p, POINTER(WeightDesc), c_int]),
+    "dimx_missing_weights": (c_int, [c_void_p]),
+    "dimx_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "dimx_vq_encode": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int32,
+                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dimx_vq_argmin": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dimx_vq_decode": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
+    "dimx_encode_ctx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
+    "dimx_decode_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dimx_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_uint64,
+                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                             c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dimx_op_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dimx_op_instnorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dimx_op_attention": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
+                                  c_void_p]),
+    "dimx_op_sample": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p,
+                               c_void_p]),
+}
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """dlopen the library (building it in-tree with hipcc first if it is absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise DimxError("libdimx_hip.so not found at %s (run python __graft_entry__.py build)" % LIB_PATH)
+        from . import build as _build
+        _build.build()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().dimx_last_error()
+        raise DimxError("%s failed (%d): %s" % (what or "dimx call", status,
+                                                 msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """raw device/host pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "dimx needs contiguous tensors"
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def default_dims():
+    d = Dims()
+    load().dimx_default_dims(ctypes.byref(d))
+    return d

@@ -1,0 +1,161 @@
+/* dimx.h -- C-ABI of libdimx_hip.so, the MI355X (gfx950) implementation of the DIM-Listener
+ * hot path.  Plain pointers and sizes only; no torch types.  Every function returns 0 on
+ * success and a negative dimx_status on failure (never throws); dimx_last_error() gives the
+ * thread-local message.  All device work is enqueued asynchronously on the hipStream_t passed
+ * in (as void*; NULL = the null stream).  A handle is bound to one device and is not
+ * re-entrant across streams.
+ *
+ * Each stage entry point replaces one method of the reference's Python operator surface
+ * (paths relative to /root/reference):
+ *
+ *   dimx_vq_encode   <- SLMFT.forward_vq / VQAutoEncoder.encode
+ *                       (code/seq2seq_pretrain.py:480-494, code/models/stage1_BIWI.py:22-27,307-317)
+ *   dimx_vq_argmin   <- VectorQuantizer.forward, argmin part (code/models/lib/quantizer.py:35-47)
+ *   dimx_vq_decode   <- SLMFT.forward_vq_decoder / VQAutoEncoder.decode
+ *                       (code/seq2seq_pretrain.py:454-464, code/models/stage1_BIWI.py:29-37,376-393)
+ *   dimx_encode_ctx  <- SLMFT.forward_encoder + the context concat of forward_decoder
+ *                       (code/seq2seq_pretrain.py:431-446)
+ *   dimx_decode_tf   <- AutoregressiveWrapper.forward via forward_decoder(mode='train')
+ *                       (code/seq2seq_pretrain.py:448)
+ *   dimx_generate    <- AutoregressiveWrapper.generate via forward_decoder(mode='val')
+ *                       (code/seq2seq_pretrain.py:450)
+ *
+ * The dimx_op_* functions expose the individual HIP kernels for unit parity tests.
+ */
+#ifndef DIMX_H
+#define DIMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dimx_ctx* dimx_handle;
+
+typedef enum {
+    DIMX_OK = 0,
+    DIMX_ERR_ARG = -1,      /* bad argument (null pointer, shape out of range, misaligned) */
+    DIMX_ERR_HIP = -2,      /* a HIP runtime call failed */
+    DIMX_ERR_WEIGHT = -3,   /* unknown / missing / wrongly shaped weight tensor */
+    DIMX_ERR_STATE = -4,    /* call order violated (e.g. decode before encode_ctx) */
+    DIMX_ERR_WORKSPACE = -5 /* workspace too small */
+} dimx_status;
+
+/* numeric modes */
+#define DIMX_MODE_PARITY_F32 0 /* f32 storage, f32-input MFMA: matches the CPU oracle to ~1e-5 */
+#define DIMX_MODE_PERF_BF16 1  /* bf16 GEMM/attention operands, f32 accumulate + f32 residual stream */
+
+/* element types for dimx_op_* */
+#define DIMX_F32 0
+#define DIMX_BF16 1
+
+typedef struct {
+    /* VQ-VAE (reference code/config.yaml:15-30) */
+    int vq_in_dim, vq_hidden, vq_layers, vq_heads, vq_inter, vq_n_embed, vq_zdim;
+    /* seq2seq (reference code/seq2seq_pretrain.py:369-418) */
+    int dim_in, dim, dim_a, enc_depth, dec_depth, heads, dim_head, num_tokens, max_seq_len, ff_mult;
+} dimx_dims;
+
+typedef struct {
+    const char* name;   /* state-dict key, e.g. "listener_vq.encoder.vertice_mapping.0.weight" */
+    const float* data;  /* HOST pointer, float32, contiguous row-major; caller keeps ownership */
+    int ndim;
+    int64_t shape[4];
+} dimx_weight_desc;
+
+int dimx_version(void);
+const char* dimx_last_error(void);
+void dimx_default_dims(dimx_dims* d);
+
+int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeric_mode);
+int dimx_destroy(dimx_handle h);
+int dimx_numeric_mode(dimx_handle h);
+
+/* Upload + pack weights (fused QKV, conv tap-major, bf16 copies, K padding).  May be called
+ * several times; every key of the hot path must have been supplied before the first stage call
+ * that needs it.  Unknown keys that belong to the reference surface but not to the path
+ * (encoder_l.*, norm_l.*, norm.*, patch_embed_l, patch_embed_dec_l, *.project_out.weight) are
+ * accepted and ignored.  Synchronous. */
+int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n);
+/* number of hot-path tensors still missing (0 = ready) */
+int dimx_missing_weights(dimx_handle h);
+
+/* Bytes of caller-provided device workspace needed by any stage call at (B, T). */
+size_t dimx_workspace_bytes(dimx_handle h, int B, int T);
+
+/* which: 0 = speaker VQ-VAE, 1 = listener VQ-VAE.
+ * x: [B,T,56] f32, valid frames left-aligned; lens: [B] int32 device (NULL = all T).
+ * pe_mode 0: every clip gets positional row 0 (the reference's batch-1 calls in forward_vq);
+ * pe_mode 1: clip b gets row b + batch_row_offset (public batched VQAutoEncoder.encode).
+ * idx: [B,T] int32, frames t >= lens[b] are set to pad_value.  z_out (optional) [B,T,128] f32. */
+int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens, int B, int T,
+                   int pe_mode, int batch_row_offset, int32_t pad_value, int32_t* idx, float* z_out,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* Nearest codebook entry, first index on ties.  z: [N,128] f32.  best_d / margin optional [N]. */
+int dimx_vq_argmin(dimx_handle h, int which, const float* z, int N, int32_t* idx, float* best_d,
+                   float* margin, void* stream);
+
+/* idx: [B,L] int32 in [0,512).  Clip b is decoded with positional row b + batch_row_offset and
+ * InstanceNorm / attention span the full L (reference behaviour on padded batches).
+ * out: [B,L,56] f32. */
+int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset,
+                   float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* Speaker encoder stack + context assembly + cross-attention K/V projection for all decoder
+ * layers.  v_speaker [B,T,56] f32, v_audio [B,T,768] f32, mask [B,T] uint8 (1 = valid frame).
+ * The result lives in the workspace (same ws must be passed to the decode call that follows).
+ * x_s_out (optional): [B,T,384] f32 = norm_s(encoder_joint(encoder_s(.))).
+ * for_generate: 0 -> cross K/V laid out for dimx_decode_tf, 1 -> for dimx_generate. */
+int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio, const uint8_t* mask,
+                    int B, int T, int for_generate, float* x_s_out, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* Teacher-forced decoder pass.  z_l [B,T] int32 (-100 = ignore), ctx_mask [B,T] uint8,
+ * kv_mask [B,T-1] uint8 keep-mask for self-attention keys (NULL = keep all).
+ * logits [B,T-1,512] f32; row_loss (optional) [B,T-1] f32 = per-position cross entropy (0 where the
+ * target is -100); argmax_tok (optional) [B,T-1] int32. */
+int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, const uint8_t* kv_mask,
+                   int B, int T, float* logits, float* row_loss, int32_t* argmax_tok, void* ws,
+                   size_t ws_bytes, void* stream);
+
+/* Autoregressive generation of T-1 tokens from start[B] with KV cache.
+ * temperature <= 0 or exp_noise == NULL && seed == 0 -> greedy argmax.
+ * exp_noise: [T-1,B,512] f32 Exp(1) samples (token = argmax softmax(top_k(logits)/temp)/noise);
+ * if NULL and seed != 0 the noise is drawn on device from a counter-based generator.
+ * tokens: [B,T-1] int32.  logits_out (optional): [B,T-1,512] f32 raw logits of every step. */
+int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T,
+                  float temperature, int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens,
+                  float* logits_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- kernel-level entry points (unit parity tests) -------------------------------------- */
+
+/* C = epilogue(A[M,K] . W[N,K]^T).  A/W element type `in_dtype`, C element type `out_dtype`.
+ * W must be K-padded to a multiple of 64 (bf16) / 32 (f32) elements with zeros (ldw = padded K).
+ * act: 0 none, 1 LeakyReLU(0.2), 2 GELU-tanh, 3 GELU-erf.  bias [N] f32 / residual [M,ldr] f32
+ * optional.  conv_T > 0: A is [B*conv_T, C] and the GEMM is a k=5 replicate-padded temporal
+ * convolution with K = 5*C, W tap-major [N][5][C]; conv_lens optional [B] int32. */
+int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void* W, int ldw, void* C,
+                 int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
+                 int ldr, int conv_T, const int32_t* conv_lens, void* stream);
+/* y = LayerNorm(x) over the last dim (C in {384,1152}), eps 1e-5; beta optional. */
+int dimx_op_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta,
+                      int M, int C, void* stream);
+/* y[b,t,c] = (x - mean_bc) / sqrt(var_bc + 1e-5) with statistics over t < len_b (biased var). */
+int dimx_op_instnorm(int out_dtype, const float* x, void* y, const int32_t* lens, int B, int T, int C,
+                     void* stream);
+/* Flash-style attention on packed [B,L,H*D] q/k and a transposed v [B,H,D,Lk_pad] (as the QKV GEMM
+ * writes it).  D in {48,64}.  out [B,Lq,H*D]. */
+int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int H,
+                      int Lq, int Lk, int D, int ldq, int ldk, int ld_vt, int ldo, float scale,
+                      int causal, const int32_t* lens, const uint8_t* kmask, void* stream);
+/* tokens = sampler(logits[R,512]) -- see dimx_generate. */
+int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise,
+                   uint64_t seed, uint64_t step, int32_t* tokens, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIMX_H */

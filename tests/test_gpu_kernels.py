@@ -1,0 +1,184 @@
+"""GPU: each HIP kernel through the C-ABI against a plain PyTorch fp32/fp64 reference of the same op."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def _err(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+ACTS = {0: lambda x: x, 1: lambda x: F.leaky_relu(x, 0.2),
+        2: lambda x: x * 0.5 * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3))),
+        3: lambda x: F.gelu(x)}
+
+
+@pytest.mark.parametrize("M,N,K,act,use_bias,use_res", [
+    (300, 384, 56, 1, True, False), (1000, 1152, 384, 0, False, True), (77, 56, 384, 0, False, False),
+    (256, 4608, 1152, 3, True, False), (130, 128, 1536, 2, True, True), (40000, 384, 384, 0, True, True),
+    (1, 512, 1152, 0, False, False), (33000, 1536, 384, 2, True, False)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gemm(dev, M, N, K, act, use_bias, use_res, bf16):
+    from dimx import engine
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) if use_bias else None
+    res = torch.randn(M, N, generator=g) if use_res else None
+    aa, ww = (_bf(a), _bf(w)) if bf16 else (a, w)
+    ref = aa.double() @ ww.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    ref = ACTS[act](ref)
+    if res is not None:
+        ref = ref + res.double()
+    out = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev) if use_bias else None, act,
+                         res.to(dev) if use_res else None, bf16=bf16)
+    e = _err(out, ref)
+    tol = 2e-3 if bf16 else 2e-5 * max(1.0, math.sqrt(K) / 8)
+    assert e < tol, "gemm err %g" % e
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gemm_bf16_out(dev, bf16):
+    from dimx import engine
+    if not bf16:
+        pytest.skip("f32 inputs always produce f32")
+    g = torch.Generator().manual_seed(3)
+    a, w = torch.randn(513, 384, generator=g), torch.randn(768, 384, generator=g) / 20
+    ref = _bf(a).double() @ _bf(w).double().t()
+    out = engine.op_gemm(a.to(dev), w.to(dev), bf16=True, out_bf16=True)
+    assert out.dtype == torch.bfloat16
+    assert _err(out.float(), ref) < 0.05
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("B,T,lens", [(3, 40, [40, 33, 5]), (2, 300, None), (4, 7, [1, 2, 7, 3])])
+def test_conv5_gemm(dev, B, T, lens, bf16):
+    from dimx import engine
+    C = 384
+    g = torch.Generator().manual_seed(B * T)
+    x = torch.randn(B, T, C, generator=g)
+    w = torch.randn(C, C, 5, generator=g) / math.sqrt(5 * C)
+    bias = torch.randn(C, generator=g)
+    xx, ww = (_bf(x), _bf(w)) if bf16 else (x, w)
+    ref = torch.zeros(B, T, C, dtype=torch.float64)
+    for b in range(B):
+        n = lens[b] if lens else T
+        xb = xx[b, :n].double().t()[None]
+        yb = F.conv1d(F.pad(xb, (2, 2), mode="replicate"), ww.double(), bias.double())
+        ref[b, :n] = F.leaky_relu(yb[0].t(), 0.2)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    out = engine.op_gemm(x.view(B * T, C).to(dev), w.to(dev), bias.to(dev), 1, bf16=bf16, conv_T=T,
+                         conv_lens=lens_t).view(B, T, C)
+    for b in range(B):
+        n = lens[b] if lens else T
+        e = _err(out[b, :n], ref[b, :n])
+        assert e < (3e-3 if bf16 else 5e-5), "conv err %g (clip %d)" % (e, b)
+
+
+@pytest.mark.parametrize("C", [384, 1152])
+@pytest.mark.parametrize("use_beta", [True, False])
+def test_layernorm(dev, C, use_beta):
+    from dimx import engine
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(1001, C, generator=g) * 3 + 1
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ref = F.layer_norm(x.double(), (C,), gamma.double(), beta.double() if use_beta else None, 1e-5)
+    out = engine.op_layernorm(x.to(dev), gamma.to(dev), beta.to(dev) if use_beta else None)
+    assert _err(out, ref) < 1e-5
+    outb = engine.op_layernorm(x.to(dev), gamma.to(dev), beta.to(dev) if use_beta else None, out_bf16=True)
+    assert _err(outb.float(), ref) < 0.05
+
+
+@pytest.mark.parametrize("B,T,lens", [(3, 40, [40, 33, 5]), (2, 299, None)])
+def test_instnorm(dev, B, T, lens):
+    from dimx import engine
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, 384, generator=g) * 2 + 0.5
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    out = engine.op_instnorm(x.to(dev), lens_t)
+    for b in range(B):
+        n = lens[b] if lens else T
+        ref = F.instance_norm(x[b, :n].double().t()[None], eps=1e-5)[0].t()
+        assert _err(out[b, :n], ref) < 2e-5
+
+
+def _attn_ref(q, k, v, scale, causal, lens, kmask):
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    dots = torch.einsum("bihd,bjhd->bhij", q.double(), k.double()) * scale
+    keep = torch.ones(B, 1, Lq, Lk, dtype=torch.bool)
+    if causal:
+        keep = keep & ~torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), diagonal=1)
+    if lens is not None:
+        keep = keep & (torch.arange(Lk)[None, :] < torch.tensor(lens)[:, None])[:, None, None, :]
+    if kmask is not None:
+        keep = keep & kmask.bool()[:, None, None, :]
+    dots = dots.masked_fill(~keep, -torch.finfo(torch.float64).max)
+    return torch.einsum("bhij,bjhd->bihd", dots.softmax(-1), v.double())
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("B,H,Lq,Lk,D,causal,lens,rand_mask", [
+    (2, 8, 40, 40, 48, False, [40, 13], False), (1, 8, 300, 300, 48, False, None, False),
+    (2, 12, 299, 299, 64, True, None, True), (3, 12, 70, 70, 64, True, None, False),
+    (2, 12, 129, 130, 64, False, None, True), (1, 12, 5, 5, 64, True, None, False),
+    (1, 8, 1500, 1500, 48, False, None, False)])
+def test_attention(dev, B, H, Lq, Lk, D, causal, lens, rand_mask, bf16):
+    from dimx import engine
+    g = torch.Generator().manual_seed(Lq * 31 + D)
+    q, k, v = (torch.randn(B, L_, H, D, generator=g) for L_ in (Lq, Lk, Lk))
+    scale = 384 ** -0.5 if D == 48 else 0.125
+    kmask = None
+    if rand_mask:
+        kmask = (torch.rand(B, Lk, generator=g) > 0.3).to(torch.uint8)
+        kmask[:, 0] = 1
+    qq, kk, vv = ((_bf(q), _bf(k), _bf(v)) if bf16 else (q, k, v))
+    ref = _attn_ref(qq, kk, vv, scale, causal, lens, kmask)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    out = engine.op_attention(q.to(dev), k.to(dev), v.to(dev), scale, causal, lens_t,
+                              kmask.to(dev) if kmask is not None else None, bf16=bf16)
+    assert torch.isfinite(out.float()).all()
+    for b in range(B):
+        n = lens[b] if lens else Lq
+        e = _err(out[b, :n].float(), ref[b, :n])
+        assert e < (2e-2 if bf16 else 2e-5), "attention err %g" % e
+
+
+def test_vq_argmin_and_sampler(dev, golden_dir):
+    from dimx import engine
+    from oracle import ref_cpu
+    g = torch.Generator().manual_seed(5)
+    # sampler vs the oracle and vs the torch.multinomial fixture
+    fx = np.load(os.path.join(golden_dir, "sampler_multinomial.npz"))
+    tok = engine.op_sample(torch.from_numpy(fx["logits"]).to(dev), 52, 1.0, torch.from_numpy(fx["noise"]).to(dev))
+    assert np.array_equal(tok.cpu().numpy(), fx["ids"].astype(np.int32))
+    logits = torch.randn(300, 512, generator=g) * 2
+    noise = torch.empty(300, 512).exponential_(1, generator=g)
+    ref = ref_cpu.sample_tokens(logits, noise)
+    tok = engine.op_sample(logits.to(dev), 52, 1.0, noise.to(dev))
+    assert (tok.cpu().long() == ref).float().mean().item() > 0.995
+    greedy = engine.op_sample(logits.to(dev), 52, 0.0)
+    assert torch.equal(greedy.cpu().long(), logits.argmax(-1))
+    dr = engine.op_sample(logits.to(dev), 52, 1.0, None, seed=1234, step=3)
+    top = ref_cpu.top_k_filter(logits, 52)
+    assert torch.isfinite(top.gather(1, dr.cpu().long()[:, None])).all(), "device-RNG sample outside the top-k set"
