@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""bench.py -- DIM-Listener clips/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the hot path over one batch of synthetic dyad clips already resident in HBM:
+listener VQ encode -> speaker encoder stack + context + cross-K/V -> T-1 autoregressive decoder steps
+(KV cache, top-k sampler) -> VQ decode -> continuous loss, i.e. ``SLMFT.forward(mode='val')``; with N > 1
+every rank does that on its own 256 clips (weak scaling, weights replicated) and the generated code
+indices are all-gathered (RCCL over xGMI) inside the timed region.
+
+N = 1 workload = BASELINE config C3 (B=256, T=300, autoregressive decode, bf16 perf mode).
+Extra objects on the line: ``roofline`` (dominant kernel, timed live with HIP events) and ``cpu_baseline``
+(the CPU oracle on a bounded sample of the same workload, rank 0 at N=1 only).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--frames 300] [--mode bf16|f32]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import dimx  # noqa: E402,F401
+from dimx import dist as ddist  # noqa: E402
+from dimx import lib as L  # noqa: E402
+from dimx import prng, weights  # noqa: E402
+from dimx.seq2seq_pretrain import SLMFT  # noqa: E402
+
+SEED = 20260928
+GFLOP_PER_CLIP_T300 = 73.5  # SURVEY.md section 8d, necessary work
+
+
+def synth_batch(B, T, device, salt):
+    v_s = torch.from_numpy(prng.normal(SEED + salt, "bench.v_speaker", (B, T, 56))).to(device)
+    v_l = torch.from_numpy(prng.normal(SEED + salt, "bench.v_listener", (B, T, 56))).to(device)
+    v_a = torch.from_numpy(prng.normal(SEED + salt, "bench.v_audio", (B, T, 768))).to(device)
+    mask = torch.ones(B, T, dtype=torch.bool, device=device)
+    return v_s, v_l, v_a, mask
+
+
+def cpu_baseline(T, seconds_budget=25.0):
+    """The CPU oracle (kind 'port') on a bounded sample: b clips of the same shape, all host cores."""
+    from oracle import ref_cpu
+    torch.set_grad_enabled(False)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = weights.synth_state_dict(weights.slmft_spec(), SEED)
+    b = 2
+    v_s = torch.from_numpy(prng.normal(SEED, "bench.v_speaker", (b, T, 56)))
+    v_l = torch.from_numpy(prng.normal(SEED, "bench.v_listener", (b, T, 56)))
+    v_a = torch.from_numpy(prng.normal(SEED, "bench.v_audio", (b, T, 768)))
+    mask = torch.ones(b, T, dtype=torch.bool)
+    noise = torch.from_numpy(prng.exponential(SEED, "bench.noise", (T - 1, b, 512)))
+    t0 = time.perf_counter()
+    ref_cpu.slmft_forward(sd, v_s, v_l, v_a, mask, "val", noise=noise)
+    t1 = time.perf_counter() - t0
+    reps, best = 1, t1
+    while (reps + 1) * t1 < seconds_budget and reps < 3:
+        t0 = time.perf_counter()
+        ref_cpu.slmft_forward(sd, v_s, v_l, v_a, mask, "val", noise=noise)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    return {"value": b / best, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "%d clips x T=%d, oracle/ref_cpu.slmft_forward(mode='val'), best of %d runs, "
+                      "torch CPU fp32, %d threads" % (b, T, reps, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = ddist.init_from_env()
+    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.set_grad_enabled(False)
+    B, T = args.batch, args.frames
+    mode = L.MODE_PERF_BF16 if args.mode == "bf16" else L.MODE_PARITY_F32
+
+    model = SLMFT(synthetic_seed=SEED, numeric_mode=mode).eval()
+    v_s, v_l, v_a, mask = synth_batch(B, T, device, salt=rank)
+    eng = model.engine(device)
+
+    def step(i):
+        _, _, pred, tokens = model(v_s, v_l, v_a, mask, mode="val", seed=SEED + i + 1, return_tokens=True)
+        gathered = ddist.all_gather_rows(tokens.to(torch.int32))
+        return pred, gathered
+
+    for i in range(args.warmup):
+        step(i)
+    ddist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pred, gathered = step(args.warmup + i)
+    torch.cuda.synchronize(device)
+    ddist.barrier()
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, device if world > 1 else None)
+    assert gathered.shape == (world * B, T - 1) and torch.isfinite(pred).all()
+
+    if rank != 0:
+        return
+    ms = elapsed / args.steps * 1e3
+    clips_s = world * B * args.steps / elapsed
+    out = {
+        "metric": "listener clips/sec (T=%d, EMOCA-56)" % T, "value": clips_s, "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "C3: B=%d/GPU synthetic dyad clips, T=%d, SLMFT.forward(mode='val'): listener VQ "
+                               "encode + encoder + %d-step AR decode (top-k 52 sampling) + VQ decode"
+                               % (B, T, T - 1),
+                   "global_batch": world * B, "seq_len": T, "parallelism": "dp%d (clips sharded, all-gather of "
+                   "code indices)" % world},
+        "achieved_tflops_necessary_work": clips_s * GFLOP_PER_CLIP_T300 * (T / 300.0) / 1e3,
+    }
+    if not args.no_roofline:
+        from dimx import roofline
+        out["roofline"] = roofline.dominant_kernel(eng, B, T, args.mode)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(T)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -289,39 +289,65 @@ static int pack_xenc(dimx_ctx* c, const std::string& pre, XEnc* e) {
 static void free_packed(dimx_ctx* c) {
     for (void* p : c->dev_allocs) (void)hipFree(p);
     c->dev_allocs.clear();
-    c->packed = false;
+    c->packed_mask = 0;
 }
 
-static int ensure_packed(dimx_ctx* c) {
-    if (c->packed) return DIMX_OK;
-    int missing = 0;
-    std::string first;
-    for (const auto& k : c->required)
-        if (!c->host.count(k)) {
-            if (!missing) first = k;
-            ++missing;
-        }
-    DIMX_REQUIRE(missing == 0, DIMX_ERR_WEIGHT, "%d hot-path weights not loaded (first: %s)", missing, first.c_str());
-    DIMX_HIP(hipSetDevice(c->device));
-    free_packed(c);
-    DIMX_TRY(pack_vq(c, 0));
-    DIMX_TRY(pack_vq(c, 1));
-    DIMX_TRY(pack_xenc(c, "encoder_s.", &c->enc_s));
-    DIMX_TRY(pack_xenc(c, "encoder_joint.", &c->enc_joint));
-    const std::string dp = "decoder_joint.net.";
-    DIMX_TRY(upload_f32(c, dp + "token_emb.emb.weight", &c->dec.tok_emb));
-    for (int i = 0; i < c->d.dec_depth; ++i) {
-        DIMX_TRY(pack_xattn(c, xl(dp, 3 * i), false, &c->dec.self_[i]));
-        DIMX_TRY(pack_xattn(c, xl(dp, 3 * i + 1), true, &c->dec.cross[i]));
-        DIMX_TRY(pack_xff(c, xl(dp, 3 * i + 2), &c->dec.ff[i]));
+enum { COMP_VQ0 = 1, COMP_VQ1 = 2, COMP_ENC = 4, COMP_DEC = 8, COMP_ALL = 15 };
+
+static std::vector<KeySpec> comp_keys(const dimx_dims& d, int comp) {
+    std::vector<KeySpec> k;
+    if (comp == COMP_VQ0) vq_keys(d, 0, k);
+    if (comp == COMP_VQ1) vq_keys(d, 1, k);
+    if (comp == COMP_ENC) {
+        xenc_keys(d, "encoder_s.", d.dim_in, k);
+        xenc_keys(d, "encoder_joint.", d.dim, k);
+        k.push_back({"patch_embed_s", {1, 1, d.dim_in}});
+        k.push_back({"patch_embed_dec_s", {1, 1, d.dim}});
+        k.push_back({"norm_s.weight", {d.dim}});
+        k.push_back({"norm_s.bias", {d.dim}});
     }
-    DIMX_TRY(upload_f32(c, dp + "attn_layers.final_norm.weight", &c->dec.final_g));
-    DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, "", false, &c->dec.logits));
-    DIMX_TRY(upload_f32(c, "patch_embed_s", &c->patch_s));
-    DIMX_TRY(upload_f32(c, "patch_embed_dec_s", &c->patch_dec_s));
-    DIMX_TRY(upload_f32(c, "norm_s.weight", &c->norm_s_g));
-    DIMX_TRY(upload_f32(c, "norm_s.bias", &c->norm_s_b));
-    c->packed = true;
+    if (comp == COMP_DEC) xdec_keys(d, "decoder_joint.net.", k);
+    return k;
+}
+
+// pack the components in `need` that are not packed yet (each stage asks only for what it uses)
+static int ensure_packed(dimx_ctx* c, int need) {
+    if ((c->packed_mask & need) == need) return DIMX_OK;
+    DIMX_HIP(hipSetDevice(c->device));
+    for (int comp = 1; comp <= COMP_DEC; comp <<= 1) {
+        if (!(need & comp) || (c->packed_mask & comp)) continue;
+        int missing = 0;
+        std::string first;
+        for (const auto& k : comp_keys(c->d, comp))
+            if (!c->host.count(k.name)) {
+                if (!missing) first = k.name;
+                ++missing;
+            }
+        DIMX_REQUIRE(missing == 0, DIMX_ERR_WEIGHT, "%d weights of this stage not loaded (first: %s)", missing,
+                     first.c_str());
+        if (comp == COMP_VQ0) DIMX_TRY(pack_vq(c, 0));
+        if (comp == COMP_VQ1) DIMX_TRY(pack_vq(c, 1));
+        if (comp == COMP_ENC) {
+            DIMX_TRY(pack_xenc(c, "encoder_s.", &c->enc_s));
+            DIMX_TRY(pack_xenc(c, "encoder_joint.", &c->enc_joint));
+            DIMX_TRY(upload_f32(c, "patch_embed_s", &c->patch_s));
+            DIMX_TRY(upload_f32(c, "patch_embed_dec_s", &c->patch_dec_s));
+            DIMX_TRY(upload_f32(c, "norm_s.weight", &c->norm_s_g));
+            DIMX_TRY(upload_f32(c, "norm_s.bias", &c->norm_s_b));
+        }
+        if (comp == COMP_DEC) {
+            const std::string dp = "decoder_joint.net.";
+            DIMX_TRY(upload_f32(c, dp + "token_emb.emb.weight", &c->dec.tok_emb));
+            for (int i = 0; i < c->d.dec_depth; ++i) {
+                DIMX_TRY(pack_xattn(c, xl(dp, 3 * i), false, &c->dec.self_[i]));
+                DIMX_TRY(pack_xattn(c, xl(dp, 3 * i + 1), true, &c->dec.cross[i]));
+                DIMX_TRY(pack_xff(c, xl(dp, 3 * i + 2), &c->dec.ff[i]));
+            }
+            DIMX_TRY(upload_f32(c, dp + "attn_layers.final_norm.weight", &c->dec.final_g));
+            DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, "", false, &c->dec.logits));
+        }
+        c->packed_mask |= comp;
+    }
     c->graph_valid = false;
     return DIMX_OK;
 }
@@ -547,6 +573,7 @@ int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n) {
     static thread_local std::map<std::string, std::vector<int64_t>> spec;
     spec.clear();
     for (const auto& k : all_keys(h->d)) spec[k.name] = k.shape;
+    bool dirty = false;
     for (int i = 0; i < n; ++i) {
         const dimx_weight_desc& w = descs[i];
         DIMX_REQUIRE(w.name && w.data && w.ndim >= 1 && w.ndim <= 4, DIMX_ERR_ARG, "dimx_load_weights: bad desc %d", i);
@@ -567,7 +594,14 @@ int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n) {
         HostTensor& t = h->host[name];
         t.shape.assign(w.shape, w.shape + w.ndim);
         t.data.assign(w.data, w.data + cnt);
-        h->packed = false;
+        dirty = true;
+    }
+    if (dirty) {  // re-pack lazily; device copies of the old tensors are released now
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        free_packed(h);
+        h->graph_valid = false;
+        h->ctx_ready = false;
     }
     return DIMX_OK;
 }
@@ -740,15 +774,15 @@ static int run_xenc(const dimx_ctx* c, const XEnc& e, const void* x_in, int ld_i
     return DIMX_OK;
 }
 
-static int check_common(dimx_handle h, int B, int T, void* ws, size_t ws_bytes) {
+static int check_common(dimx_handle h, int B, int T, void* ws, size_t ws_bytes, int need) {
     DIMX_REQUIRE(h, DIMX_ERR_ARG, "null handle");
     DIMX_REQUIRE(B >= 1 && T >= 1 && T <= h->d.max_seq_len, DIMX_ERR_ARG, "B=%d T=%d out of range (T <= %d)", B, T,
                  h->d.max_seq_len);
     DIMX_REQUIRE(ws && ((uintptr_t)ws % 256) == 0, DIMX_ERR_ARG, "workspace must be 256-byte aligned");
-    const size_t need = workspace_bytes(h, B, T);
-    DIMX_REQUIRE(ws_bytes >= need, DIMX_ERR_WORKSPACE, "workspace %zu < required %zu", ws_bytes, need);
+    const size_t need_bytes = workspace_bytes(h, B, T);
+    DIMX_REQUIRE(ws_bytes >= need_bytes, DIMX_ERR_WORKSPACE, "workspace %zu < required %zu", ws_bytes, need_bytes);
     DIMX_HIP(hipSetDevice(h->device));
-    DIMX_TRY(ensure_packed(h));
+    DIMX_TRY(ensure_packed(h, need));
     return DIMX_OK;
 }
 
@@ -773,15 +807,16 @@ int dimx_vq_argmin(dimx_handle h, int which, const float* z, int N, int32_t* idx
                    void* stream) {
     DIMX_REQUIRE(h && (which == 0 || which == 1), DIMX_ERR_ARG, "vq_argmin: bad handle/which");
     DIMX_HIP(hipSetDevice(h->device));
-    DIMX_TRY(ensure_packed(h));
+    DIMX_TRY(ensure_packed(h, which == 0 ? COMP_VQ0 : COMP_VQ1));
     return launch_vq_argmin(z, N, h->vq[which].Et, h->vq[which].ee, idx, best_d, margin, (hipStream_t)stream);
 }
 
 int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens, int B, int T, int pe_mode,
                    int batch_row_offset, int32_t pad_value, int32_t* idx, float* z_out, void* ws, size_t ws_bytes,
                    void* stream) {
-    DIMX_TRY(check_common(h, B, T, ws, ws_bytes));
-    DIMX_REQUIRE(x && idx && (which == 0 || which == 1), DIMX_ERR_ARG, "vq_encode: null argument");
+    DIMX_REQUIRE(which == 0 || which == 1, DIMX_ERR_ARG, "vq_encode: which must be 0 or 1");
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, which == 0 ? COMP_VQ0 : COMP_VQ1));
+    DIMX_REQUIRE(x && idx, DIMX_ERR_ARG, "vq_encode: null argument");
     DIMX_REQUIRE(pe_mode == 0 || B + batch_row_offset <= 5000, DIMX_ERR_ARG, "vq_encode: positional row out of range");
     hipStream_t st = (hipStream_t)stream;
     const VQNet& v = h->vq[which];
@@ -813,8 +848,9 @@ int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens
 
 int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset, float* out,
                    void* ws, size_t ws_bytes, void* stream) {
-    DIMX_TRY(check_common(h, B, L, ws, ws_bytes));
-    DIMX_REQUIRE(idx && out && (which == 0 || which == 1), DIMX_ERR_ARG, "vq_decode: null argument");
+    DIMX_REQUIRE(which == 0 || which == 1, DIMX_ERR_ARG, "vq_decode: which must be 0 or 1");
+    DIMX_TRY(check_common(h, B, L, ws, ws_bytes, which == 0 ? COMP_VQ0 : COMP_VQ1));
+    DIMX_REQUIRE(idx && out, DIMX_ERR_ARG, "vq_decode: null argument");
     DIMX_REQUIRE(B + batch_row_offset <= 5000 && batch_row_offset >= 0, DIMX_ERR_ARG,
                  "vq_decode: positional row %d out of range", B + batch_row_offset);
     hipStream_t st = (hipStream_t)stream;
@@ -842,7 +878,7 @@ int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, i
 
 int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio, const uint8_t* mask, int B, int T,
                     int for_generate, float* x_s_out, void* ws, size_t ws_bytes, void* stream) {
-    DIMX_TRY(check_common(h, B, T, ws, ws_bytes));
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_ENC | COMP_DEC));
     DIMX_REQUIRE(v_speaker && v_audio && mask, DIMX_ERR_ARG, "encode_ctx: null argument");
     hipStream_t st = (hipStream_t)stream;
     CtxPersist cp;
@@ -905,7 +941,7 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
 
 int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, const uint8_t* kv_mask, int B, int T,
                    float* logits, float* row_loss, int32_t* argmax_tok, void* ws, size_t ws_bytes, void* stream) {
-    DIMX_TRY(check_common(h, B, T, ws, ws_bytes));
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_DEC));
     DIMX_REQUIRE(z_l && ctx_mask && logits && T >= 2, DIMX_ERR_ARG, "decode_tf: null argument or T < 2");
     DIMX_REQUIRE(h->ctx_ready && h->ctx_B == B && h->ctx_T == T && h->ctx_ws == ws && !h->ctx_for_generate,
                  DIMX_ERR_STATE, "decode_tf: call dimx_encode_ctx(for_generate=0) with the same B, T, ws first");
@@ -1087,7 +1123,7 @@ extern "C" {
 int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T, float temperature,
                   int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens, float* logits_out, void* ws,
                   size_t ws_bytes, void* stream) {
-    DIMX_TRY(check_common(h, B, T, ws, ws_bytes));
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_DEC));
     DIMX_REQUIRE(start && ctx_mask && tokens && T >= 2, DIMX_ERR_ARG, "generate: null argument or T < 2");
     DIMX_REQUIRE(h->ctx_ready && h->ctx_B == B && h->ctx_T == T && h->ctx_ws == ws && h->ctx_for_generate,
                  DIMX_ERR_STATE, "generate: call dimx_encode_ctx(for_generate=1) with the same B, T, ws first");
@@ -1186,6 +1222,27 @@ int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, v
     a.kmask = kmask;
     a.kmask_ld = Lk;
     return launch_attention(a, (hipStream_t)stream);
+}
+
+int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void* vcache, void* out, int B, int H,
+                        int Tmax, int n_keys, float scale, const uint8_t* kmask, void* stream) {
+    DecodeAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = dtype;
+    a.q = q;
+    a.q_ld = H * 64;
+    a.kcache = const_cast<void*>(kcache);
+    a.vcache = const_cast<void*>(vcache);
+    a.Tmax = Tmax;
+    a.out = out;
+    a.o_ld = H * 64;
+    a.B = B;
+    a.H = H;
+    a.n_keys = n_keys;
+    a.kmask = kmask;
+    a.kmask_ld = n_keys;
+    a.scale = scale;
+    return launch_decode_attn(a, (hipStream_t)stream);
 }
 
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise, uint64_t seed,

@@ -100,7 +100,7 @@ struct dimx_ctx {
     int at = DIMX_F32;  // operand storage type of GEMM/attention inputs
     std::map<std::string, dimx::HostTensor> host;
     std::vector<std::string> required;
-    bool packed = false;
+    int packed_mask = 0;  // COMP_* bits of the components whose packed device copies are current
     std::vector<void*> dev_allocs;
     dimx::VQNet vq[2];  // 0 speaker, 1 listener
     dimx::XEnc enc_s, enc_joint;

@@ -1,0 +1,84 @@
+"""Multi-GPU plumbing: one process per GPU, batch sharded by contiguous rows, weights replicated, and ONE
+collective per evaluation batch -- an all-gather of the generated code indices (and optionally the decoded
+coefficients) so that any rank can run the host-side metrics.
+
+``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI inside a node); the same code runs on the
+"gloo" backend for the CPU tests.  Payloads are 150 KB - 2.5 MB per rank: latency-bound, so a single
+un-bucketed all_gather_into_tensor is the right shape (no ring tuning, no overlap machinery).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def rank():
+    return dist.get_rank() if is_initialized() else 0
+
+
+def world_size():
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return 0, 1, local
+    if not is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size(), local
+
+
+def shard_bounds(n, r, w):
+    """Contiguous shard [lo, hi) of n rows for rank r of w (first n % w ranks get one extra row)."""
+    base, extra = divmod(n, w)
+    lo = r * base + min(r, extra)
+    return lo, lo + base + (1 if r < extra else 0)
+
+
+def all_gather_rows(t):
+    """Concatenate every rank's rows along dim 0 (shards may differ in length by one row)."""
+    if world_size() == 1:
+        return t
+    t = t.contiguous()
+    w = world_size()
+    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    if len(set(counts)) == 1:
+        out = torch.empty((w * counts[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    out = torch.empty((w * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[i * mx:i * mx + c] for i, c in enumerate(counts)], 0)
+
+
+def max_over_ranks(x: float, device=None) -> float:
+    if world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,91 @@
+"""Live roofline measurement of the dominant kernels of the autoregressive decode loop, for bench.py.
+
+The two kernels that dominate the rocprofv3 kernel trace of the C3 workload (profiles/) are launched here
+exactly as dimx_generate launches them, on the current stream, bracketed by HIP events:
+
+  * decode attention (cross-attention form): pure HBM stream of the [B,12,T,64] K and V caches.
+    Algorithmic bytes per launch = B*12*T*64 * 2 (K,V) * elem_size (+ q and out, B*768*elem_size each);
+    bound = HBM (8 TB/s peak).  The four decoder layers' caches are visited round-robin so the working set
+    (4 x 236 MB at B=256,T=300, bf16) exceeds the 256 MB Infinity Cache like it does in the real loop.
+  * decode GEMM (the 1152 <- 4608 feed-forward down projection, M = B rows, f32 residual epilogue).
+    Algorithmic flops per launch = 2*B*1152*4608; bound = MFMA (2.5 PFLOP/s dense bf16, 157.3 TFLOP/s f32).
+
+`traffic` (HBM bytes per launch from the TCC PMC counters) is filled in from profiles/ when a PMC pass was
+collected for the same commit, else null.
+"""
+import torch
+
+from . import engine as E
+
+HBM_PEAK_GBS = 8000.0
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+
+
+def _time_launches(fn, n_warm, n_iter):
+    for i in range(n_warm):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n_iter):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n_iter
+
+
+def decode_attention(B, T, mode, device, iters=40):
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    es = 2 if mode == "bf16" else 4
+    H, Tp = 12, (T + 7) // 8 * 8
+    layers = 4
+    kc = [torch.randn(B, H, Tp, 64, device=device).to(dt) for _ in range(layers)]
+    vc = [torch.randn(B, H, Tp, 64, device=device).to(dt) for _ in range(layers)]
+    q = torch.randn(B, H * 64, device=device).to(dt)
+    sec = _time_launches(lambda i: E.op_decode_attn(q, kc[i % layers], vc[i % layers], T, 0.125), 8, iters)
+    alg_bytes = B * H * T * 64 * 2 * es + 2 * B * H * 64 * es
+    gbs = alg_bytes / sec / 1e9
+    return {"kernel": "decode_attn_kernel<%s> (cross-attention, %d keys)" % (mode, T), "bound": "hbm",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sec * 1e6}
+
+
+def decode_gemm(B, mode, device, iters=40):
+    M, N, K = B, 1152, 4608
+    a = torch.randn(M, K, device=device)
+    w = [torch.randn(N, K, device=device) / 68.0 for _ in range(4)]
+    bias = torch.randn(N, device=device)
+    res = torch.randn(M, N, device=device)
+    bf = mode == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    a_ = a.to(dt).contiguous()
+    w_ = [x.to(dt).contiguous() for x in w]
+    from . import lib as L
+    lib = L.load()
+    out = torch.empty(M, N, device=device)
+
+    def run(i):
+        L.check(lib.dimx_op_gemm(L.BF16 if bf else L.F32, L.F32, L.ptr(a_), K, L.ptr(w_[i % 4]), K, L.ptr(out), N, M,
+                                 N, K, L.ptr(bias), 0, L.ptr(res), N, 0, None, L.stream_ptr(device)), "gemm")
+    sec = _time_launches(run, 8, iters)
+    flops = 2.0 * M * N * K
+    tf = flops / sec / 1e12
+    peak = MFMA_PEAK_TFLOPS[mode]
+    return {"kernel": "gemm_kernel<%s,float> M=%d N=%d K=%d (decode FF down-projection)" % (mode, M, N, K),
+            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+            "algorithmic_flops_per_launch": flops, "avg_launch_us": sec * 1e6}
+
+
+def dominant_kernel(eng, B, T, mode):
+    """Roofline object for bench.py: the kernel with the largest share of the decode loop, with the other
+    candidate attached under 'secondary'."""
+    dev = eng.device
+    att = decode_attention(B, T, mode, dev)
+    gem = decode_gemm(B, mode, dev)
+    # per decode step: 8 attention launches vs 16 small-M GEMM launches of comparable size
+    att_share = 8 * att["avg_launch_us"]
+    gem_share = 16 * gem["avg_launch_us"]
+    first, second = (att, gem) if att_share >= gem_share else (gem, att)
+    first = dict(first)
+    first["secondary"] = second
+    return first

@@ -1,0 +1,157 @@
+"""Drop-in ``SLMFT`` (DIM-Listener): same constructor surface, parameter names, method names and
+``forward`` signature/return as the reference ``code/seq2seq_pretrain.py:325-514``, computing on the
+HIP library (``include/dimx.h``) through ``dimx.engine.Engine``.
+
+Differences that are deliberate and documented:
+  * the no-arg constructor still works, but since the reference's checkpoint files do not exist here the
+    VQ-VAEs start from deterministic synthetic weights; ``vq_speaker_ckpt`` / ``vq_listener_ckpt`` accept
+    the reference's ``model.pth.tar`` files (``{'state_dict': ...}``) when they do exist;
+  * randomness is injectable: ``noise`` (Exp(1) sampling noise, [T-1,B,512]), ``kv_mask`` (the
+    AutoregressiveWrapper key mask, [B,T-1] bool), ``greedy`` and ``seed``; the defaults draw fresh
+    randomness like the reference;
+  * ``forward_vq`` encodes each stream once, batched over ragged clips on the GPU (the reference encodes
+    batch-1 clips in a Python loop, twice, code/seq2seq_pretrain.py:497-500); results are identical.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import config as _config
+from . import lib as L
+from . import weights as W
+from .models import _EngineOwner, build_param_tree, get_model
+
+
+def compact_by_mask(x, mask):
+    """Left-align the valid frames of every clip (``v[i][mask[i]]`` of the reference, batched).
+    Returns (x_compact, lens int32).  A prefix mask (the engine protocol) is returned unchanged."""
+    lens = mask.sum(1).to(torch.int32)
+    T = mask.shape[1]
+    prefix = torch.arange(T, device=mask.device)[None, :] < lens[:, None]
+    if torch.equal(prefix, mask):
+        return x, lens
+    order = torch.argsort((~mask).to(torch.int8), dim=1, stable=True)
+    xc = torch.gather(x, 1, order[..., None].expand(-1, -1, x.shape[-1]))
+    return xc * prefix[..., None].to(x.dtype), lens
+
+
+class SLMFT(_EngineOwner):
+    def __init__(self, config_path=None, vq_speaker_ckpt=None, vq_listener_ckpt=None,
+                 synthetic_seed=20260928, numeric_mode=L.MODE_PARITY_F32):
+        super().__init__(numeric_mode)
+        config_path = config_path or ("./config.yaml" if os.path.isfile("./config.yaml") else _config.DEFAULT_CONFIG)
+        cfg_s = _config.load_cfg_from_cfg_file(config_path)
+        cfg_l = _config.load_cfg_from_cfg_file(config_path)
+        self.speaker_vq = get_model(cfg_s, synthetic_seed=synthetic_seed, weight_prefix="speaker_vq.", which=0,
+                                    numeric_mode=numeric_mode)
+        self.listener_vq = get_model(cfg_l, synthetic_seed=synthetic_seed, weight_prefix="listener_vq.", which=1,
+                                     numeric_mode=numeric_mode)
+        for m, ck in ((self.speaker_vq, vq_speaker_ckpt), (self.listener_vq, vq_listener_ckpt)):
+            if ck is not None:
+                m.load_state_dict(torch.load(ck, map_location="cpu")["state_dict"])
+            m.eval()
+        self.speaker_face_quan_num = cfg_s.face_quan_num
+        self.speaker_zquant_dim = cfg_s.zquant_dim
+        self.s2s = W.S2SDims()
+        spec = [e for e in W.slmft_spec(self.speaker_vq.dims, self.s2s)
+                if not (e[0].startswith("speaker_vq.") or e[0].startswith("listener_vq."))]
+        build_param_tree(self, spec, W.synth_state_dict(spec, synthetic_seed))
+        self.mask_prob = self.s2s.mask_prob
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine_state_dict(self):
+        return self.state_dict()
+
+    def _mask8(self, mask):
+        return mask.to(torch.uint8).contiguous()
+
+    # ------------------------------------------------------------------ reference sub-APIs
+    @torch.no_grad()
+    def forward_vq(self, v_speaker, v_listener, mask, with_speaker=True):
+        """reference :480-494 -> (z_speaker [B,T] padded with 0, z_listener [B,T] padded with -100), int64."""
+        eng = self.engine(v_speaker.device)
+        xl, lens = compact_by_mask(v_listener, mask)
+        z_l = eng.vq_encode(1, xl, lens, pe_mode=0, pad_value=-100).long()
+        z_s = None
+        if with_speaker:
+            xs, _ = compact_by_mask(v_speaker, mask)
+            z_s = eng.vq_encode(0, xs, lens, pe_mode=0, pad_value=0).long()
+        return z_s, z_l
+
+    @torch.no_grad()
+    def forward_encoder(self, v_speaker, mask):
+        """reference :431-442 -> x_s [B,T,384] (rows of padded frames are unspecified)."""
+        eng = self.engine(v_speaker.device)
+        zeros = torch.zeros(v_speaker.shape[0], v_speaker.shape[1], self.s2s.dim_a, device=v_speaker.device)
+        return eng.encode_ctx(v_speaker, zeros, self._mask8(mask), False, return_x_s=True)
+
+    @torch.no_grad()
+    def forward_decoder(self, x_s, z_l, x_a, mask, mode, v_speaker=None, noise=None, kv_mask=None, greedy=False,
+                        seed=None, temperature=1.0):
+        """reference :444-452.  The encoder output lives inside the engine workspace, so this needs the
+        speaker motion (``v_speaker``) rather than ``x_s`` to (re)build the context."""
+        assert v_speaker is not None, "dimx keeps x_s on the device: pass v_speaker= to forward_decoder"
+        eng = self.engine(v_speaker.device)
+        m8 = self._mask8(mask)
+        B, T = z_l.shape
+        if mode == "train":
+            eng.encode_ctx(v_speaker, x_a, m8, False)
+            if kv_mask is None:
+                kv_mask = self.draw_kv_mask(B, T, v_speaker.device)
+            elif kv_mask is False:
+                kv_mask = None
+            logits, row_loss, _ = eng.decode_tf(z_l, m8, self._mask8(kv_mask) if kv_mask is not None else None)
+            n_valid = (z_l[:, 1:] != -100).sum().clamp(min=1)
+            return row_loss.sum() / n_valid, logits
+        eng.encode_ctx(v_speaker, x_a, m8, True)
+        if greedy:
+            temperature, seed_v = 0.0, 0
+        else:
+            seed_v = 0 if noise is not None else (seed if seed is not None else
+                                                  int(torch.randint(1, 2 ** 62, (1,)).item()))
+        tokens = eng.generate(z_l[:, 0], m8, T, temperature, 52, noise, seed_v)
+        return 0.0, tokens.long()
+
+    def draw_kv_mask(self, B, T, device, generator=None):
+        """AutoregressiveWrapper(mask_prob=0.15) key mask (reference ctor :419): keep-mask [B,T-1]."""
+        n = T - 1
+        rand = torch.randn(B, n, device=device, generator=generator)
+        rand[:, 0] = -torch.finfo(rand.dtype).max
+        num_mask = min(int(T * self.mask_prob), T - 1)
+        idx = rand.topk(num_mask, dim=-1).indices
+        return ~torch.zeros(B, n, device=device).scatter(1, idx, 1.0).bool()
+
+    @torch.no_grad()
+    def forward_vq_decoder(self, logits_l, mode="train", batch_row_offset=0):
+        """reference :454-464: argmax (train) / tokens (val) -> codebook lookup -> listener_vq.decode."""
+        pred_seq_l = torch.argmax(logits_l, dim=-1) if mode == "train" else logits_l
+        return self.engine(pred_seq_l.device).vq_decode(1, pred_seq_l, batch_row_offset)
+
+    def forward_continuous_loss(self, pred, target, mask):
+        """reference :466-478."""
+        target = target[:, 1:, :]
+        m = mask[:, 1:].reshape(-1)
+        p = pred.reshape(-1, pred.shape[-1])[m]
+        t = target.reshape(-1, target.shape[-1])[m]
+        return torch.mean(F.pairwise_distance(p[:, 6:], t[:, 6:])) + torch.mean(F.pairwise_distance(p[:, 0:6], t[:, 0:6]))
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, v_speaker, v_listener, v_audio, mask, mode="train", speaker_ids=None, listener_ids=None,
+                noise=None, kv_mask=None, greedy=False, seed=None, temperature=1.0, batch_row_offset=0,
+                return_tokens=False):
+        """reference :496-514 -> (total_loss, dict, pred_cont_seq_l [B,T-1,56])."""
+        mask = mask.bool()
+        _, z_l = self.forward_vq(v_speaker, v_listener, mask, with_speaker=False)
+        l_ce_l, px_l = self.forward_decoder(None, z_l, v_audio, mask, mode, v_speaker=v_speaker, noise=noise,
+                                            kv_mask=kv_mask, greedy=greedy, seed=seed, temperature=temperature)
+        pred = self.forward_vq_decoder(px_l, mode=mode, batch_row_offset=batch_row_offset)
+        l_cont_l = self.forward_continuous_loss(pred, v_listener, mask)
+        total_loss = l_ce_l + l_cont_l
+        d = {"l_ce_s": 0, "l_ce_l": l_ce_l, "l_cont_s": 0, "l_cont_l": l_cont_l, "nce": 0, "c_acc": 0}
+        if return_tokens:
+            tokens = px_l if mode != "train" else torch.argmax(px_l, dim=-1)
+            return total_loss, d, pred, tokens
+        return total_loss, d, pred

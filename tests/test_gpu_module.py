@@ -1,0 +1,113 @@
+"""GPU: the drop-in nn.Module surface (SLMFT / VQAutoEncoder / evaluation engine) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _clips(B, T, lens, seed=5):
+    from dimx import prng
+    v_s = torch.from_numpy(prng.normal(seed, "m.vs", (B, T, 56)))
+    v_l = torch.from_numpy(prng.normal(seed, "m.vl", (B, T, 56)))
+    v_a = torch.from_numpy(prng.normal(seed, "m.va", (B, T, 768)))
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    for j, n in enumerate(lens):
+        mask[j, :n] = True
+    return v_s, v_l, v_a, mask
+
+
+@pytest.fixture(scope="module")
+def model():
+    from dimx.seq2seq_pretrain import SLMFT
+    return SLMFT().eval()
+
+
+def test_slmft_forward_train_and_val_match_oracle(model, full_sd):
+    from dimx import prng
+    from oracle import ref_cpu
+    B, T, lens = 3, 48, [48, 40, 9]
+    v_s, v_l, v_a, mask = _clips(B, T, lens)
+    dev = torch.device("cuda:0")
+    kv = ref_cpu.ar_kv_mask(B, T, 0.15, torch.Generator().manual_seed(2))
+    tot, d, pred = model(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mode="train", kv_mask=kv.to(dev))
+    rt, rd, rpred = ref_cpu.slmft_forward(full_sd, v_s, v_l, v_a, mask, "train", kv_mask=kv)
+    assert pred.shape == (B, T - 1, 56)
+    for b, n in enumerate(lens):
+        assert (pred[b, :n - 1].cpu() - rpred[b, :n - 1]).abs().max() < 1e-4
+    assert abs(float(tot) - float(rt)) < 1e-3 and abs(float(d["l_ce_l"]) - float(rd["l_ce_l"])) < 1e-3
+    noise = torch.from_numpy(prng.exponential(8, "m.noise", (T - 1, B, 512)))
+    tot, d, pred, tok = model(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mode="val", noise=noise.to(dev),
+                              return_tokens=True)
+    rt, rd, rpred, aux = ref_cpu.slmft_forward(full_sd, v_s, v_l, v_a, mask, "val", noise=noise, return_aux=True)
+    assert torch.equal(tok.cpu(), aux["tokens"])
+    assert (pred.cpu() - rpred).abs().max() < 1e-4
+    assert d["l_ce_l"] == 0.0 and abs(float(tot) - float(rt)) < 1e-3
+    # default call draws fresh randomness (like the reference): two calls differ, greedy calls agree
+    a = model(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mode="val", return_tokens=True)[3]
+    b = model(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mode="val", return_tokens=True)[3]
+    g1 = model(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mode="val", greedy=True, return_tokens=True)[3]
+    g2 = model(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mode="val", greedy=True, return_tokens=True)[3]
+    assert not torch.equal(a, b) and torch.equal(g1, g2)
+
+
+def test_non_prefix_mask_is_compacted_like_the_reference(model, full_sd):
+    from oracle import ref_cpu
+    v_s, v_l, v_a, _ = _clips(2, 20, [20, 20])
+    mask = torch.ones(2, 20, dtype=torch.bool)
+    mask[1, 3] = False
+    mask[1, 11:14] = False
+    _, zl = model.forward_vq(v_s.cuda(), v_l.cuda(), mask.cuda(), with_speaker=False)
+    _, ref = ref_cpu.forward_vq(full_sd, v_s, v_l, mask, with_speaker=False)
+    assert torch.equal(zl.cpu(), ref)
+
+
+def test_vq_autoencoder_module_roundtrip(golden_dir):
+    import os
+    from dimx import config
+    from dimx.models import get_model
+    g = np.load(os.path.join(golden_dir, "vq_roundtrip_C1.npz"))
+    m = get_model(config.load_cfg_from_cfg_file(config.DEFAULT_CONFIG)).eval()
+    x = torch.from_numpy(g["x"]).cuda()
+    dec, loss, info = m(x)
+    assert np.array_equal(info[2].view(-1).cpu().numpy(), g["idx"].astype(np.int64))
+    assert np.abs(dec.cpu().numpy() - g["xhat"]).max() < 1e-4
+    assert info[1].shape == (300, 512) and float(info[1].sum()) == 300.0
+    quant, idx = m.get_quant(x)
+    assert quant.shape == (1, 128, 300)
+    assert np.abs(m.decode_to_img(idx, (1, 300, 128)).cpu().numpy() - g["xhat"]).max() < 1e-4
+
+
+def test_evaluation_engine_protocol(model):
+    from dimx import x_engine_pt
+    B, T = 3, 32
+    lens = [32, 20, 11]
+    v_s, v_l, v_a, mask = _clips(B, T, lens)
+    src = torch.cat([v_s, v_a], -1) * mask[..., None]
+    loader = [(src, v_l * mask[..., None], lens, None, ["a", "b", "c"])]
+    yt, yp, xs, ids = x_engine_pt.evaluate_finetune_epoch(model, loader, torch.device("cuda:0"))
+    assert ids == ["a", "b", "c"] and [a.shape for a in yp] == [(n - 1, 56) for n in lens]
+    assert all(a.shape == b.shape for a, b in zip(yt, yp)) and xs[1].shape == (19, 56)
+    yt2, yp2, xs2, ids2 = x_engine_pt.evaluate_test_epoch(model, loader, torch.device("cuda:0"), beam_size=3)
+    assert [a.shape for a in yp2] == [(n - 1, 56) for n in lens] and np.isfinite(yp2[0]).all()
+    tok, pred = x_engine_pt.generate_sharded(model, v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda(), greedy=True)
+    assert tok.shape == (B, T - 1) and pred.shape == (B, T - 1, 56)
+
+
+def test_decode_attention_kernel(model):
+    from dimx import engine
+    g = torch.Generator().manual_seed(0)
+    B, H, T = 5, 12, 77
+    q = torch.randn(B, H * 64, generator=g)
+    k = torch.randn(B, H, 80, 64, generator=g)
+    v = torch.randn(B, H, 80, 64, generator=g)
+    km = (torch.rand(B, T, generator=g) > 0.3).to(torch.uint8)
+    km[:, 0] = 1
+    s = torch.einsum("bhd,bhjd->bhj", q.view(B, H, 64).double(), k[:, :, :T].double()) * 0.125
+    s = s.masked_fill(km[:, None, :] == 0, -1e300)
+    ref = torch.einsum("bhj,bhjd->bhd", s.softmax(-1), v[:, :, :T].double()).reshape(B, H * 64)
+    out = engine.op_decode_attn(q.cuda(), k.cuda(), v.cuda(), T, 0.125, km.cuda())
+    assert (out.cpu().double() - ref).abs().max() < 2e-5
+    outb = engine.op_decode_attn(q.cuda().bfloat16(), k.cuda().bfloat16(), v.cuda().bfloat16(), T, 0.125, km.cuda())
+    assert (outb.float().cpu().double() - ref).abs().max() < 5e-2
