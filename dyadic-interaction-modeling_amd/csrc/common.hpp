@@ -148,6 +148,10 @@ struct GemmArgs {
     // segment s goes to seg[s].ptr + b*sb + t*st + (nn / D)*sh + (nn % D)*sd, nn = n - s*seg_width
     OutSeg seg[3];
     int nseg, seg_width;
+    // scheduling knobs
+    int allow_splitk;  // perf mode: split K with f32 atomics when the grid is small (in-place residual only)
+    int splitk;        // set by the launcher
+    int force_simple;  // tests: force the register-staged kernel
 };
 
 void gemm_args_init(GemmArgs& a);

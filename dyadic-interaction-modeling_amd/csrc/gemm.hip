@@ -27,6 +27,7 @@ void gemm_args_init(GemmArgs& a) {
     a.rowadd_scale = 1.f;
     a.nseg = 1;
     a.rowT = 1;
+    a.splitk = 1;
 }
 
 void gemm_set_plain_out(GemmArgs& a, void* C, int ldc) {
@@ -232,6 +233,237 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined variant (K % BK == 0, no gather): tiles go global -> LDS by LDS-DMA (global_load_lds,
+// 16 B per lane, 1 KiB per wave instruction) into a STAGES-deep ring, STAGES-1 tiles in flight.  The
+// wave-uniform destination is linear, so the XOR swizzle is applied on the per-lane SOURCE address.
+// Fragment reads are inline-asm ds_read_b128 (the compiler would otherwise drain vmcnt(0) before every
+// LDS read while a DMA is pending); tile arrival is ordered by a counted s_waitcnt vmcnt + one raw
+// s_barrier per k-tile.  Optional split-K: partial sums are added with global_atomic_add_f32 onto the
+// f32 residual stream in place (bf16 perf mode only; the parity mode keeps a fixed summation order).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int OFF> __device__ __forceinline__ void ds_read128(u32x4_t& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <typename T, int MI, int NI> struct FragMma;
+template <int MI, int NI> struct FragMma<bf16, MI, NI> {
+    static __device__ __forceinline__ void run(f32x16_t (&acc)[MI][NI], const u32x4_t (&fa)[MI], const u32x4_t (&fw)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
+                                                                   __builtin_bit_cast(bf16x8_t, fw[j]), acc[i][j], 0, 0, 0);
+    }
+};
+template <int MI, int NI> struct FragMma<float, MI, NI> {
+    static __device__ __forceinline__ void run(f32x16_t (&acc)[MI][NI], const u32x4_t (&fa)[MI], const u32x4_t (&fw)[NI]) {
+        // NB: cast the whole 128-bit fragment first, then index (per-element bit_cast of an asm output
+        // vector miscompiles to element 0 on hipcc 7.2)
+        f32x4_t a4[MI], w4[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a4[i] = __builtin_bit_cast(f32x4_t, fa[i]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) w4[j] = __builtin_bit_cast(f32x4_t, fw[j]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][0], w4[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][1], w4[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][2], w4[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][3], w4[j][3], acc[i][j], 0, 0, 0);
+            }
+    }
+};
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int BK = 8 * EPC;
+    constexpr int LA = BM / 8 / NW, LW = BN / 8 / NW;  // wave-wide DMA instructions per tile per wave
+    constexpr int LPT = LA + LW;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
+    static_assert((STAGES - 1) * LPT < 64, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    const int split = blockIdx.x / ntiles, tile = blockIdx.x - split * ntiles;
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const T* __restrict__ A = (const T*)a.A;
+    const T* __restrict__ W = (const T*)a.W;
+
+    // k-tiles of this split
+    const int nk_all = a.ldw / BK;
+    const int per = (nk_all + a.splitk - 1) / a.splitk;
+    const int kt0 = split * per;
+    int nk = nk_all - kt0;
+    nk = nk > per ? per : nk;
+    if (nk <= 0) return;
+
+    // DMA piece j of this wave covers tile rows (wave*L + j)*8 .. +7; lane l -> row + (l>>3), slot l&7
+    const T* gA[LA];
+    const T* gW[LW];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int row = (wave * LA + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
+        gA[j] = A + (size_t)m * a.lda + c * EPC + (size_t)kt0 * BK;
+    }
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        const int row = (wave * LW + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int n = n0 + row;
+        n = n < a.N ? n : a.N - 1;
+        gW[j] = W + (size_t)n * a.ldw + c * EPC + (size_t)kt0 * BK;
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < LA; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gA[j] + (size_t)kt * BK),
+                                             (lds_void_t*)(base + (wave * LA + j) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < LW; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gW[j] + (size_t)kt * BK),
+                                             (lds_void_t*)(base + BM * 128 + (wave * LW + j) * 1024), 16, 0, 0);
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+    unsigned aoff[4], woff[4];
+    {
+        const int ra = wm * MI * 32 + l31, rw = wn * NI * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            aoff[ks] = lds0 + lds_off(ra, 2 * ks + half);
+            woff[ks] = lds0 + BM * 128 + lds_off(rw, 2 * ks + half);
+        }
+    }
+
+    f32x16_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    for (int it = 0; it < nk; ++it) {
+        // tile `it` has landed once at most min(STAGES-2, nk-1-it) younger tiles are still in flight
+        if (nk - 1 - it >= STAGES - 2)
+            wait_vmcnt<(STAGES - 2) * LPT>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4_t fa[MI], fw[NI];
+            const unsigned pa = aoff[ks] + boff, pw = woff[ks] + boff;
+            ds_read128<0>(fa[0], pa);
+            if (MI > 1) ds_read128<4096>(fa[MI > 1 ? 1 : 0], pa);
+            ds_read128<0>(fw[0], pw);
+            if (NI > 1) ds_read128<4096>(fw[NI > 1 ? 1 : 0], pw);
+            wait_lgkm0();
+            __builtin_amdgcn_sched_barrier(0);
+            FragMma<T, MI, NI>::run(acc, fa, fw);
+        }
+    }
+
+    // ---- epilogue (same math as gemm_kernel; split-K partials are atomically added in place)
+    const int rowT = a.rowT;
+    const bool first = split == 0;
+    const bool atomic = a.splitk > 1;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * NI * 32 + j * 32 + l31;
+        if (n >= a.N) continue;
+        const float bias_v = (a.bias && first) ? a.bias[n] : 0.f;
+        int s = 0, nn = n;
+        if (a.nseg > 1) {
+            s = n / a.seg_width;
+            nn = n - s * a.seg_width;
+        }
+        const OutSeg sg = a.seg[s];
+        const int hh = nn / sg.D, dd = nn - hh * sg.D;
+        OutT* obase = (OutT*)sg.ptr + (long)hh * sg.sh + (long)dd * sg.sd;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mb = m0 + wm * MI * 32 + i * 32 + 4 * half;
+            int b0, t0;
+            if (rowT == 1) {
+                b0 = mb;
+                t0 = 0;
+            } else {
+                b0 = mb / rowT;
+                t0 = mb - b0 * rowT;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                const int m = mb + off;
+                if (m >= a.M) continue;
+                int b = b0, t = t0;
+                if (rowT == 1) {
+                    b = m;
+                } else {
+                    t += off;
+                    while (t >= rowT) {
+                        t -= rowT;
+                        ++b;
+                    }
+                }
+                OutT* dst = obase + (long)b * sg.sb + (long)t * sg.st;
+                if (atomic) {  // f32 only (checked by the launcher): in-place accumulation onto the residual
+                    float v = acc[i][j][r] + bias_v;
+                    unsafeAtomicAdd((float*)dst, v);
+                } else {
+                    float v = apply_act(acc[i][j][r] + bias_v, a.act);
+                    if (a.rowadd_mode) {
+                        const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b + a.rowadd_off : a.rowadd_off);
+                        v += a.rowadd[(size_t)ri * a.ld_rowadd + n] * a.rowadd_scale;
+                    }
+                    if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
+                    store_from_f32<OutT>(dst, v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES>
+static int launch_glds(const GemmArgs& a, hipStream_t s) {
+    const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
+    dim3 grid(tiles * a.splitk), block(WM * WN * 64);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES>), grid, block, 0, s, a);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
 template <typename T, typename OutT, int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
@@ -244,11 +476,33 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return DIMX_OK;
 }
 
-template <typename T, typename OutT> static int launch_typed(const GemmArgs& a, hipStream_t s) {
-    // large-M (prefill / teacher-forced / VQ stacks): 128x128 tiles; small M (decode steps): 64x64.
+template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.splitk = 1;
+    const int bk = 8 * Elem<T>::kPerChunk;
     const long tiles128 = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
-    if (tiles128 >= 256) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
-    return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
+    const bool pipelined = a.conv_T == 0 && a.K % bk == 0 && a.K == a.ldw && !a.force_simple;
+    if (!pipelined) {
+        // gather / ragged-K path: register-staged kernel
+        if (tiles128 >= 256) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
+        return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
+    }
+    if (tiles128 >= 256) return launch_glds<T, OutT, 128, 128, 2, 2, 3>(a, s);
+    // small-M (decode step) regime: 64x64 tiles, 4-deep ring; split K when the grid cannot fill the chip and
+    // the output is the f32 residual stream updated in place
+    const int tiles64 = ceil_div(a.M, 64) * ceil_div(a.N, 64);
+    const int nk = a.ldw / bk;
+    const bool inplace = a.residual && a.nseg == 1 && a.seg[0].ptr == (void*)a.residual && a.seg[0].sd == 1 &&
+                         a.seg[0].sh == 0 && a.seg[0].st == a.ldr && a.rowT == 1;
+    if (a.allow_splitk && inplace && a.act == ACT_NONE && a.rowadd_mode == 0 && sizeof(OutT) == 4 && tiles64 < 256) {
+        int sp = (512 + tiles64 - 1) / tiles64;
+        const int max_sp = nk / 4 > 0 ? nk / 4 : 1;
+        sp = sp > max_sp ? max_sp : sp;
+        sp = sp > 8 ? 8 : sp;
+        a.splitk = sp < 1 ? 1 : sp;
+        if (a.splitk > 1) a.residual = nullptr;  // the residual already sits in the output
+    }
+    return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {

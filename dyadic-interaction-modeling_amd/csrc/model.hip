@@ -367,6 +367,7 @@ static int gemm_lin(const dimx_ctx* c, const void* A, int lda, const Linear& L, 
     g.N = L.N;
     g.K = L.K;
     g.bias = L.bias;
+    g.allow_splitk = c->at == DIMX_BF16 ? 1 : 0;  // parity mode keeps a fixed summation order
     return DIMX_OK;
 }
 
@@ -1170,7 +1171,7 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
 // ---------------------------------------------------------------- kernel-level entry points
 int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M,
                  int N, int K, const float* bias, int act, const float* residual, int ldr, int conv_T,
-                 const int32_t* conv_lens, void* stream) {
+                 const int32_t* conv_lens, int flags, void* stream) {
     GemmArgs g;
     gemm_args_init(g);
     g.in_dtype = in_dtype;
@@ -1186,6 +1187,8 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     g.act = act;
     g.residual = residual;
     g.ldr = ldr;
+    g.allow_splitk = flags & 1;
+    g.force_simple = (flags >> 1) & 1;
     if (conv_T > 0) {
         g.conv_T = conv_T;
         g.conv_lens = conv_lens;

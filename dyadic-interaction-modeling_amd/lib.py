@@ -58,7 +58,7 @@ SIGNATURES = {
     "dimx_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_uint64,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
-                             c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+                             c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "dimx_op_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dimx_op_instnorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dimx_op_attention": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

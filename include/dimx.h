@@ -136,10 +136,12 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
  * W must be K-padded to a multiple of 64 (bf16) / 32 (f32) elements with zeros (ldw = padded K).
  * act: 0 none, 1 LeakyReLU(0.2), 2 GELU-tanh, 3 GELU-erf.  bias [N] f32 / residual [M,ldr] f32
  * optional.  conv_T > 0: A is [B*conv_T, C] and the GEMM is a k=5 replicate-padded temporal
- * convolution with K = 5*C, W tap-major [N][5][C]; conv_lens optional [B] int32. */
+ * convolution with K = 5*C, W tap-major [N][5][C]; conv_lens optional [B] int32.
+ * flags: bit 0 = allow split-K with f32 atomics (only taken when residual == C, i.e. in-place accumulation
+ * onto the residual stream, small M); bit 1 = force the register-staged (non LDS-DMA) kernel. */
 int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void* W, int ldw, void* C,
                  int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
-                 int ldr, int conv_T, const int32_t* conv_lens, void* stream);
+                 int ldr, int conv_T, const int32_t* conv_lens, int flags, void* stream);
 /* y = LayerNorm(x) over the last dim (C in {384,1152}), eps 1e-5; beta optional. */
 int dimx_op_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta,
                       int M, int C, void* stream);

@@ -71,7 +71,7 @@ def test_vq_autoencoder_module_roundtrip(golden_dir):
     m = get_model(config.load_cfg_from_cfg_file(config.DEFAULT_CONFIG)).eval()
     x = torch.from_numpy(g["x"]).cuda()
     dec, loss, info = m(x)
-    assert np.array_equal(info[2].view(-1).cpu().numpy(), g["idx"].astype(np.int64))
+    assert np.array_equal(info[2].view(-1).cpu().numpy(), g["idx"].astype(np.int64).reshape(-1))
     assert np.abs(dec.cpu().numpy() - g["xhat"]).max() < 1e-4
     assert info[1].shape == (300, 512) and float(info[1].sum()) == 300.0
     quant, idx = m.get_quant(x)
