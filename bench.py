@@ -81,7 +81,7 @@ def cpu_baseline(T, timeout_s=240):
     """Run the CPU oracle on a bounded sample in a subprocess (hard timeout: the bench never hangs on it)."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(T), "4"],
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(T), "32"],
                            capture_output=True, text=True, timeout=timeout_s)
         for line in r.stdout.splitlines():
             if line.startswith("CPU_BASELINE "):
@@ -90,7 +90,7 @@ def cpu_baseline(T, timeout_s=240):
                 "sample": "cpu worker failed: " + (r.stderr or "")[-200:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "clips/s", "cores": 0, "kind": "port",
-                "sample": "cpu worker exceeded %d s on 4 clips x T=%d" % (timeout_s, T)}
+                "sample": "cpu worker exceeded %d s on 32 clips x T=%d" % (timeout_s, T)}
 
 
 def main():

@@ -152,6 +152,8 @@ struct GemmArgs {
     int allow_splitk;  // perf mode: split K with f32 atomics when the grid is small (in-place residual only)
     int splitk;        // set by the launcher
     int force_simple;  // tests: force the register-staged kernel
+    int cfg;           // tile/stage configuration id of the LDS-DMA kernel (0 = automatic)
+    int force_splitk;  // tuning: requested split count (0 = automatic)
 };
 
 void gemm_args_init(GemmArgs& a);

@@ -251,7 +251,7 @@ template <int OFF> __device__ __forceinline__ void ds_read128(u32x4_t& v, unsign
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
 
 template <typename T, int MI, int NI> struct FragMma;
 template <int MI, int NI> struct FragMma<bf16, MI, NI> {
@@ -301,7 +301,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
-    const int split = blockIdx.x / ntiles, tile = blockIdx.x - split * ntiles;
+    // XCD-aware order: consecutive block ids land on different XCDs (8 private L2s), so give every XCD a
+    // contiguous run of tiles -- tiles that share an A row panel then hit the same L2 (speed only).
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int split = bid / ntiles, tile = bid - split * ntiles;
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const T* __restrict__ A = (const T*)a.A;
@@ -380,17 +387,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
         __builtin_amdgcn_s_barrier();
         if (it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
         const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
+        // all fragment reads of a group of k-steps are issued back to back; the MFMAs of k-step s start as
+        // soon as the reads of steps <= s have returned (LDS returns in order: counted lgkmcnt)
+        constexpr int RPK = MI + NI;                      // ds_read_b128 per k-step
+        constexpr int GROUP = (4 * RPK <= 12) ? 4 : 2;    // k-steps per group (lgkmcnt is a 4-bit counter)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            u32x4_t fa[MI], fw[NI];
-            const unsigned pa = aoff[ks] + boff, pw = woff[ks] + boff;
-            ds_read128<0>(fa[0], pa);
-            if (MI > 1) ds_read128<4096>(fa[MI > 1 ? 1 : 0], pa);
-            ds_read128<0>(fw[0], pw);
-            if (NI > 1) ds_read128<4096>(fw[NI > 1 ? 1 : 0], pw);
-            wait_lgkm0();
-            __builtin_amdgcn_sched_barrier(0);
-            FragMma<T, MI, NI>::run(acc, fa, fw);
+        for (int g0 = 0; g0 < 4; g0 += GROUP) {
+            u32x4_t fa[GROUP][MI], fw[GROUP][NI];
+#pragma unroll
+            for (int q = 0; q < GROUP; ++q) {
+                const unsigned pa = aoff[g0 + q] + boff, pw = woff[g0 + q] + boff;
+                ds_read128<0>(fa[q][0], pa);
+                if (MI > 1) ds_read128<4096>(fa[q][MI > 1 ? 1 : 0], pa);
+                ds_read128<0>(fw[q][0], pw);
+                if (NI > 1) ds_read128<4096>(fw[q][NI > 1 ? 1 : 0], pw);
+            }
+#pragma unroll
+            for (int q = 0; q < GROUP; ++q) {
+                if (q == 0) wait_lgkm<(GROUP - 1) * RPK>();
+                if (q == 1) wait_lgkm<(GROUP - 2) * RPK>();
+                if (q == 2) wait_lgkm<(GROUP > 2 ? GROUP - 3 : 0) * RPK>();
+                if (q == 3) wait_lgkm<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                FragMma<T, MI, NI>::run(acc, fa[q], fw[q]);
+            }
         }
     }
 
@@ -476,6 +496,38 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return DIMX_OK;
 }
 
+// cfg ids (GemmArgs.cfg, 0 = automatic): tile / waves / ring depth of the LDS-DMA kernel
+//  1: 128x128 2 stages   2: 128x128 3 stages   3: 64x64 4 stages   4: 64x64 3 stages   5: 64x64 2 stages
+//  6: 128x64 3 stages    7: 128x64 2 stages    8: 64x128 3 stages
+template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case 1: return launch_glds<T, OutT, 128, 128, 2, 2, 2>(a, s);
+        case 2: return launch_glds<T, OutT, 128, 128, 2, 2, 3>(a, s);
+        case 3: return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
+        case 4: return launch_glds<T, OutT, 64, 64, 2, 2, 3>(a, s);
+        case 5: return launch_glds<T, OutT, 64, 64, 2, 2, 2>(a, s);
+        case 6: return launch_glds<T, OutT, 128, 64, 2, 2, 3>(a, s);
+        case 7: return launch_glds<T, OutT, 128, 64, 2, 2, 2>(a, s);
+        case 8: return launch_glds<T, OutT, 64, 128, 2, 2, 3>(a, s);
+        case 9: return launch_glds<T, OutT, 64, 64, 2, 2, 8>(a, s);
+        case 10: return launch_glds<T, OutT, 64, 64, 2, 2, 6>(a, s);
+        case 11: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
+        case 12: return launch_glds<T, OutT, 128, 64, 2, 2, 4>(a, s);
+        default: break;
+    }
+    set_error("gemm: unknown cfg %d", cfg);
+    return DIMX_ERR_ARG;
+}
+
+static inline void cfg_tile(int cfg, int& bm, int& bn) {
+    switch (cfg) {
+        case 1: case 2: case 11: bm = 128; bn = 128; break;
+        case 6: case 7: case 12: bm = 128; bn = 64; break;
+        case 8: bm = 64; bn = 128; break;
+        default: bm = 64; bn = 64; break;
+    }
+}
+
 template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     a.splitk = 1;
@@ -487,22 +539,24 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
         if (tiles128 >= 256) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
         return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
     }
-    if (tiles128 >= 256) return launch_glds<T, OutT, 128, 128, 2, 2, 3>(a, s);
-    // small-M (decode step) regime: 64x64 tiles, 4-deep ring; split K when the grid cannot fill the chip and
-    // the output is the f32 residual stream updated in place
-    const int tiles64 = ceil_div(a.M, 64) * ceil_div(a.N, 64);
+    int cfg = a.cfg;
+    if (cfg == 0) cfg = tiles128 >= 512 ? 7 : 4;  // measured on MI355X (tools/bench_gemm.py): 128x64x2 for large M, 64x64x3 for decode
+    int bm, bn;
+    cfg_tile(cfg, bm, bn);
+    // small grids (decode step): split K when the output is the f32 residual stream updated in place
+    const int tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
     const int nk = a.ldw / bk;
     const bool inplace = a.residual && a.nseg == 1 && a.seg[0].ptr == (void*)a.residual && a.seg[0].sd == 1 &&
                          a.seg[0].sh == 0 && a.seg[0].st == a.ldr && a.rowT == 1;
-    if (a.allow_splitk && inplace && a.act == ACT_NONE && a.rowadd_mode == 0 && sizeof(OutT) == 4 && tiles64 < 256) {
-        int sp = (512 + tiles64 - 1) / tiles64;
+    if (a.allow_splitk && inplace && a.act == ACT_NONE && a.rowadd_mode == 0 && sizeof(OutT) == 4 && tiles < 256) {
+        int sp = a.force_splitk > 0 ? a.force_splitk : (512 + tiles - 1) / tiles;
         const int max_sp = nk / 4 > 0 ? nk / 4 : 1;
         sp = sp > max_sp ? max_sp : sp;
-        sp = sp > 8 ? 8 : sp;
+        sp = sp > 16 ? 16 : sp;
         a.splitk = sp < 1 ? 1 : sp;
         if (a.splitk > 1) a.residual = nullptr;  // the residual already sits in the output
     }
-    return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
+    return launch_by_cfg<T, OutT>(a, cfg, s);
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {

@@ -1189,6 +1189,8 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     g.ldr = ldr;
     g.allow_splitk = flags & 1;
     g.force_simple = (flags >> 1) & 1;
+    g.cfg = (flags >> 8) & 0xff;           /* tuning: tile/stage config id */
+    g.force_splitk = (flags >> 16) & 0xff; /* tuning: split count */
     if (conv_T > 0) {
         g.conv_T = conv_T;
         g.conv_lens = conv_lens;

@@ -45,7 +45,7 @@ def decode_attention(B, T, mode, device, iters=40):
     sec = _time_launches(lambda i: E.op_decode_attn(q, kc[i % layers], vc[i % layers], T, 0.125), 8, iters)
     alg_bytes = B * H * T * 64 * 2 * es + 2 * B * H * 64 * es
     gbs = alg_bytes / sec / 1e9
-    return {"kernel": "decode_attn_kernel<%s> (cross-attention, %d keys)" % (mode, T), "bound": "hbm",
+    return {"kernel": "decode_attn_kernel<%s, false> (cross-attention form, %d keys)" % ("dimx::bf16" if mode == "bf16" else "float", T), "bound": "hbm",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sec * 1e6}
 
