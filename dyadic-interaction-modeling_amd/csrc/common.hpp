@@ -154,6 +154,7 @@ struct GemmArgs {
     int force_simple;  // tests: force the register-staged kernel
     int cfg;           // tile/stage configuration id of the LDS-DMA kernel (0 = automatic)
     int force_splitk;  // tuning: requested split count (0 = automatic)
+    int accumulate;    // the f32 output is pre-zeroed (and re-zeroed by its consumer): split-K partials may be atomically added
 };
 
 void gemm_args_init(GemmArgs& a);
@@ -188,6 +189,7 @@ struct DecodeAttnArgs {
     int dtype;             // storage type of q / caches / out
     const void* q;         // [B, q_ld] : head h at h*64
     int q_ld;
+    int q_f32;             // q / knew / vnew are f32 accumulators: read, then zero them for the next split-K GEMM
     const void* knew;      // self-attn: this step's k/v rows [B, *] (nullptr for cross attention)
     const void* vnew;
     int kv_ld;
@@ -221,7 +223,7 @@ int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss
                      int V, hipStream_t s);
 int launch_sample(const float* logits, int ld_logits, int R, int top_k, float temperature, const float* noise,
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
-                  int tok_col_from_step, hipStream_t s);
+                  int tok_col_from_step, int zero_logits, hipStream_t s);
 int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
                       const int32_t* step_dev, float* x, int B, hipStream_t s);
 int launch_step_inc(int32_t* step_dev, hipStream_t s);

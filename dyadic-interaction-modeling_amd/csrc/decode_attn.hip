@@ -39,14 +39,46 @@ template <> __device__ __forceinline__ void store_chunk<bf16, 8>(bf16* p, const 
                             pack_bf16x2(v[6], v[7]));
 }
 
+template <typename T, int EPC> __device__ __forceinline__ void cvt_chunk(const uint4& u, float (&v)[EPC]);
+template <> __device__ __forceinline__ void cvt_chunk<float, 4>(const uint4& u, float (&v)[4]) {
+    v[0] = __builtin_bit_cast(float, u.x); v[1] = __builtin_bit_cast(float, u.y);
+    v[2] = __builtin_bit_cast(float, u.z); v[3] = __builtin_bit_cast(float, u.w);
+}
+template <> __device__ __forceinline__ void cvt_chunk<bf16, 8>(const uint4& u, float (&v)[8]) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+        v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+}
+
 // SELF = true: self-attention form (append this step's k/v, keys = step counter + 1);
 // SELF = false: cross-attention form (fixed n_keys, optional key mask).  Two instantiations so that the two
 // launch shapes show up as separate rows of a rocprofv3 kernel trace.
-template <typename T, bool SELF>
+// The kernel is a latency-bound HBM stream: every wave keeps 2 x U independent 16-byte loads per lane in
+// flight (the next batch of U key groups is issued before the current one is consumed).
+template <int EPC> __device__ __forceinline__ void load_f32_chunk(const float* p, float (&v)[EPC]) {
+#pragma unroll
+    for (int i = 0; i < EPC / 4; ++i) {
+        const float4 f = *(const float4*)(p + 4 * i);
+        v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+    }
+}
+template <int EPC> __device__ __forceinline__ void zero_f32_chunk(float* p) {
+#pragma unroll
+    for (int i = 0; i < EPC / 4; ++i) *(float4*)(p + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// QF32: q (and knew/vnew) are f32 split-K accumulators [B, ld]; they are read here and zeroed at the end of
+// the kernel so that the next layer's GEMM can accumulate into them again.
+template <typename T, bool SELF, bool QF32>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int LPK = 64 / EPC;   // lanes per key: 8 (bf16) / 16 (f32)
     constexpr int KPI = 64 / LPK;   // keys per wave-wide load: 8 / 4
+    constexpr int U = 4;            // key groups per batch
+    constexpr int KB = U * KPI;     // keys per batch
     __shared__ float sc[4][kMaxKeys];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -54,48 +86,72 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     const bool active = pair < a.B * a.H;
     const int b = active ? pair / a.H : 0, h = active ? pair % a.H : 0;
     const int sub = lane / LPK, ch = lane % LPK;
-    constexpr bool self = SELF;
     int n = a.n_keys;
-    if (self) n = *a.step;  // keys already in the cache
+    if (SELF) n = *a.step;  // keys already in the cache
     const float scale2 = a.scale * 1.4426950408889634f;
 
     const T* kc = (const T*)a.kcache + ((size_t)(b * a.H + h) * a.Tmax) * 64 + ch * EPC;
     const T* vc = (const T*)a.vcache + ((size_t)(b * a.H + h) * a.Tmax) * 64 + ch * EPC;
     float* s = sc[wave];
+    const bool masked = !SELF && a.kmask != nullptr;
 
+    auto load_batch = [&](const T* base, int j0, uint4 (&r)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * KPI + sub;
+            r[u] = *(const uint4*)(base + (size_t)(j < n ? j : (n > 0 ? n - 1 : 0)) * 64);
+        }
+    };
+
+    uint4 cur[U], nxt[U];
+    if (n > 0) load_batch(kc, 0, cur);
+    // key mask -> additive bias in LDS (cross-attention): coalesced byte loads, once per launch
+    if (masked) {
+        for (int j = lane; j < n; j += 64) s[j] = a.kmask[(size_t)b * a.kmask_ld + j] ? 0.f : kNegD;
+    }
     float qv[EPC];
-    load_chunk<T, EPC>((const T*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, qv);
+    if (QF32)
+        load_f32_chunk<EPC>((const float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, qv);
+    else
+        load_chunk<T, EPC>((const T*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, qv);
+    if (masked) __syncthreads();
 
     // ---- phase 1: scores
     float mx = kNegD;
-    for (int j0 = 0; j0 < n; j0 += 4 * KPI) {  // wave-uniform trip count, 4 loads in flight per lane
-        float kv[4][EPC];
+    for (int j0 = 0; j0 < n; j0 += KB) {
+        if (j0 + KB < n) load_batch(kc, j0 + KB, nxt);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int j = j0 + u * KPI + sub;
-            load_chunk<T, EPC>(kc + (size_t)(j < n ? j : n - 1) * 64, kv[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * KPI + sub;
+            float kv[EPC];
+            cvt_chunk<T, EPC>(cur[u], kv);
             float d = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) d = fmaf(qv[e], kv[u][e], d);
+            for (int e = 0; e < EPC; ++e) d = fmaf(qv[e], kv[e], d);
 #pragma unroll
             for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o);
             if (j < n) {
                 float sv = d * scale2;
-                if (a.kmask && a.kmask[(size_t)b * a.kmask_ld + j] == 0) sv = kNegD;
+                if (masked && s[j] != 0.f) sv = kNegD;
                 if (ch == 0) s[j] = sv;
                 mx = fmaxf(mx, sv);
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
+    // first V batch goes out before the softmax pass
+    if (n > 0) load_batch(vc, 0, cur);
     float knv[EPC], vnv[EPC];
     int total = n;
-    if (self) {
-        load_chunk<T, EPC>((const T*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, knv);
-        load_chunk<T, EPC>((const T*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, vnv);
+    if (SELF) {
+        if (QF32) {
+            load_f32_chunk<EPC>((const float*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, knv);
+            load_f32_chunk<EPC>((const float*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, vnv);
+        } else {
+            load_chunk<T, EPC>((const T*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, knv);
+            load_chunk<T, EPC>((const T*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, vnv);
+        }
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) d = fmaf(qv[e], knv[e], d);
@@ -127,22 +183,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     float acc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-    for (int j0 = 0; j0 < n; j0 += 4 * KPI) {
-        float vv[4][EPC];
+    for (int j0 = 0; j0 < n; j0 += KB) {
+        if (j0 + KB < n) load_batch(vc, j0 + KB, nxt);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int j = j0 + u * KPI + sub;
-            load_chunk<T, EPC>(vc + (size_t)(j < n ? j : n - 1) * 64, vv[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * KPI + sub;
+            float vv[EPC];
+            cvt_chunk<T, EPC>(cur[u], vv);
             const float p = j < n ? s[j] : 0.f;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[e] = fmaf(p, vv[u][e], acc[e]);
+            for (int e = 0; e < EPC; ++e) acc[e] = fmaf(p, vv[e], acc[e]);
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
-    if (self && sub == 0) {
+    if (SELF && sub == 0) {
         const float p = s[n];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = fmaf(p, vnv[e], acc[e]);
@@ -156,6 +211,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] *= inv;
         store_chunk<T, EPC>((T*)a.out + (size_t)b * a.o_ld + h * 64 + ch * EPC, acc);
+        if (QF32) {  // hand the accumulators back zeroed (all reads of this launch are long complete)
+            zero_f32_chunk<EPC>((float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC);
+            if (SELF) {
+                zero_f32_chunk<EPC>((float*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC);
+                zero_f32_chunk<EPC>((float*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC);
+            }
+        }
     }
 }
 
@@ -168,13 +230,15 @@ int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s) {
     DIMX_REQUIRE(a.Tmax <= kMaxKeys && a.n_keys <= kMaxKeys, DIMX_ERR_ARG, "decode_attn: more than %d keys", kMaxKeys);
     dim3 grid(ceil_div(a.B * a.H, 4)), block(256);
     const bool self = a.knew != nullptr;
+#define DA_LAUNCH(TT, SS, QQ) hipLaunchKernelGGL((decode_attn_kernel<TT, SS, QQ>), grid, block, 0, s, a)
     if (a.dtype == DIMX_BF16) {
-        if (self) hipLaunchKernelGGL((decode_attn_kernel<bf16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((decode_attn_kernel<bf16, false>), grid, block, 0, s, a);
+        if (a.q_f32) { if (self) DA_LAUNCH(bf16, true, true); else DA_LAUNCH(bf16, false, true); }
+        else { if (self) DA_LAUNCH(bf16, true, false); else DA_LAUNCH(bf16, false, false); }
     } else {
-        if (self) hipLaunchKernelGGL((decode_attn_kernel<float, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((decode_attn_kernel<float, false>), grid, block, 0, s, a);
+        if (a.q_f32) { if (self) DA_LAUNCH(float, true, true); else DA_LAUNCH(float, false, true); }
+        else { if (self) DA_LAUNCH(float, true, false); else DA_LAUNCH(float, false, false); }
     }
+#undef DA_LAUNCH
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      float temperature, const float* __restrict__ noise,
                                                      uint64_t seed, const int32_t* __restrict__ step_dev,
                                                      uint64_t step_host, int32_t* __restrict__ tokens, int tok_ld,
-                                                     int tok_col_from_step) {
+                                                     int tok_col_from_step, int zero_logits) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= R) return;
     const uint64_t step = step_dev ? (uint64_t)*step_dev : step_host;
@@ -145,6 +145,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             mx = v[c];
             mi = lane + 64 * c;
         }
+    }
+    if (zero_logits) {  // the logits buffer is a split-K accumulator: hand it back zeroed
+#pragma unroll
+        for (int c = 0; c < 8; ++c) const_cast<float*>(lr)[lane + 64 * c] = 0.f;
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -317,10 +321,10 @@ int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss
 
 int launch_sample(const float* logits, int ld_logits, int R, int top_k, float temperature, const float* noise,
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
-                  int tok_col_from_step, hipStream_t s) {
+                  int tok_col_from_step, int zero_logits, hipStream_t s) {
     DIMX_REQUIRE(logits && tokens && R > 0, DIMX_ERR_ARG, "sample: bad arguments");
     hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, logits, ld_logits, R, top_k,
-                       temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step);
+                       temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, zero_logits);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

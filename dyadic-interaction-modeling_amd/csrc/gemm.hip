@@ -548,7 +548,9 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     const int nk = a.ldw / bk;
     const bool inplace = a.residual && a.nseg == 1 && a.seg[0].ptr == (void*)a.residual && a.seg[0].sd == 1 &&
                          a.seg[0].sh == 0 && a.seg[0].st == a.ldr && a.rowT == 1;
-    if (a.allow_splitk && inplace && a.act == ACT_NONE && a.rowadd_mode == 0 && sizeof(OutT) == 4 && tiles < 256) {
+    const bool accum = a.accumulate && !a.residual && a.nseg == 1 && a.seg[0].sd == 1;
+    if (a.allow_splitk && (inplace || accum) && a.act == ACT_NONE && a.rowadd_mode == 0 && sizeof(OutT) == 4 &&
+        tiles < 256) {
         int sp = a.force_splitk > 0 ? a.force_splitk : (512 + tiles - 1) / tiles;
         const int max_sp = nk / 4 > 0 ? nk / 4 : 1;
         sp = sp > max_sp ? max_sp : sp;

@@ -637,7 +637,8 @@ struct GenScratch {
     void* sk[8];
     void* sv[8];
     float *x, *logits;
-    void *y, *qkv, *o, *f;
+    void *y, *o, *f;
+    float *qkv, *qc;  // f32 split-K accumulators (zeroed once, then re-zeroed by their consumers)
     int32_t* step;
 };
 
@@ -687,7 +688,8 @@ static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) 
     }
     s.x = (float*)ar.take((size_t)B * D * 4);
     s.y = ar.take((size_t)B * D * es);
-    s.qkv = ar.take((size_t)B * 3 * inner * es);
+    s.qkv = (float*)ar.take((size_t)B * 3 * inner * 4);
+    s.qc = (float*)ar.take((size_t)B * inner * 4);
     s.o = ar.take((size_t)B * inner * es);
     s.f = ar.take((size_t)B * D * c->d.ff_mult * es);
     s.logits = (float*)ar.take((size_t)B * c->d.num_tokens * 4);
@@ -1037,15 +1039,17 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, GenScratch& s, const in
         DecodeAttnArgs a;
         DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.self_[l].ln_g, nullptr, B, DD, st));
         gemm_lin(h, s.y, DD, h->dec.self_[l].qkv, B, g);
-        g.out_dtype = h->at;
+        g.out_dtype = DIMX_F32;
+        g.accumulate = 1;
         gemm_set_plain_out(g, s.qkv, 3 * inner);
         DIMX_TRY(launch_gemm(g, st));
         memset(&a, 0, sizeof(a));
         a.dtype = h->at;
         a.q = s.qkv;
         a.q_ld = 3 * inner;
-        a.knew = (const unsigned char*)s.qkv + (size_t)inner * es;
-        a.vnew = (const unsigned char*)s.qkv + (size_t)2 * inner * es;
+        a.q_f32 = 1;
+        a.knew = s.qkv + inner;
+        a.vnew = s.qkv + 2 * inner;
         a.kv_ld = 3 * inner;
         a.kcache = s.sk[l];
         a.vcache = s.sv[l];
@@ -1066,13 +1070,15 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, GenScratch& s, const in
 
         DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.cross[l].ln_g, nullptr, B, DD, st));
         gemm_lin(h, s.y, DD, h->dec.cross[l].qkv, B, g);
-        g.out_dtype = h->at;
-        gemm_set_plain_out(g, s.qkv, inner);
+        g.out_dtype = DIMX_F32;
+        g.accumulate = 1;
+        gemm_set_plain_out(g, s.qc, inner);
         DIMX_TRY(launch_gemm(g, st));
         memset(&a, 0, sizeof(a));
         a.dtype = h->at;
-        a.q = s.qkv;
+        a.q = s.qc;
         a.q_ld = inner;
+        a.q_f32 = 1;
         a.kcache = cp.ck[l];
         a.vcache = cp.cv[l];
         a.Tmax = Tp;
@@ -1109,10 +1115,11 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, GenScratch& s, const in
     GemmArgs g;
     gemm_lin(h, s.y, DD, h->dec.logits, B, g);
     g.out_dtype = DIMX_F32;
+    g.accumulate = 1;
     gemm_set_plain_out(g, s.logits, V);
     DIMX_TRY(launch_gemm(g, st));
     if (logits_out) DIMX_TRY(launch_copy_rows_step(s.logits, logits_out, B, V, n, s.step, st));
-    DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, st));
+    DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, 1, st));
     DIMX_TRY(launch_step_inc(s.step, st));
     return DIMX_OK;
 }
@@ -1136,6 +1143,10 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "generate: workspace overflow");
     const int n = T - 1;
     DIMX_HIP(hipMemsetAsync(s.step, 0, 4, st));
+    // split-K accumulators start at zero; every consumer zeroes what it has read
+    DIMX_HIP(hipMemsetAsync(s.qkv, 0, (size_t)B * 3 * h->d.heads * h->d.dim_head * 4, st));
+    DIMX_HIP(hipMemsetAsync(s.qc, 0, (size_t)B * h->d.heads * h->d.dim_head * 4, st));
+    DIMX_HIP(hipMemsetAsync(s.logits, 0, (size_t)B * h->d.num_tokens * 4, st));
     if (!h->use_graph) {
         for (int t = 0; t < n; ++t)
             DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, B, T, temperature, top_k, exp_noise, seed, tokens, logits_out, st));
@@ -1254,7 +1265,7 @@ int dimx_op_sample(const float* logits, int R, int top_k, float temperature, con
                    uint64_t step, int32_t* tokens, void* stream) {
     // exp_noise here is the [R,512] slice of this step (step only salts the on-device generator)
     return launch_sample(logits, 512, R, top_k, temperature, exp_noise, seed, nullptr, exp_noise ? 0 : step, tokens, 1,
-                         0, (hipStream_t)stream);
+                         0, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"
