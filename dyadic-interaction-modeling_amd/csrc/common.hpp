@@ -223,7 +223,8 @@ int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss
                      int V, hipStream_t s);
 int launch_sample(const float* logits, int ld_logits, int R, int top_k, float temperature, const float* noise,
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
-                  int tok_col_from_step, int zero_logits, hipStream_t s);
+                  int tok_col_from_step, int zero_logits, int row0, int rows_total, const float* emb_table, int emb_C,
+                  float* x_next, int32_t* step_rw, unsigned* done_ctr, hipStream_t s);
 int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
                       const int32_t* step_dev, float* x, int B, hipStream_t s);
 int launch_step_inc(int32_t* step_dev, hipStream_t s);

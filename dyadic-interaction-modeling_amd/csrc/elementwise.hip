@@ -130,10 +130,13 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      float temperature, const float* __restrict__ noise,
                                                      uint64_t seed, const int32_t* __restrict__ step_dev,
                                                      uint64_t step_host, int32_t* __restrict__ tokens, int tok_ld,
-                                                     int tok_col_from_step, int zero_logits) {
+                                                     int tok_col_from_step, int zero_logits, int row0, int rows_total,
+                                                     const float* __restrict__ emb_table, int emb_C,
+                                                     float* __restrict__ x_next, int32_t* __restrict__ step_rw,
+                                                     unsigned* __restrict__ done_ctr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= R) return;
     const uint64_t step = step_dev ? (uint64_t)*step_dev : step_host;
+    if (row < R) {
     const float* lr = logits + (size_t)row * ld;
     float v[8];
     float mx = -3.0e38f;
@@ -191,9 +194,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             const int i = lane + 64 * c;
             float q;
             if (noise) {
-                q = noise[((size_t)step * R + row) * 512 + i];
+                q = noise[((size_t)step * rows_total + row0 + row) * 512 + i];
             } else {
-                const uint64_t r = splitmix(seed, ((uint64_t)step * R + row) * 512 + i);
+                const uint64_t r = splitmix(seed, ((uint64_t)step * rows_total + row0 + row) * 512 + i);
                 const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
                 q = fmaxf(-log1pf(-u), 9.313225746154785e-10f);
             }
@@ -215,6 +218,24 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         tok = bi;
     }
     if (lane == 0) tokens[(size_t)row * tok_ld + (tok_col_from_step ? (int)step : 0)] = tok;
+    if (x_next) {  // next step's decoder input: token embedding row (fused embed_step)
+        const float2* src = (const float2*)(emb_table + (size_t)tok * emb_C);
+        float2* dst = (float2*)(x_next + (size_t)row * emb_C);
+        for (int i = lane; i < emb_C / 2; i += 64) dst[i] = src[i];
+    }
+    }  // row < R
+    // the block that finishes last advances the device step counter (every block has read it by then)
+    if (step_rw) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned prev = atomicAdd(done_ctr, 1u);
+            if (prev == gridDim.x - 1) {
+                *done_ctr = 0u;
+                *step_rw = (int32_t)step + 1;
+            }
+        }
+    }
 }
 
 // x[b, :] = token_emb[tok_b], tok_b = start[b] at step 0 else the token sampled at the previous step
@@ -321,10 +342,12 @@ int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss
 
 int launch_sample(const float* logits, int ld_logits, int R, int top_k, float temperature, const float* noise,
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
-                  int tok_col_from_step, int zero_logits, hipStream_t s) {
+                  int tok_col_from_step, int zero_logits, int row0, int rows_total, const float* emb_table, int emb_C,
+                  float* x_next, int32_t* step_rw, unsigned* done_ctr, hipStream_t s) {
     DIMX_REQUIRE(logits && tokens && R > 0, DIMX_ERR_ARG, "sample: bad arguments");
     hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, logits, ld_logits, R, top_k,
-                       temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, zero_logits);
+                       temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, zero_logits, row0,
+                       rows_total, emb_table, emb_C, x_next, step_rw, done_ctr);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -285,7 +285,8 @@ template <int MI, int NI> struct FragMma<float, MI, NI> {
     }
 };
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES>
+// ABL (ablation, tuning only): 0 normal, 1 = no MFMA/ds_read in the loop (DMA only), 2 = no DMA in the loop
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a) {
     constexpr int NW = WM * WN;
     constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
@@ -376,16 +377,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
 
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) issue(s, s);
+        if (s < nk && (ABL != 2 || s == 0)) issue(s, s);
 
     for (int it = 0; it < nk; ++it) {
         // tile `it` has landed once at most min(STAGES-2, nk-1-it) younger tiles are still in flight
-        if (nk - 1 - it >= STAGES - 2)
-            wait_vmcnt<(STAGES - 2) * LPT>();
-        else
+        if (ABL == 2 || nk - 1 - it < STAGES - 2)
             wait_vmcnt<0>();
+        else
+            wait_vmcnt<(STAGES - 2) * LPT>();
         __builtin_amdgcn_s_barrier();
-        if (it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        if (ABL != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        if (ABL == 1) continue;
         const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
         // all fragment reads of a group of k-steps are issued back to back; the MFMAs of k-step s start as
         // soon as the reads of steps <= s have returned (LDS returns in order: counted lgkmcnt)
@@ -475,11 +477,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
 static int launch_glds(const GemmArgs& a, hipStream_t s) {
     const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
     dim3 grid(tiles * a.splitk), block(WM * WN * 64);
-    hipLaunchKernelGGL((gemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES, ABL>), grid, block, 0, s, a);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
@@ -513,6 +515,12 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 10: return launch_glds<T, OutT, 64, 64, 2, 2, 6>(a, s);
         case 11: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
         case 12: return launch_glds<T, OutT, 128, 64, 2, 2, 4>(a, s);
+        case 13: return launch_glds<T, OutT, 128, 64, 4, 2, 3>(a, s);   // 8 waves
+        case 14: return launch_glds<T, OutT, 128, 128, 4, 2, 2>(a, s);  // 8 waves
+        case 15: return launch_glds<T, OutT, 128, 128, 4, 2, 3>(a, s);  // 8 waves
+        case 16: return launch_glds<T, OutT, 256, 64, 8, 1, 2>(a, s);   // 8 waves, whole-M column tile
+        case 20: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 1>(a, s);  // ablation: DMA only
+        case 21: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 2>(a, s);  // ablation: compute only
         default: break;
     }
     set_error("gemm: unknown cfg %d", cfg);
@@ -521,8 +529,9 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
 
 static inline void cfg_tile(int cfg, int& bm, int& bn) {
     switch (cfg) {
-        case 1: case 2: case 11: bm = 128; bn = 128; break;
-        case 6: case 7: case 12: bm = 128; bn = 64; break;
+        case 1: case 2: case 11: case 14: case 15: bm = 128; bn = 128; break;
+        case 6: case 7: case 12: case 13: bm = 128; bn = 64; break;
+        case 16: bm = 256; bn = 64; break;
         case 8: bm = 64; bn = 128; break;
         default: bm = 64; bn = 64; break;
     }
@@ -551,7 +560,8 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     const bool accum = a.accumulate && !a.residual && a.nseg == 1 && a.seg[0].sd == 1;
     if (a.allow_splitk && (inplace || accum) && a.act == ACT_NONE && a.rowadd_mode == 0 && sizeof(OutT) == 4 &&
         tiles < 256) {
-        int sp = a.force_splitk > 0 ? a.force_splitk : (512 + tiles - 1) / tiles;
+        // measured (tools/bench_gemm.py under rocprofv3): ~288 blocks (one per CU + a few) is the sweet spot
+        int sp = a.force_splitk > 0 ? a.force_splitk : (288 + tiles / 2) / tiles;
         const int max_sp = nk / 4 > 0 ? nk / 4 : 1;
         sp = sp > max_sp ? max_sp : sp;
         sp = sp > 16 ? 16 : sp;

@@ -553,6 +553,8 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     for (const auto& k : all_keys(d)) c->required.push_back(k.name);
     const char* ng = getenv("DIMX_NO_GRAPH");
     c->use_graph = (ng && ng[0] == '1') ? 0 : 1;
+    const char* gg = getenv("DIMX_GEN_GROUPS");
+    if (gg && atoi(gg) >= 1 && atoi(gg) <= dimx_ctx::kMaxGroups) c->gen_groups = atoi(gg);
     *h = c;
     return DIMX_OK;
 }
@@ -560,7 +562,12 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
 int dimx_destroy(dimx_handle h) {
     if (!h) return DIMX_OK;
     (void)hipSetDevice(h->device);
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    for (int g = 0; g < dimx_ctx::kMaxGroups; ++g) {
+        if (h->graph_exec[g]) (void)hipGraphExecDestroy(h->graph_exec[g]);
+        if (h->grp_stream[g]) (void)hipStreamDestroy(h->grp_stream[g]);
+        if (h->ev_join[g]) (void)hipEventDestroy(h->ev_join[g]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     free_packed(h);
     delete h;
@@ -693,7 +700,7 @@ static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) 
     s.o = ar.take((size_t)B * inner * es);
     s.f = ar.take((size_t)B * D * c->d.ff_mult * es);
     s.logits = (float*)ar.take((size_t)B * c->d.num_tokens * 4);
-    s.step = (int32_t*)ar.take(256);
+    s.step = (int32_t*)ar.take(64 * dimx_ctx::kMaxGroups);  // one counter per clip group, 64 B apart
 }
 
 static size_t workspace_bytes(const dimx_ctx* c, int B, int T) {
@@ -1025,15 +1032,34 @@ int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, c
 
 namespace dimx {
 
-// one decoder step: x = emb(token) -> 4 x {self, cross, ff} -> logits -> sample -> step += 1
-static int gen_step(dimx_handle h, const CtxPersist& cp, GenScratch& s, const int32_t* start, const uint8_t* ctx_mask,
-                    int B, int T, float temperature, int top_k, const float* noise, uint64_t seed, int32_t* tokens,
-                    float* logits_out, hipStream_t st) {
+// one decoder step for the clip group [row0, row0 + B) of a batch of Btot clips:
+// x = emb(token) -> 4 x {self, cross, ff} -> logits -> sample -> step += 1
+static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, const int32_t* start,
+                    const uint8_t* ctx_mask, int row0, int B, int Btot, int grp, int T, float temperature, int top_k,
+                    const float* noise, uint64_t seed, int32_t* tokens, float* logits_out, hipStream_t st,
+                    bool embed_only = false) {
     const int DD = h->d.dim + h->d.dim_a, heads = h->d.heads, D = h->d.dim_head, inner = heads * D;
     const int V = h->d.num_tokens, n = T - 1, Tp = tpad(T);
     const size_t es = es_of(h);
     const float scale = 1.0f / sqrtf((float)D);
-    DIMX_TRY(launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, st));
+    // this group's slices of every per-clip buffer
+    GenScratch s = s0;
+    auto boff = [&](void* p, size_t per_row_bytes) { return (void*)((unsigned char*)p + (size_t)row0 * per_row_bytes); };
+    s.x = s0.x + (size_t)row0 * DD;
+    s.y = boff(s0.y, DD * es);
+    s.qkv = s0.qkv + (size_t)row0 * 3 * inner;
+    s.qc = s0.qc + (size_t)row0 * inner;
+    s.o = boff(s0.o, inner * es);
+    s.f = boff(s0.f, (size_t)DD * h->d.ff_mult * es);
+    s.logits = s0.logits + (size_t)row0 * V;
+    s.step = s0.step + 16 * grp;
+    start += row0;
+    ctx_mask += (size_t)row0 * T;
+    tokens += (size_t)row0 * n;
+    if (logits_out) logits_out += (size_t)row0 * n * V;
+    if (embed_only) {  // step 0 input = embedding of the start token (later steps: fused into the sampler)
+        return launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, st);
+    }
     for (int l = 0; l < h->d.dec_depth; ++l) {
         GemmArgs g;
         DecodeAttnArgs a;
@@ -1051,8 +1077,8 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, GenScratch& s, const in
         a.knew = s.qkv + inner;
         a.vnew = s.qkv + 2 * inner;
         a.kv_ld = 3 * inner;
-        a.kcache = s.sk[l];
-        a.vcache = s.sv[l];
+        a.kcache = boff(s0.sk[l], (size_t)heads * T * 64 * es);
+        a.vcache = boff(s0.sv[l], (size_t)heads * T * 64 * es);
         a.Tmax = T;
         a.out = s.o;
         a.o_ld = inner;
@@ -1079,8 +1105,8 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, GenScratch& s, const in
         a.q = s.qc;
         a.q_ld = inner;
         a.q_f32 = 1;
-        a.kcache = cp.ck[l];
-        a.vcache = cp.cv[l];
+        a.kcache = boff(cp.ck[l], (size_t)heads * Tp * 64 * es);
+        a.vcache = boff(cp.cv[l], (size_t)heads * Tp * 64 * es);
         a.Tmax = Tp;
         a.out = s.o;
         a.o_ld = inner;
@@ -1119,8 +1145,8 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, GenScratch& s, const in
     gemm_set_plain_out(g, s.logits, V);
     DIMX_TRY(launch_gemm(g, st));
     if (logits_out) DIMX_TRY(launch_copy_rows_step(s.logits, logits_out, B, V, n, s.step, st));
-    DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, 1, st));
-    DIMX_TRY(launch_step_inc(s.step, st));
+    DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, 1, row0, Btot,
+                           h->dec.tok_emb, DD, s.x, s.step, (unsigned*)(s.step + 8), st));
     return DIMX_OK;
 }
 
@@ -1142,40 +1168,77 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     plan_gen(h, ar, B, T, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "generate: workspace overflow");
     const int n = T - 1;
-    DIMX_HIP(hipMemsetAsync(s.step, 0, 4, st));
+    DIMX_HIP(hipMemsetAsync(s.step, 0, 64 * dimx_ctx::kMaxGroups, st));
     // split-K accumulators start at zero; every consumer zeroes what it has read
     DIMX_HIP(hipMemsetAsync(s.qkv, 0, (size_t)B * 3 * h->d.heads * h->d.dim_head * 4, st));
     DIMX_HIP(hipMemsetAsync(s.qc, 0, (size_t)B * h->d.heads * h->d.dim_head * 4, st));
     DIMX_HIP(hipMemsetAsync(s.logits, 0, (size_t)B * h->d.num_tokens * 4, st));
+
+    // Independent clip groups run as separate step graphs on separate streams: every decode kernel is
+    // latency-bound at these sizes, so two groups in flight let one group's GEMM/LayerNorm chain overlap the
+    // other group's HBM-bound attention.  Results do not depend on the grouping (per-clip state only; the
+    // sampler's noise / counter-based RNG is indexed by the global clip row).
+    int G = h->gen_groups < 1 ? 1 : h->gen_groups;
+    if (G > B) G = B;
+    int lo[dimx_ctx::kMaxGroups + 1];
+    for (int g = 0; g <= G; ++g) lo[g] = (int)((long)B * g / G);
+    hipStream_t gs[dimx_ctx::kMaxGroups];
+    if (G == 1) {
+        gs[0] = st;
+    } else {
+        if (!h->ev_fork) DIMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        DIMX_HIP(hipEventRecord(h->ev_fork, st));
+        for (int g = 0; g < G; ++g) {
+            if (!h->grp_stream[g]) DIMX_HIP(hipStreamCreateWithFlags(&h->grp_stream[g], hipStreamNonBlocking));
+            if (!h->ev_join[g]) DIMX_HIP(hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
+            gs[g] = h->grp_stream[g];
+            DIMX_HIP(hipStreamWaitEvent(gs[g], h->ev_fork, 0));
+        }
+    }
+    for (int g = 0; g < G; ++g)
+        DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], B, g, T, temperature, top_k, exp_noise,
+                          seed, tokens, logits_out, gs[g], true));
     if (!h->use_graph) {
         for (int t = 0; t < n; ++t)
-            DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, B, T, temperature, top_k, exp_noise, seed, tokens, logits_out, st));
-        return DIMX_OK;
-    }
-    GraphKey key{ws, B, T, top_k, temperature, exp_noise, seed, start, ctx_mask, tokens, logits_out};
-    if (!(h->graph_valid && h->graph_key == key)) {
-        if (h->graph_exec) {
-            (void)hipGraphExecDestroy(h->graph_exec);
-            h->graph_exec = nullptr;
+            for (int g = 0; g < G; ++g)
+                DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], B, g, T, temperature, top_k,
+                                  exp_noise, seed, tokens, logits_out, gs[g]));
+    } else {
+        GraphKey key{ws, B, T, top_k, temperature, exp_noise, seed, start, ctx_mask, tokens, logits_out, G};
+        if (!(h->graph_valid && h->graph_key == key)) {
+            h->graph_valid = false;
+            if (!h->cap_stream) DIMX_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+            for (int g = 0; g < dimx_ctx::kMaxGroups; ++g)
+                if (h->graph_exec[g]) {
+                    (void)hipGraphExecDestroy(h->graph_exec[g]);
+                    h->graph_exec[g] = nullptr;
+                }
+            for (int g = 0; g < G; ++g) {
+                hipGraph_t graph = nullptr;
+                DIMX_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+                const int rc = gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], B, g, T, temperature, top_k,
+                                        exp_noise, seed, tokens, logits_out, h->cap_stream);
+                const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+                if (rc != DIMX_OK) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    return rc;
+                }
+                DIMX_HIP(ce);
+                DIMX_HIP(hipGraphInstantiate(&h->graph_exec[g], graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+            }
+            h->graph_key = key;
+            h->graph_valid = true;
         }
-        h->graph_valid = false;
-        hipGraph_t graph = nullptr;
-        if (!h->cap_stream) DIMX_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-        DIMX_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        const int rc = gen_step(h, cp, s, start, ctx_mask, B, T, temperature, top_k, exp_noise, seed, tokens, logits_out,
-                                h->cap_stream);
-        const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
-        if (rc != DIMX_OK) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc;
-        }
-        DIMX_HIP(ce);
-        DIMX_HIP(hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        h->graph_key = key;
-        h->graph_valid = true;
+        for (int t = 0; t < n; ++t)
+            for (int g = 0; g < G; ++g) DIMX_HIP(hipGraphLaunch(h->graph_exec[g], gs[g]));
     }
-    for (int t = 0; t < n; ++t) DIMX_HIP(hipGraphLaunch(h->graph_exec, st));
+    if (G > 1) {
+        for (int g = 0; g < G; ++g) {
+            DIMX_HIP(hipEventRecord(h->ev_join[g], gs[g]));
+            DIMX_HIP(hipStreamWaitEvent(st, h->ev_join[g], 0));
+        }
+    }
     return DIMX_OK;
 }
 
@@ -1200,6 +1263,7 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     g.ldr = ldr;
     g.allow_splitk = flags & 1;
     g.force_simple = (flags >> 1) & 1;
+    g.accumulate = (flags >> 2) & 1;       /* C is pre-zeroed: split-K partials are atomically added */
     g.cfg = (flags >> 8) & 0xff;           /* tuning: tile/stage config id */
     g.force_splitk = (flags >> 16) & 0xff; /* tuning: split count */
     if (conv_T > 0) {
@@ -1265,7 +1329,7 @@ int dimx_op_sample(const float* logits, int R, int top_k, float temperature, con
                    uint64_t step, int32_t* tokens, void* stream) {
     // exp_noise here is the [R,512] slice of this step (step only salts the on-device generator)
     return launch_sample(logits, 512, R, top_k, temperature, exp_noise, seed, nullptr, exp_noise ? 0 : step, tokens, 1,
-                         0, 0, (hipStream_t)stream);
+                         0, 0, 0, R, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -84,8 +84,9 @@ struct GraphKey {
     const void* noise;
     uint64_t seed;
     const void *start, *mask, *tokens, *logits_out;
+    int groups;
     bool operator==(const GraphKey& o) const {
-        return ws == o.ws && B == o.B && T == o.T && top_k == o.top_k && temperature == o.temperature &&
+        return groups == o.groups && ws == o.ws && B == o.B && T == o.T && top_k == o.top_k && temperature == o.temperature &&
                noise == o.noise && seed == o.seed && start == o.start && mask == o.mask && tokens == o.tokens &&
                logits_out == o.logits_out;
     }
@@ -111,7 +112,12 @@ struct dimx_ctx {
     int ctx_B = 0, ctx_T = 0, ctx_for_generate = 0;
     void* ctx_ws = nullptr;
     // generate step graph
-    hipGraphExec_t graph_exec = nullptr;
+    static constexpr int kMaxGroups = 8;
+    hipGraphExec_t graph_exec[kMaxGroups] = {};
+    hipStream_t grp_stream[kMaxGroups] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups] = {};
+    int gen_groups = 1;  // independent clip groups decoded concurrently on separate streams (DIMX_GEN_GROUPS;
+                         // measured on MI355X: 1 is fastest, concurrent step graphs do not overlap usefully)
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the null stream)
     dimx::GraphKey graph_key{};
     bool graph_valid = false;

@@ -21,12 +21,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     const float2* xr = (const float2*)(x + (size_t)row * C);
-    float2 v[NV];
+    const float2* g2 = (const float2*)gamma;
+    const float2* b2 = (const float2*)beta;
+    float2 v[NV], gv[NV], bv[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i] = xr[lane + 64 * i];
         s += v[i].x + v[i].y;
+    }
+    // gamma / beta are fetched now so that their (possibly HBM-miss) latency overlaps the two reductions
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        gv[i] = g2[lane + 64 * i];
+        bv[i] = beta ? b2[lane + 64 * i] : make_float2(0.f, 0.f);
     }
     const float mean = wave_sum(s) * (1.0f / C);
     float q = 0.f;
@@ -36,21 +44,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         q += a * a + b * b;
     }
     const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
-    const float2* g2 = (const float2*)gamma;
-    const float2* b2 = (const float2*)beta;
     OutT* yr = y + (size_t)row * C;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c2 = lane + 64 * i;
-        const float2 g = g2[c2];
-        float o0 = (v[i].x - mean) * rstd * g.x, o1 = (v[i].y - mean) * rstd * g.y;
-        if (beta) {
-            const float2 bb = b2[c2];
-            o0 += bb.x;
-            o1 += bb.y;
+        const float o0 = (v[i].x - mean) * rstd * gv[i].x + bv[i].x;
+        const float o1 = (v[i].y - mean) * rstd * gv[i].y + bv[i].y;
+        if (sizeof(OutT) == 2) {
+            *(uint32_t*)(yr + 2 * c2) = pack_bf16x2(o0, o1);
+        } else {
+            *(float2*)(yr + 2 * c2) = make_float2(o0, o1);
         }
-        store_from_f32<OutT>(yr + 2 * c2, o0);
-        store_from_f32<OutT>(yr + 2 * c2 + 1, o1);
     }
 }
 

@@ -123,6 +123,31 @@ def test_generate_graph_equals_eager(full_sd, monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_generate_is_independent_of_clip_grouping(full_sd):
+    """dimx_generate decodes independent clip groups concurrently on separate streams; the tokens must not
+    depend on the number of groups (sampler noise is indexed by the global clip row)."""
+    import os
+    from dimx import engine, lib, prng
+    B, T = 5, 36
+    v_s, v_a, z, mask = _case(B, T, [36, 30, 36, 12, 25], seed=6)
+    noise = torch.from_numpy(prng.exponential(2, "grp.noise", (T - 1, B, 512))).cuda()
+    m8 = mask.to(torch.uint8).cuda()
+    outs = []
+    for groups in ("1", "2", "3"):
+        os.environ["DIMX_GEN_GROUPS"] = groups
+        e = engine.Engine("cuda:0", lib.MODE_PARITY_F32)
+        e.load_state_dict(full_sd)
+        e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+        a = e.generate(z[:, 0].cuda(), m8, T, 1.0, 52, noise).cpu()
+        e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+        b = e.generate(z[:, 0].cuda(), m8, T, 1.0, 52, None, seed=77).cpu()
+        outs.append((a, b))
+        e.close()
+    os.environ.pop("DIMX_GEN_GROUPS", None)
+    for a, b in outs[1:]:
+        assert torch.equal(a, outs[0][0]) and torch.equal(b, outs[0][1])
+
+
 def test_bf16_mode_agreement_report(eng_bf16, full_sd):
     """perf mode: report (not assert bit-exactness) token agreement and logit error vs the f32 oracle."""
     from oracle import ref_cpu
