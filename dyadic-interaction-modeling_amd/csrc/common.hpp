@@ -154,17 +154,24 @@ struct GemmArgs {
     int force_simple;  // tests: force the register-staged kernel
     int cfg;           // tile/stage configuration id of the LDS-DMA kernel (0 = automatic)
     int force_splitk;  // tuning: requested split count (0 = automatic)
-    int accumulate;    // the f32 output is pre-zeroed (and re-zeroed by its consumer): split-K partials may be atomically added
+    int out_slabs;     // split-K partial sums go to f32 slabs C + split*slab_stride (plain stores, fixed order
+                       // reduction by the consumer kernel); requires act none, no residual/rowadd, plain output
+    long slab_stride;  // elements between slabs
 };
 
 void gemm_args_init(GemmArgs& a);
 // plain row-major output helper
 void gemm_set_plain_out(GemmArgs& a, void* C, int ldc);
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// number of K splits launch_gemm will use for an out_slabs GEMM (the consumer needs it)
+int gemm_plan_splits(const GemmArgs& a);
 
 // ---------------------------------------------------------------- other launchers
 int launch_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta, int M,
                      int C, hipStream_t s);
+// x[row] += sum_s slabs[s][row] (fixed order), then y = LayerNorm(x); decode-step residual + pre-norm
+int launch_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
+                               const float* gamma, int M, int C, hipStream_t s);
 int launch_instnorm(int out_dtype, const float* x, void* y, const int32_t* lens, int B, int T, int C,
                     hipStream_t s);
 
@@ -189,7 +196,9 @@ struct DecodeAttnArgs {
     int dtype;             // storage type of q / caches / out
     const void* q;         // [B, q_ld] : head h at h*64
     int q_ld;
-    int q_f32;             // q / knew / vnew are f32 accumulators: read, then zero them for the next split-K GEMM
+    int q_f32;             // q / knew / vnew are f32 split-K slabs [nslab][B, ld]: summed in slab order on load
+    int nslab;
+    long slab_stride;      // elements between slabs
     const void* knew;      // self-attn: this step's k/v rows [B, *] (nullptr for cross attention)
     const void* vnew;
     int kv_ld;
@@ -223,8 +232,9 @@ int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss
                      int V, hipStream_t s);
 int launch_sample(const float* logits, int ld_logits, int R, int top_k, float temperature, const float* noise,
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
-                  int tok_col_from_step, int zero_logits, int row0, int rows_total, const float* emb_table, int emb_C,
-                  float* x_next, int32_t* step_rw, unsigned* done_ctr, hipStream_t s);
+                  int tok_col_from_step, int nslab, long slab_stride, float* logits_out, int logits_out_ld, int row0,
+                  int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
+                  hipStream_t s);
 int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
                       const int32_t* step_dev, float* x, int B, hipStream_t s);
 int launch_step_inc(int32_t* step_dev, hipStream_t s);

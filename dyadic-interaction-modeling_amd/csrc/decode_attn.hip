@@ -65,13 +65,19 @@ template <int EPC> __device__ __forceinline__ void load_f32_chunk(const float* p
         v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
     }
 }
-template <int EPC> __device__ __forceinline__ void zero_f32_chunk(float* p) {
+// sum of the split-K slabs in slab order (deterministic)
+template <int EPC> __device__ __forceinline__ void load_f32_slabs(const float* p, int nslab, long stride, float (&v)[EPC]) {
+    load_f32_chunk<EPC>(p, v);
+    for (int s = 1; s < nslab; ++s) {
+        float t[EPC];
+        load_f32_chunk<EPC>(p + (size_t)s * stride, t);
 #pragma unroll
-    for (int i = 0; i < EPC / 4; ++i) *(float4*)(p + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = 0; e < EPC; ++e) v[e] += t[e];
+    }
 }
 
-// QF32: q (and knew/vnew) are f32 split-K accumulators [B, ld]; they are read here and zeroed at the end of
-// the kernel so that the next layer's GEMM can accumulate into them again.
+// QF32: q (and knew/vnew) are f32 split-K slabs [nslab][B, ld] written by the projection GEMM; they are
+// summed here in slab order.
 template <typename T, bool SELF, bool QF32>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a) {
     constexpr int EPC = 16 / sizeof(T);
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     }
     float qv[EPC];
     if (QF32)
-        load_f32_chunk<EPC>((const float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, qv);
+        load_f32_slabs<EPC>((const float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, a.nslab, a.slab_stride, qv);
     else
         load_chunk<T, EPC>((const T*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, qv);
     if (masked) __syncthreads();
@@ -146,8 +152,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     int total = n;
     if (SELF) {
         if (QF32) {
-            load_f32_chunk<EPC>((const float*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, knv);
-            load_f32_chunk<EPC>((const float*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, vnv);
+            load_f32_slabs<EPC>((const float*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, a.nslab, a.slab_stride, knv);
+            load_f32_slabs<EPC>((const float*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, a.nslab, a.slab_stride, vnv);
         } else {
             load_chunk<T, EPC>((const T*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, knv);
             load_chunk<T, EPC>((const T*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, vnv);
@@ -211,13 +217,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] *= inv;
         store_chunk<T, EPC>((T*)a.out + (size_t)b * a.o_ld + h * 64 + ch * EPC, acc);
-        if (QF32) {  // hand the accumulators back zeroed (all reads of this launch are long complete)
-            zero_f32_chunk<EPC>((float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC);
-            if (SELF) {
-                zero_f32_chunk<EPC>((float*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC);
-                zero_f32_chunk<EPC>((float*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC);
-            }
-        }
     }
 }
 

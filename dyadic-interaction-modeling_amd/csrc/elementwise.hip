@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      float temperature, const float* __restrict__ noise,
                                                      uint64_t seed, const int32_t* __restrict__ step_dev,
                                                      uint64_t step_host, int32_t* __restrict__ tokens, int tok_ld,
-                                                     int tok_col_from_step, int zero_logits, int row0, int rows_total,
+                                                     int tok_col_from_step, int nslab, long slab_stride,
+                                                     float* __restrict__ logits_out, int logits_out_ld, int row0,
+                                                     int rows_total,
                                                      const float* __restrict__ emb_table, int emb_C,
                                                      float* __restrict__ x_next, int32_t* __restrict__ step_rw,
                                                      unsigned* __restrict__ done_ctr) {
@@ -144,14 +146,16 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         v[c] = lr[lane + 64 * c];
+        for (int sidx = 1; sidx < nslab; ++sidx) v[c] += lr[(size_t)sidx * slab_stride + lane + 64 * c];  // split-K slabs
         if (v[c] > mx) {
             mx = v[c];
             mi = lane + 64 * c;
         }
     }
-    if (zero_logits) {  // the logits buffer is a split-K accumulator: hand it back zeroed
+    if (logits_out) {  // per-step dump of the raw logits: [rows, steps, 512]
+        float* lo = logits_out + ((size_t)row * logits_out_ld + step) * 512;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) const_cast<float*>(lr)[lane + 64 * c] = 0.f;
+        for (int c = 0; c < 8; ++c) lo[lane + 64 * c] = v[c];
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -342,12 +346,13 @@ int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss
 
 int launch_sample(const float* logits, int ld_logits, int R, int top_k, float temperature, const float* noise,
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
-                  int tok_col_from_step, int zero_logits, int row0, int rows_total, const float* emb_table, int emb_C,
-                  float* x_next, int32_t* step_rw, unsigned* done_ctr, hipStream_t s) {
+                  int tok_col_from_step, int nslab, long slab_stride, float* logits_out, int logits_out_ld, int row0,
+                  int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
+                  hipStream_t s) {
     DIMX_REQUIRE(logits && tokens && R > 0, DIMX_ERR_ARG, "sample: bad arguments");
     hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, logits, ld_logits, R, top_k,
-                       temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, zero_logits, row0,
-                       rows_total, emb_table, emb_C, x_next, step_rw, done_ctr);
+                       temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, nslab < 1 ? 1 : nslab,
+                       slab_stride, logits_out, logits_out_ld, row0, rows_total, emb_table, emb_C, x_next, step_rw, done_ctr);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     // ---- epilogue (same math as gemm_kernel; split-K partials are atomically added in place)
     const int rowT = a.rowT;
     const bool first = split == 0;
-    const bool atomic = a.splitk > 1;
+    const bool slabs = a.out_slabs != 0;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * NI * 32 + j * 32 + l31;
@@ -460,9 +460,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
                     }
                 }
                 OutT* dst = obase + (long)b * sg.sb + (long)t * sg.st;
-                if (atomic) {  // f32 only (checked by the launcher): in-place accumulation onto the residual
-                    float v = acc[i][j][r] + bias_v;
-                    unsafeAtomicAdd((float*)dst, v);
+                if (slabs) {  // f32 partial sum of this K split; the consumer adds the slabs in order
+                    ((float*)dst)[(long)split * a.slab_stride] = acc[i][j][r] + bias_v;
                 } else {
                     float v = apply_act(acc[i][j][r] + bias_v, a.act);
                     if (a.rowadd_mode) {
@@ -550,25 +549,31 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     }
     int cfg = a.cfg;
     if (cfg == 0) cfg = tiles128 >= 512 ? 7 : 4;  // measured on MI355X (tools/bench_gemm.py): 128x64x2 for large M, 64x64x3 for decode
-    int bm, bn;
-    cfg_tile(cfg, bm, bn);
-    // small grids (decode step): split K when the output is the f32 residual stream updated in place
-    const int tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
-    const int nk = a.ldw / bk;
-    const bool inplace = a.residual && a.nseg == 1 && a.seg[0].ptr == (void*)a.residual && a.seg[0].sd == 1 &&
-                         a.seg[0].sh == 0 && a.seg[0].st == a.ldr && a.rowT == 1;
-    const bool accum = a.accumulate && !a.residual && a.nseg == 1 && a.seg[0].sd == 1;
-    if (a.allow_splitk && (inplace || accum) && a.act == ACT_NONE && a.rowadd_mode == 0 && sizeof(OutT) == 4 &&
-        tiles < 256) {
-        // measured (tools/bench_gemm.py under rocprofv3): ~288 blocks (one per CU + a few) is the sweet spot
-        int sp = a.force_splitk > 0 ? a.force_splitk : (288 + tiles / 2) / tiles;
-        const int max_sp = nk / 4 > 0 ? nk / 4 : 1;
-        sp = sp > max_sp ? max_sp : sp;
-        sp = sp > 16 ? 16 : sp;
-        a.splitk = sp < 1 ? 1 : sp;
-        if (a.splitk > 1) a.residual = nullptr;  // the residual already sits in the output
+    if (a.out_slabs) {
+        a.splitk = gemm_plan_splits(a0);
+        a.residual = nullptr;
     }
     return launch_by_cfg<T, OutT>(a, cfg, s);
+}
+
+int gemm_plan_splits(const GemmArgs& a) {
+    if (!a.out_slabs) return 1;
+    if (a.force_splitk > 0) return a.force_splitk;
+    if (!a.allow_splitk) return 1;
+    const int bk = a.in_dtype == DIMX_BF16 ? 64 : 32;
+    if (a.conv_T != 0 || a.K % bk != 0 || a.K != a.ldw || a.force_simple) return 1;  // register-staged kernel: no split
+    int cfg = a.cfg, bm, bn;
+    if (cfg == 0) cfg = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) >= 512 ? 7 : 4;
+    cfg_tile(cfg, bm, bn);
+    const int tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
+    if (tiles >= 256) return 1;
+    const int nk = a.ldw / bk;
+    // measured (tools/bench_gemm.py under rocprofv3): ~288 blocks (one per CU + a few) is the sweet spot
+    int sp = (288 + tiles / 2) / tiles;
+    const int max_sp = nk / 4 > 0 ? nk / 4 : 1;
+    sp = sp > max_sp ? max_sp : sp;
+    sp = sp > 8 ? 8 : sp;
+    return sp < 1 ? 1 : sp;
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
@@ -588,6 +593,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     }
     for (int i = 0; i < a.nseg; ++i)
         DIMX_REQUIRE(a.seg[i].ptr && a.seg[i].D > 0, DIMX_ERR_ARG, "gemm: output segment %d unset", i);
+    if (a.out_slabs)
+        DIMX_REQUIRE(a.out_dtype == DIMX_F32 && a.act == ACT_NONE && !a.residual && a.rowadd_mode == 0 && a.nseg == 1 &&
+                         a.conv_T == 0 && a.K == a.ldw,
+                     DIMX_ERR_ARG, "gemm: slab output needs a plain f32 GEMM without activation/residual");
     if (a.in_dtype == DIMX_BF16) {
         if (a.out_dtype == DIMX_BF16) return launch_typed<bf16, bf16>(a, s);
         return launch_typed<bf16, float>(a, s);

@@ -645,7 +645,8 @@ struct GenScratch {
     void* sv[8];
     float *x, *logits;
     void *y, *o, *f;
-    float *qkv, *qc;  // f32 split-K accumulators (zeroed once, then re-zeroed by their consumers)
+    float *qkv, *qc, *xr;  // f32 split-K slabs [kMaxSlabs][B, N] of the qkv / cross-q / residual projections
+    long st_qkv, st_qc, st_xr, st_lg;  // slab strides (elements)
     int32_t* step;
 };
 
@@ -695,11 +696,17 @@ static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) 
     }
     s.x = (float*)ar.take((size_t)B * D * 4);
     s.y = ar.take((size_t)B * D * es);
-    s.qkv = (float*)ar.take((size_t)B * 3 * inner * 4);
-    s.qc = (float*)ar.take((size_t)B * inner * 4);
+    constexpr int kMaxSlabs = 8;
+    s.st_qkv = (long)B * 3 * inner;
+    s.st_qc = (long)B * inner;
+    s.st_xr = (long)B * D;
+    s.st_lg = (long)B * c->d.num_tokens;
+    s.qkv = (float*)ar.take((size_t)kMaxSlabs * s.st_qkv * 4);
+    s.qc = (float*)ar.take((size_t)kMaxSlabs * s.st_qc * 4);
+    s.xr = (float*)ar.take((size_t)kMaxSlabs * s.st_xr * 4);
     s.o = ar.take((size_t)B * inner * es);
     s.f = ar.take((size_t)B * D * c->d.ff_mult * es);
-    s.logits = (float*)ar.take((size_t)B * c->d.num_tokens * 4);
+    s.logits = (float*)ar.take((size_t)kMaxSlabs * B * c->d.num_tokens * 4);
     s.step = (int32_t*)ar.take(64 * dimx_ctx::kMaxGroups);  // one counter per clip group, 64 B apart
 }
 
@@ -1049,6 +1056,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     s.y = boff(s0.y, DD * es);
     s.qkv = s0.qkv + (size_t)row0 * 3 * inner;
     s.qc = s0.qc + (size_t)row0 * inner;
+    s.xr = s0.xr + (size_t)row0 * DD;
     s.o = boff(s0.o, inner * es);
     s.f = boff(s0.f, (size_t)DD * h->d.ff_mult * es);
     s.logits = s0.logits + (size_t)row0 * V;
@@ -1060,20 +1068,34 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     if (embed_only) {  // step 0 input = embedding of the start token (later steps: fused into the sampler)
         return launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, st);
     }
+    // Every projection whose output is a small [B, N] f32 matrix is a split-K GEMM writing per-split slabs;
+    // the consumer (LayerNorm / attention / sampler) adds the slabs in order: deterministic, no atomics, and
+    // the residual add rides along in the pre-norm kernel.
+    auto slab_gemm = [&](const void* A, int lda, const Linear& L, float* out, long stride, int* nsl) -> int {
+        GemmArgs g;
+        gemm_lin(h, A, lda, L, B, g);
+        g.out_dtype = DIMX_F32;
+        g.out_slabs = 1;
+        g.slab_stride = stride;
+        gemm_set_plain_out(g, out, L.N);
+        *nsl = gemm_plan_splits(g);
+        g.force_splitk = *nsl;
+        return launch_gemm(g, st);
+    };
+    int pending = 0;  // slabs of the previous residual projection not yet folded into x
     for (int l = 0; l < h->d.dec_depth; ++l) {
         GemmArgs g;
         DecodeAttnArgs a;
-        DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.self_[l].ln_g, nullptr, B, DD, st));
-        gemm_lin(h, s.y, DD, h->dec.self_[l].qkv, B, g);
-        g.out_dtype = DIMX_F32;
-        g.accumulate = 1;
-        gemm_set_plain_out(g, s.qkv, 3 * inner);
-        DIMX_TRY(launch_gemm(g, st));
+        int ns = 0;
+        DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.self_[l].ln_g, B, DD, st));
+        DIMX_TRY(slab_gemm(s.y, DD, h->dec.self_[l].qkv, s.qkv, s0.st_qkv, &ns));
         memset(&a, 0, sizeof(a));
         a.dtype = h->at;
         a.q = s.qkv;
         a.q_ld = 3 * inner;
         a.q_f32 = 1;
+        a.nslab = ns;
+        a.slab_stride = s0.st_qkv;
         a.knew = s.qkv + inner;
         a.vnew = s.qkv + 2 * inner;
         a.kv_ld = 3 * inner;
@@ -1087,24 +1109,17 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         a.step = s.step;
         a.scale = scale;
         DIMX_TRY(launch_decode_attn(a, st));
-        gemm_lin(h, s.o, inner, h->dec.self_[l].out, B, g);
-        g.out_dtype = DIMX_F32;
-        g.residual = s.x;
-        g.ldr = DD;
-        gemm_set_plain_out(g, s.x, DD);
-        DIMX_TRY(launch_gemm(g, st));
+        DIMX_TRY(slab_gemm(s.o, inner, h->dec.self_[l].out, s.xr, s0.st_xr, &pending));
 
-        DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.cross[l].ln_g, nullptr, B, DD, st));
-        gemm_lin(h, s.y, DD, h->dec.cross[l].qkv, B, g);
-        g.out_dtype = DIMX_F32;
-        g.accumulate = 1;
-        gemm_set_plain_out(g, s.qc, inner);
-        DIMX_TRY(launch_gemm(g, st));
+        DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.cross[l].ln_g, B, DD, st));
+        DIMX_TRY(slab_gemm(s.y, DD, h->dec.cross[l].qkv, s.qc, s0.st_qc, &ns));
         memset(&a, 0, sizeof(a));
         a.dtype = h->at;
         a.q = s.qc;
         a.q_ld = inner;
         a.q_f32 = 1;
+        a.nslab = ns;
+        a.slab_stride = s0.st_qc;
         a.kcache = boff(cp.ck[l], (size_t)heads * Tp * 64 * es);
         a.vcache = boff(cp.cv[l], (size_t)heads * Tp * 64 * es);
         a.Tmax = Tp;
@@ -1117,36 +1132,21 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         a.kmask_ld = T;
         a.scale = scale;
         DIMX_TRY(launch_decode_attn(a, st));
-        gemm_lin(h, s.o, inner, h->dec.cross[l].out, B, g);
-        g.out_dtype = DIMX_F32;
-        g.residual = s.x;
-        g.ldr = DD;
-        gemm_set_plain_out(g, s.x, DD);
-        DIMX_TRY(launch_gemm(g, st));
+        DIMX_TRY(slab_gemm(s.o, inner, h->dec.cross[l].out, s.xr, s0.st_xr, &pending));
 
-        DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.ff[l].ln_g, nullptr, B, DD, st));
+        DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.ff[l].ln_g, B, DD, st));
         gemm_lin(h, s.y, DD, h->dec.ff[l].f1, B, g);
         g.out_dtype = h->at;
         g.act = ACT_GELU_ERF;
         gemm_set_plain_out(g, s.f, DD * h->d.ff_mult);
         DIMX_TRY(launch_gemm(g, st));
-        gemm_lin(h, s.f, DD * h->d.ff_mult, h->dec.ff[l].f2, B, g);
-        g.out_dtype = DIMX_F32;
-        g.residual = s.x;
-        g.ldr = DD;
-        gemm_set_plain_out(g, s.x, DD);
-        DIMX_TRY(launch_gemm(g, st));
+        DIMX_TRY(slab_gemm(s.f, DD * h->d.ff_mult, h->dec.ff[l].f2, s.xr, s0.st_xr, &pending));
     }
-    DIMX_TRY(launch_layernorm(h->at, s.x, s.y, h->dec.final_g, nullptr, B, DD, st));
-    GemmArgs g;
-    gemm_lin(h, s.y, DD, h->dec.logits, B, g);
-    g.out_dtype = DIMX_F32;
-    g.accumulate = 1;
-    gemm_set_plain_out(g, s.logits, V);
-    DIMX_TRY(launch_gemm(g, st));
-    if (logits_out) DIMX_TRY(launch_copy_rows_step(s.logits, logits_out, B, V, n, s.step, st));
-    DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, 1, row0, Btot,
-                           h->dec.tok_emb, DD, s.x, s.step, (unsigned*)(s.step + 8), st));
+    DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.final_g, B, DD, st));
+    int nlg = 0;
+    DIMX_TRY(slab_gemm(s.y, DD, h->dec.logits, s.logits, s0.st_lg, &nlg));
+    DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, nlg, s0.st_lg,
+                           logits_out, n, row0, Btot, h->dec.tok_emb, DD, s.x, s.step, (unsigned*)(s.step + 8), st));
     return DIMX_OK;
 }
 
@@ -1169,11 +1169,6 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "generate: workspace overflow");
     const int n = T - 1;
     DIMX_HIP(hipMemsetAsync(s.step, 0, 64 * dimx_ctx::kMaxGroups, st));
-    // split-K accumulators start at zero; every consumer zeroes what it has read
-    DIMX_HIP(hipMemsetAsync(s.qkv, 0, (size_t)B * 3 * h->d.heads * h->d.dim_head * 4, st));
-    DIMX_HIP(hipMemsetAsync(s.qc, 0, (size_t)B * h->d.heads * h->d.dim_head * 4, st));
-    DIMX_HIP(hipMemsetAsync(s.logits, 0, (size_t)B * h->d.num_tokens * 4, st));
-
     // Independent clip groups run as separate step graphs on separate streams: every decode kernel is
     // latency-bound at these sizes, so two groups in flight let one group's GEMM/LayerNorm chain overlap the
     // other group's HBM-bound attention.  Results do not depend on the grouping (per-clip state only; the
@@ -1263,7 +1258,8 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     g.ldr = ldr;
     g.allow_splitk = flags & 1;
     g.force_simple = (flags >> 1) & 1;
-    g.accumulate = (flags >> 2) & 1;       /* C is pre-zeroed: split-K partials are atomically added */
+    g.out_slabs = (flags >> 2) & 1;        /* C = [splits][M, ldc] f32 slabs (split count = flags bits 16..23) */
+    g.slab_stride = (long)M * ldc;
     g.cfg = (flags >> 8) & 0xff;           /* tuning: tile/stage config id */
     g.force_splitk = (flags >> 16) & 0xff; /* tuning: split count */
     if (conv_T > 0) {
@@ -1329,7 +1325,7 @@ int dimx_op_sample(const float* logits, int R, int top_k, float temperature, con
                    uint64_t step, int32_t* tokens, void* stream) {
     // exp_noise here is the [R,512] slice of this step (step only salts the on-device generator)
     return launch_sample(logits, 512, R, top_k, temperature, exp_noise, seed, nullptr, exp_noise ? 0 : step, tokens, 1,
-                         0, 0, 0, R, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
+                         0, 1, 0, nullptr, 0, 0, R, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

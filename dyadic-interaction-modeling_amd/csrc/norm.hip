@@ -58,6 +58,78 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Decode-step residual update fused with the following pre-norm:
+//   x[row] += slabs[0][row] + slabs[1][row] + ...   (split-K partial sums of the previous projection, added
+//   in slab order -> deterministic, no atomics), x is written back, y = LayerNorm(x) (gamma only, x-tf style).
+template <typename OutT, int C>
+__global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restrict__ x,
+                                                                  const float* __restrict__ slabs, int nslab,
+                                                                  long slab_stride, OutT* __restrict__ y,
+                                                                  const float* __restrict__ gamma, int M) {
+    constexpr int NV = C / 128;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float2* xr = (float2*)(x + (size_t)row * C);
+    const float2* g2 = (const float2*)gamma;
+    float2 v[NV], gv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[lane + 64 * i];
+        gv[i] = g2[lane + 64 * i];
+    }
+    for (int sidx = 0; sidx < nslab; ++sidx) {
+        const float2* sr = (const float2*)(slabs + (size_t)sidx * slab_stride + (size_t)row * C);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float2 p = sr[lane + 64 * i];
+            v[i].x += p.x;
+            v[i].y += p.y;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (nslab > 0) xr[lane + 64 * i] = v[i];
+        s += v[i].x + v[i].y;
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean;
+        q += a * a + b * b;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+    OutT* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c2 = lane + 64 * i;
+        const float o0 = (v[i].x - mean) * rstd * gv[i].x, o1 = (v[i].y - mean) * rstd * gv[i].y;
+        if (sizeof(OutT) == 2) {
+            *(uint32_t*)(yr + 2 * c2) = pack_bf16x2(o0, o1);
+        } else {
+            *(float2*)(yr + 2 * c2) = make_float2(o0, o1);
+        }
+    }
+}
+
+int launch_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
+                               const float* gamma, int M, int C, hipStream_t s) {
+    DIMX_REQUIRE(x && y && gamma && M > 0 && (nslab == 0 || slabs), DIMX_ERR_ARG, "add_slabs_layernorm: null operand");
+    DIMX_REQUIRE(C == 1152 || C == 384, DIMX_ERR_ARG, "add_slabs_layernorm: C=%d", C);
+    dim3 grid(ceil_div(M, 4)), block(256);
+#define ASL(OT, CC) hipLaunchKernelGGL((add_slabs_layernorm_kernel<OT, CC>), grid, block, 0, s, x, slabs, nslab, slab_stride, (OT*)y, gamma, M)
+    if (out_dtype == DIMX_BF16) {
+        if (C == 384) ASL(bf16, 384); else ASL(bf16, 1152);
+    } else {
+        if (C == 384) ASL(float, 384); else ASL(float, 1152);
+    }
+#undef ASL
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
 int launch_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta, int M, int C,
                      hipStream_t s) {
     DIMX_REQUIRE(x && y && gamma && M > 0, DIMX_ERR_ARG, "layernorm: null operand");

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
             const int tok = (t0 + t) < N ? (t0 + t) : N - 1;
             zr[t][0] = z[(size_t)tok * 128 + lane];
             zr[t][1] = z[(size_t)tok * 128 + 64 + lane];
-            zz[t] = wave_sum(zr[t][0] * zr[t][0] + zr[t][1] * zr[t][1]);
+            zz[t] = wave_sum(fmaf(zr[t][1], zr[t][1], zr[t][0] * zr[t][0]));  // explicit order: oracle/vq_argmin.c
         }
         float acc[TPW][8];
 #pragma unroll
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
             Best bst = {3.0e38f, 0x7fffffff, 3.0e38f};
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float d = (zz[t] + eev[c]) - 2.0f * acc[t][c];
+                const float d = fmaf(-2.0f, acc[t][c], zz[t] + eev[c]);  // = (zz + ee) - 2 dot, exactly
                 best_push(bst, d, lane + 64 * c);
             }
 #pragma unroll

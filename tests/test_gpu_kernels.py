@@ -57,22 +57,27 @@ def test_gemm(dev, M, N, K, act, use_bias, use_res, bf16):
     assert e < tol, "gemm err %g" % e
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 1152, 4608), (256, 1152, 768), (17, 1152, 4608), (64, 384, 1536)])
+@pytest.mark.parametrize("M,N,K,S", [(256, 1152, 4608, 4), (256, 1152, 768, 3), (17, 1152, 4608, 8), (64, 384, 1536, 2),
+                                     (256, 2304, 1152, 1)])
 @pytest.mark.parametrize("bf16", [False, True])
-def test_gemm_inplace_splitk_and_simple_kernel(dev, M, N, K, bf16):
-    """decode-step residual GEMM: split-K partial sums added atomically onto the residual, and the
-    register-staged kernel as a cross-check of the LDS-DMA pipeline."""
+def test_gemm_splitk_slabs_and_simple_kernel(dev, M, N, K, S, bf16):
+    """decode-step projections: split-K partial sums land in S f32 slabs that the consumer adds in order
+    (deterministic); plus the register-staged kernel as a cross-check of the LDS-DMA pipeline."""
     from dimx import engine
     g = torch.Generator().manual_seed(K + M)
     a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
-    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    bias = torch.randn(N, generator=g)
     aa, ww = (_bf(a), _bf(w)) if bf16 else (a, w)
-    ref = aa.double() @ ww.double().t() + bias.double() + res.double()
+    ref = aa.double() @ ww.double().t() + bias.double()
     tol = 2e-3 if bf16 else 1e-4
-    o1 = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), 0, res.to(dev), bf16=bf16, inplace_splitk=True)
-    o2 = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), 0, res.to(dev), bf16=bf16, force_simple=True)
-    o3 = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), 0, res.to(dev), bf16=bf16)
-    assert _err(o1, ref) < tol and _err(o2, ref) < tol and _err(o3, ref) < tol
+    sl = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), 0, None, bf16=bf16, slabs=S)
+    assert sl.shape == (S, M, N) and torch.isfinite(sl).all()
+    assert _err(sl.sum(0), ref) < tol
+    sl2 = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), 0, None, bf16=bf16, slabs=S)
+    assert torch.equal(sl, sl2), "split-K slabs must be bit-reproducible"
+    o2 = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), 0, None, bf16=bf16, force_simple=True)
+    o3 = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), 0, None, bf16=bf16)
+    assert _err(o2, ref) < tol and _err(o3, ref) < tol
     assert _err(o2, o3) < (1e-5 if not bf16 else 1e-4)   # same products, only the summation order differs
 
 
