@@ -231,8 +231,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     // the block that finishes last advances the device step counter (every block has read it by then)
     if (step_rw) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
+        if (threadIdx.x == 0) {  // no fence needed: only the READ of the step counter must precede the arrival
             const unsigned prev = atomicAdd(done_ctr, 1u);
             if (prev == gridDim.x - 1) {
                 *done_ctr = 0u;

@@ -60,6 +60,134 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + (((kc ^ (row >> 1)) & 7) << 4); }
 
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by both kernels.  PMC on the prefill shapes showed ~2200 VALU instructions per wave against
+// 48 MFMAs -- the epilogue, not the main loop, was the bottleneck -- so it is specialised:
+//   * ACT is a compile-time parameter (the caller switches once, outside the element loops);
+//   * FAST (bf16 perf mode): GELU through v_exp_f32 / v_rcp_f32 approximations (error far below bf16
+//     rounding); the f32 parity mode keeps tanhf / erff;
+//   * a plain row-major destination gets a dedicated path (one 64-bit base per column, 32-bit row offsets);
+//     the generic path handles head-major K/V caches, transposed V^T and per-row positional adds.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, bool FAST> __device__ __forceinline__ float act_fn(float x) {
+    if (ACT == ACT_LEAKY) return x > 0.f ? x : 0.2f * x;
+    if (ACT == ACT_GELU_TANH) {
+        const float u = 0.7978845608028654f * (x + 0.044715f * (x * x * x));
+        if (FAST) {  // tanh(u) = 1 - 2 / (1 + e^{2u})
+            const float e = __expf(2.0f * u);
+            const float t = 1.0f - 2.0f * __frcp_rn(1.0f + e);
+            return x * (0.5f * (1.0f + t));
+        }
+        return x * (0.5f * (1.0f + tanhf(u)));
+    }
+    if (ACT == ACT_GELU_ERF) {
+        if (FAST) {  // Abramowitz-Stegun 7.1.26, |error| < 1.5e-7
+            const float z = fabsf(x) * 0.7071067811865476f;
+            const float t = __frcp_rn(1.0f + 0.3275911f * z);
+            const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+            const float er = 1.0f - poly * __expf(-z * z);
+            return 0.5f * x * (1.0f + (x < 0.f ? -er : er));
+        }
+        return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+    }
+    return x;
+}
+
+template <typename OutT, int MI, int NI, int ACT, bool FAST>
+__device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w,
+                                              int half, int l31, int split) {
+    const bool first = split == 0;
+    const bool plain = a.nseg == 1 && a.seg[0].sd == 1 && a.seg[0].sh == 0 && a.seg[0].sb == a.seg[0].st * (long)a.rowT;
+    if (plain && a.rowadd_mode == 0) {
+        const int ldc = (int)a.seg[0].st;
+        OutT* C = (OutT*)a.seg[0].ptr + (a.out_slabs ? (size_t)split * a.slab_stride : 0);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0w + j * 32 + l31;
+            if (n >= a.N) continue;
+            const float bias_v = (a.bias && first) ? a.bias[n] : 0.f;
+            OutT* col = C + n;
+            const float* rcol = a.residual ? a.residual + n : nullptr;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int mb = m0w + i * 32 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m >= a.M) continue;
+                    float v = act_fn<ACT, FAST>(acc[i][j][r] + bias_v);
+                    if (rcol) v += rcol[(size_t)m * a.ldr];
+                    store_from_f32<OutT>(col + (size_t)m * ldc, v);
+                }
+            }
+        }
+        return;
+    }
+    const int rowT = a.rowT;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0w + j * 32 + l31;
+        if (n >= a.N) continue;
+        const float bias_v = (a.bias && first) ? a.bias[n] : 0.f;
+        int s = 0, nn = n;
+        if (a.nseg > 1) {
+            s = n / a.seg_width;
+            nn = n - s * a.seg_width;
+        }
+        const OutSeg sg = a.seg[s];
+        const int hh = nn / sg.D, dd = nn - hh * sg.D;
+        OutT* obase = (OutT*)sg.ptr + (long)hh * sg.sh + (long)dd * sg.sd;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mb = m0w + i * 32 + 4 * half;
+            int b0, t0;
+            if (rowT == 1) {
+                b0 = mb;
+                t0 = 0;
+            } else {
+                b0 = mb / rowT;
+                t0 = mb - b0 * rowT;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                const int m = mb + off;
+                if (m >= a.M) continue;
+                int b = b0, t = t0;
+                if (rowT == 1) {
+                    b = m;
+                } else {
+                    t += off;
+                    while (t >= rowT) {
+                        t -= rowT;
+                        ++b;
+                    }
+                }
+                float v = act_fn<ACT, FAST>(acc[i][j][r] + bias_v);
+                if (a.rowadd_mode) {
+                    const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b + a.rowadd_off : a.rowadd_off);
+                    v += a.rowadd[(size_t)ri * a.ld_rowadd + n] * a.rowadd_scale;
+                }
+                if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
+                store_from_f32<OutT>(obase + (long)b * sg.sb + (long)t * sg.st, v);
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT, int MI, int NI>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w, int half,
+                                         int l31, int split) {
+    constexpr bool FAST = sizeof(T) == 2;
+    switch (a.act) {
+        case ACT_LEAKY: epilogue_tile<OutT, MI, NI, ACT_LEAKY, FAST>(a, acc, m0w, n0w, half, l31, split); break;
+        case ACT_GELU_TANH: epilogue_tile<OutT, MI, NI, ACT_GELU_TANH, FAST>(a, acc, m0w, n0w, half, l31, split); break;
+        case ACT_GELU_ERF: epilogue_tile<OutT, MI, NI, ACT_GELU_ERF, FAST>(a, acc, m0w, n0w, half, l31, split); break;
+        default: epilogue_tile<OutT, MI, NI, ACT_NONE, FAST>(a, acc, m0w, n0w, half, l31, split); break;
+    }
+}
+
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs a) {
     constexpr int NT = WM * WN * 64;
@@ -181,56 +309,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs a) {
     }
 
     // ---- epilogue
-    const int rowT = a.rowT;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * NI * 32 + j * 32 + l31;
-        if (n >= a.N) continue;
-        const float bias_v = a.bias ? a.bias[n] : 0.f;
-        int s = 0, nn = n;
-        if (a.nseg > 1) {
-            s = n / a.seg_width;
-            nn = n - s * a.seg_width;
-        }
-        const OutSeg sg = a.seg[s];
-        const int hh = nn / sg.D, dd = nn - hh * sg.D;
-        OutT* obase = (OutT*)sg.ptr + (long)hh * sg.sh + (long)dd * sg.sd;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int mb = m0 + wm * MI * 32 + i * 32 + 4 * half;
-            int b0, t0;
-            if (rowT == 1) {
-                b0 = mb;
-                t0 = 0;
-            } else {
-                b0 = mb / rowT;
-                t0 = mb - b0 * rowT;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                const int m = mb + off;
-                if (m >= a.M) continue;
-                int b = b0, t = t0;
-                if (rowT == 1) {
-                    b = m;
-                } else {
-                    t += off;
-                    while (t >= rowT) {
-                        t -= rowT;
-                        ++b;
-                    }
-                }
-                float v = apply_act(acc[i][j][r] + bias_v, a.act);
-                if (a.rowadd_mode) {
-                    const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b + a.rowadd_off : a.rowadd_off);
-                    v += a.rowadd[(size_t)ri * a.ld_rowadd + n] * a.rowadd_scale;
-                }
-                if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
-                store_from_f32<OutT>(obase + (long)b * sg.sb + (long)t * sg.st, v);
-            }
-        }
-    }
+    epilogue<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, 0);
 }
 
 
@@ -392,7 +471,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
         // all fragment reads of a group of k-steps are issued back to back; the MFMAs of k-step s start as
         // soon as the reads of steps <= s have returned (LDS returns in order: counted lgkmcnt)
         constexpr int RPK = MI + NI;                      // ds_read_b128 per k-step
-        constexpr int GROUP = (4 * RPK <= 12) ? 4 : 2;    // k-steps per group (lgkmcnt is a 4-bit counter)
+        constexpr int GROUP = (4 * RPK <= 12) ? 4 : (2 * RPK <= 12 ? 2 : 1);  // k-steps per group (lgkmcnt: 4 bits)
 #pragma unroll
         for (int g0 = 0; g0 < 4; g0 += GROUP) {
             u32x4_t fa[GROUP][MI], fw[GROUP][NI];
@@ -401,8 +480,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
                 const unsigned pa = aoff[g0 + q] + boff, pw = woff[g0 + q] + boff;
                 ds_read128<0>(fa[q][0], pa);
                 if (MI > 1) ds_read128<4096>(fa[q][MI > 1 ? 1 : 0], pa);
+                if (MI > 2) ds_read128<8192>(fa[q][MI > 2 ? 2 : 0], pa);
+                if (MI > 3) ds_read128<12288>(fa[q][MI > 3 ? 3 : 0], pa);
                 ds_read128<0>(fw[q][0], pw);
                 if (NI > 1) ds_read128<4096>(fw[q][NI > 1 ? 1 : 0], pw);
+                if (NI > 2) ds_read128<8192>(fw[q][NI > 2 ? 2 : 0], pw);
+                if (NI > 3) ds_read128<12288>(fw[q][NI > 3 ? 3 : 0], pw);
             }
 #pragma unroll
             for (int q = 0; q < GROUP; ++q) {
@@ -416,64 +499,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
         }
     }
 
-    // ---- epilogue (same math as gemm_kernel; split-K partials are atomically added in place)
-    const int rowT = a.rowT;
-    const bool first = split == 0;
-    const bool slabs = a.out_slabs != 0;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * NI * 32 + j * 32 + l31;
-        if (n >= a.N) continue;
-        const float bias_v = (a.bias && first) ? a.bias[n] : 0.f;
-        int s = 0, nn = n;
-        if (a.nseg > 1) {
-            s = n / a.seg_width;
-            nn = n - s * a.seg_width;
-        }
-        const OutSeg sg = a.seg[s];
-        const int hh = nn / sg.D, dd = nn - hh * sg.D;
-        OutT* obase = (OutT*)sg.ptr + (long)hh * sg.sh + (long)dd * sg.sd;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int mb = m0 + wm * MI * 32 + i * 32 + 4 * half;
-            int b0, t0;
-            if (rowT == 1) {
-                b0 = mb;
-                t0 = 0;
-            } else {
-                b0 = mb / rowT;
-                t0 = mb - b0 * rowT;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                const int m = mb + off;
-                if (m >= a.M) continue;
-                int b = b0, t = t0;
-                if (rowT == 1) {
-                    b = m;
-                } else {
-                    t += off;
-                    while (t >= rowT) {
-                        t -= rowT;
-                        ++b;
-                    }
-                }
-                OutT* dst = obase + (long)b * sg.sb + (long)t * sg.st;
-                if (slabs) {  // f32 partial sum of this K split; the consumer adds the slabs in order
-                    ((float*)dst)[(long)split * a.slab_stride] = acc[i][j][r] + bias_v;
-                } else {
-                    float v = apply_act(acc[i][j][r] + bias_v, a.act);
-                    if (a.rowadd_mode) {
-                        const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b + a.rowadd_off : a.rowadd_off);
-                        v += a.rowadd[(size_t)ri * a.ld_rowadd + n] * a.rowadd_scale;
-                    }
-                    if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
-                    store_from_f32<OutT>(dst, v);
-                }
-            }
-        }
-    }
+    // ---- epilogue (split-K: this split's partial sums go to its own f32 slab)
+    epilogue<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, split);
 }
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
@@ -518,6 +545,9 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 14: return launch_glds<T, OutT, 128, 128, 4, 2, 2>(a, s);  // 8 waves
         case 15: return launch_glds<T, OutT, 128, 128, 4, 2, 3>(a, s);  // 8 waves
         case 16: return launch_glds<T, OutT, 256, 64, 8, 1, 2>(a, s);   // 8 waves, whole-M column tile
+        case 17: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 144 KB ring
+        case 18: return launch_glds<T, OutT, 256, 128, 4, 2, 2>(a, s);  // 8 waves, 96 KB ring
+        case 19: return launch_glds<T, OutT, 256, 256, 4, 2, 2>(a, s);  // 8 waves, 128 KB ring
         case 20: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 1>(a, s);  // ablation: DMA only
         case 21: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 2>(a, s);  // ablation: compute only
         default: break;
@@ -531,6 +561,8 @@ static inline void cfg_tile(int cfg, int& bm, int& bn) {
         case 1: case 2: case 11: case 14: case 15: bm = 128; bn = 128; break;
         case 6: case 7: case 12: case 13: bm = 128; bn = 64; break;
         case 16: bm = 256; bn = 64; break;
+        case 17: case 18: bm = 256; bn = 128; break;
+        case 19: bm = 256; bn = 256; break;
         case 8: bm = 64; bn = 128; break;
         default: bm = 64; bn = 64; break;
     }
@@ -548,7 +580,7 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
         return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
     }
     int cfg = a.cfg;
-    if (cfg == 0) cfg = tiles128 >= 512 ? 7 : 4;  // measured on MI355X (tools/bench_gemm.py): 128x64x2 for large M, 64x64x3 for decode
+    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : 4;  // measured on MI355X (tools/bench_gemm.py): 128x128 8-wave for large M, 64x64x3 for decode
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;
@@ -563,7 +595,7 @@ int gemm_plan_splits(const GemmArgs& a) {
     const int bk = a.in_dtype == DIMX_BF16 ? 64 : 32;
     if (a.conv_T != 0 || a.K % bk != 0 || a.K != a.ldw || a.force_simple) return 1;  // register-staged kernel: no split
     int cfg = a.cfg, bm, bn;
-    if (cfg == 0) cfg = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) >= 512 ? 7 : 4;
+    if (cfg == 0) cfg = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) >= 512 ? 14 : 4;
     cfg_tile(cfg, bm, bn);
     const int tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
     if (tiles >= 256) return 1;
