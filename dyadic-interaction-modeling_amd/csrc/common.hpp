@@ -199,6 +199,7 @@ struct DecodeAttnArgs {
     int q_f32;             // q / knew / vnew are f32 split-K slabs [nslab][B, ld]: summed in slab order on load
     int nslab;
     long slab_stride;      // elements between slabs
+    int force_nsplit;      // tests: waves per (clip, head) (0 = automatic)
     const void* knew;      // self-attn: this step's k/v rows [B, *] (nullptr for cross attention)
     const void* vnew;
     int kv_ld;

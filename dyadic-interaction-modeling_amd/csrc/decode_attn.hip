@@ -53,11 +53,6 @@ template <> __device__ __forceinline__ void cvt_chunk<bf16, 8>(const uint4& u, f
     }
 }
 
-// SELF = true: self-attention form (append this step's k/v, keys = step counter + 1);
-// SELF = false: cross-attention form (fixed n_keys, optional key mask).  Two instantiations so that the two
-// launch shapes show up as separate rows of a rocprofv3 kernel trace.
-// The kernel is a latency-bound HBM stream: every wave keeps 2 x U independent 16-byte loads per lane in
-// flight (the next batch of U key groups is issued before the current one is consumed).
 template <int EPC> __device__ __forceinline__ void load_f32_chunk(const float* p, float (&v)[EPC]) {
 #pragma unroll
     for (int i = 0; i < EPC / 4; ++i) {
@@ -76,19 +71,31 @@ template <int EPC> __device__ __forceinline__ void load_f32_slabs(const float* p
     }
 }
 
+// SELF = true: self-attention form (append this step's k/v, keys = step counter + 1);
+// SELF = false: cross-attention form (fixed n_keys, optional key mask).  Two instantiations so that the two
+// launch shapes show up as separate rows of a rocprofv3 kernel trace.
 // QF32: q (and knew/vnew) are f32 split-K slabs [nslab][B, ld] written by the projection GEMM; they are
 // summed here in slab order.
-template <typename T, bool SELF, bool QF32>
+// NSPLIT (1, 2 or 4): waves per (clip, head).  Small batches / long contexts (BASELINE C5: 64 clips x 1500
+// keys per GPU) do not have B*H >= CUs * waves to saturate HBM, so the keys of one (clip, head) are split
+// over NSPLIT waves of the block and the partial (max, sum, acc) are combined through LDS in a fixed order.
+// The kernel is a latency-bound HBM stream: every wave keeps 2 x U independent 16-byte loads per lane in
+// flight (the next batch of U key groups is issued before the current one is consumed).
+template <typename T, bool SELF, bool QF32, int NSPLIT>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int LPK = 64 / EPC;   // lanes per key: 8 (bf16) / 16 (f32)
     constexpr int KPI = 64 / LPK;   // keys per wave-wide load: 8 / 4
     constexpr int U = 4;            // key groups per batch (8 measured no faster on MI355X)
     constexpr int KB = U * KPI;     // keys per batch
-    __shared__ float sc[4][kMaxKeys];
+    constexpr int PPB = 4 / NSPLIT; // (clip, head) pairs per block
+    __shared__ float sc[PPB][kMaxKeys];
+    __shared__ float red_m[4], red_l[4];
+    __shared__ float red_acc[4][64];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * 4 + wave;
+    const int pib = wave / NSPLIT, part = wave % NSPLIT;
+    const int pair = blockIdx.x * PPB + pib;
     const bool active = pair < a.B * a.H;
     const int b = active ? pair / a.H : 0, h = active ? pair % a.H : 0;
     const int sub = lane / LPK, ch = lane % LPK;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 
     const T* kc = (const T*)a.kcache + ((size_t)(b * a.H + h) * a.Tmax) * 64 + ch * EPC;
     const T* vc = (const T*)a.vcache + ((size_t)(b * a.H + h) * a.Tmax) * 64 + ch * EPC;
-    float* s = sc[wave];
+    float* s = sc[pib];
     const bool masked = !SELF && a.kmask != nullptr;
 
     auto load_batch = [&](const T* base, int j0, uint4 (&r)[U]) {
@@ -108,12 +115,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
             r[u] = *(const uint4*)(base + (size_t)(j < n ? j : (n > 0 ? n - 1 : 0)) * 64);
         }
     };
+    const int jfirst = part * KB, jstep = NSPLIT * KB;  // this wave's key batches: jfirst, jfirst + jstep, ...
 
     uint4 cur[U], nxt[U];
-    if (n > 0) load_batch(kc, 0, cur);
+    if (jfirst < n) load_batch(kc, jfirst, cur);
     // key mask -> additive bias in LDS (cross-attention): coalesced byte loads, once per launch
     if (masked) {
-        for (int j = lane; j < n; j += 64) s[j] = a.kmask[(size_t)b * a.kmask_ld + j] ? 0.f : kNegD;
+        for (int j = part * 64 + lane; j < n; j += NSPLIT * 64) s[j] = a.kmask[(size_t)b * a.kmask_ld + j] ? 0.f : kNegD;
     }
     float qv[EPC];
     if (QF32)
@@ -124,8 +132,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 
     // ---- phase 1: scores
     float mx = kNegD;
-    for (int j0 = 0; j0 < n; j0 += KB) {
-        if (j0 + KB < n) load_batch(kc, j0 + KB, nxt);
+    for (int j0 = jfirst; j0 < n; j0 += jstep) {
+        if (j0 + jstep < n) load_batch(kc, j0 + jstep, nxt);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * KPI + sub;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
     // first V batch goes out before the softmax pass
-    if (n > 0) load_batch(vc, 0, cur);
+    if (jfirst < n) load_batch(vc, jfirst, cur);
     float knv[EPC], vnv[EPC];
     int total = n;
     if (SELF) {
@@ -164,33 +172,50 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 #pragma unroll
         for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o);
         const float sv = d * scale2;
-        if (lane == 0) s[n] = sv;
-        mx = fmaxf(mx, sv);
         total = n + 1;
-        if (active && sub == 0) {  // append to the cache for the following steps
-            store_chunk<T, EPC>((T*)a.kcache + ((size_t)(b * a.H + h) * a.Tmax + n) * 64 + ch * EPC, knv);
-            store_chunk<T, EPC>((T*)a.vcache + ((size_t)(b * a.H + h) * a.Tmax + n) * 64 + ch * EPC, vnv);
+        if (part == 0) {  // the new key belongs to the first wave of the pair
+            if (lane == 0) s[n] = sv;
+            mx = fmaxf(mx, sv);
+            if (active && sub == 0) {  // append to the cache for the following steps
+                store_chunk<T, EPC>((T*)a.kcache + ((size_t)(b * a.H + h) * a.Tmax + n) * 64 + ch * EPC, knv);
+                store_chunk<T, EPC>((T*)a.vcache + ((size_t)(b * a.H + h) * a.Tmax + n) * 64 + ch * EPC, vnv);
+            }
         }
     }
     mx = wave_max(mx);
+    if (NSPLIT > 1) {
+        if (lane == 0) red_m[wave] = mx;
+    }
     __syncthreads();
+    if (NSPLIT > 1) {
+#pragma unroll
+        for (int p = 0; p < NSPLIT; ++p) mx = fmaxf(mx, red_m[pib * NSPLIT + p]);
+    }
 
-    // ---- phase 2: probabilities (unnormalised) + row sum
+    // ---- phase 2: probabilities (unnormalised) + row sum (each wave handles a slice of the pair's keys)
     float lsum = 0.f;
-    for (int j = lane; j < total; j += 64) {
+    for (int j = part * 64 + lane; j < total; j += NSPLIT * 64) {
         const float p = exp2f(s[j] - mx);
         s[j] = p;
         lsum += p;
     }
     lsum = wave_sum(lsum);
+    if (NSPLIT > 1) {
+        if (lane == 0) red_l[wave] = lsum;
+    }
     __syncthreads();
+    if (NSPLIT > 1) {
+        lsum = 0.f;
+#pragma unroll
+        for (int p = 0; p < NSPLIT; ++p) lsum += red_l[pib * NSPLIT + p];
+    }
 
     // ---- phase 3: o = sum_j p_j v_j
     float acc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-    for (int j0 = 0; j0 < n; j0 += KB) {
-        if (j0 + KB < n) load_batch(vc, j0 + KB, nxt);
+    for (int j0 = jfirst; j0 < n; j0 += jstep) {
+        if (j0 + jstep < n) load_batch(vc, j0 + jstep, nxt);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * KPI + sub;
@@ -203,7 +228,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
-    if (SELF && sub == 0) {
+    if (SELF && part == 0 && sub == 0) {
         const float p = s[n];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = fmaf(p, vnv[e], acc[e]);
@@ -212,7 +237,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     for (int o = LPK; o < 64; o <<= 1)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] += __shfl_xor(acc[e], o);
-    if (active && sub == 0) {
+    if (NSPLIT > 1) {  // combine the partial outputs of the pair's waves in wave order
+        if (sub == 0) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) red_acc[wave][ch * EPC + e] = acc[e];
+        }
+        __syncthreads();
+        if (part == 0 && sub == 0) {
+#pragma unroll
+            for (int p = 1; p < NSPLIT; ++p)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += red_acc[pib * NSPLIT + p][ch * EPC + e];
+        }
+    }
+    if (active && part == 0 && sub == 0) {
         const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] *= inv;
@@ -227,16 +265,29 @@ int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s) {
     DIMX_REQUIRE((a.knew == nullptr) == (a.vnew == nullptr), DIMX_ERR_ARG, "decode_attn: knew/vnew mismatch");
     DIMX_REQUIRE(a.knew == nullptr || a.step != nullptr, DIMX_ERR_ARG, "decode_attn: self attention needs a step counter");
     DIMX_REQUIRE(a.Tmax <= kMaxKeys && a.n_keys <= kMaxKeys, DIMX_ERR_ARG, "decode_attn: more than %d keys", kMaxKeys);
-    dim3 grid(ceil_div(a.B * a.H, 4)), block(256);
+    // waves per (clip, head): enough waves to cover the chip (~12 per CU) without splitting large batches
+    const int pairs = a.B * a.H;
+    int nsplit = 1;
+    if (pairs * 2 <= 3072) nsplit = 2;
+    if (pairs * 4 <= 3072) nsplit = 4;
+    if (a.force_nsplit == 1 || a.force_nsplit == 2 || a.force_nsplit == 4) nsplit = a.force_nsplit;
+    dim3 grid(ceil_div(pairs, 4 / nsplit)), block(256);
     const bool self = a.knew != nullptr;
-#define DA_LAUNCH(TT, SS, QQ) hipLaunchKernelGGL((decode_attn_kernel<TT, SS, QQ>), grid, block, 0, s, a)
+#define DA_LAUNCH(TT, SS, QQ, NS) hipLaunchKernelGGL((decode_attn_kernel<TT, SS, QQ, NS>), grid, block, 0, s, a)
+#define DA_NS(TT, SS, QQ)                          \
+    do {                                           \
+        if (nsplit == 4) DA_LAUNCH(TT, SS, QQ, 4); \
+        else if (nsplit == 2) DA_LAUNCH(TT, SS, QQ, 2); \
+        else DA_LAUNCH(TT, SS, QQ, 1);             \
+    } while (0)
     if (a.dtype == DIMX_BF16) {
-        if (a.q_f32) { if (self) DA_LAUNCH(bf16, true, true); else DA_LAUNCH(bf16, false, true); }
-        else { if (self) DA_LAUNCH(bf16, true, false); else DA_LAUNCH(bf16, false, false); }
+        if (a.q_f32) { if (self) DA_NS(bf16, true, true); else DA_NS(bf16, false, true); }
+        else { if (self) DA_NS(bf16, true, false); else DA_NS(bf16, false, false); }
     } else {
-        if (a.q_f32) { if (self) DA_LAUNCH(float, true, true); else DA_LAUNCH(float, false, true); }
-        else { if (self) DA_LAUNCH(float, true, false); else DA_LAUNCH(float, false, false); }
+        if (a.q_f32) { if (self) DA_NS(float, true, true); else DA_NS(float, false, true); }
+        else { if (self) DA_NS(float, true, false); else DA_NS(float, false, false); }
     }
+#undef DA_NS
 #undef DA_LAUNCH
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;

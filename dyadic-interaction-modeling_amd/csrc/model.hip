@@ -1301,7 +1301,7 @@ int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, v
 }
 
 int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void* vcache, void* out, int B, int H,
-                        int Tmax, int n_keys, float scale, const uint8_t* kmask, void* stream) {
+                        int Tmax, int n_keys, float scale, const uint8_t* kmask, int nsplit, void* stream) {
     DecodeAttnArgs a;
     memset(&a, 0, sizeof(a));
     a.dtype = dtype;
@@ -1318,6 +1318,7 @@ int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void
     a.kmask = kmask;
     a.kmask_ld = n_keys;
     a.scale = scale;
+    a.force_nsplit = nsplit;
     return launch_decode_attn(a, (hipStream_t)stream);
 }
 

@@ -241,13 +241,13 @@ def op_sample(logits, top_k=52, temperature=1.0, noise=None, seed=0, step=0):
     return tok
 
 
-def op_decode_attn(q, kcache, vcache, n_keys, scale, kmask=None):
+def op_decode_attn(q, kcache, vcache, n_keys, scale, kmask=None, nsplit=0):
     """q [B,H*64]; kcache/vcache [B,H,Tmax,64] (f32 or bf16) -> [B,H*64]."""
     lib = L.load()
     B, H, Tmax, _ = kcache.shape
     bf = kcache.dtype == torch.bfloat16
     out = torch.empty_like(q)
     L.check(lib.dimx_op_decode_attn(L.BF16 if bf else L.F32, L.ptr(q), L.ptr(kcache), L.ptr(vcache), L.ptr(out), B, H,
-                                    Tmax, n_keys, float(scale), L.ptr(kmask), L.stream_ptr(q.device)),
+                                    Tmax, n_keys, float(scale), L.ptr(kmask), nsplit, L.stream_ptr(q.device)),
             "dimx_op_decode_attn")
     return out

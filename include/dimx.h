@@ -154,9 +154,10 @@ int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, v
                       int Lq, int Lk, int D, int ldq, int ldk, int ld_vt, int ldo, float scale,
                       int causal, const int32_t* lens, const uint8_t* kmask, void* stream);
 /* One-query (autoregressive step) attention over a [B,H,Tmax,64] K/V cache, n_keys keys per (clip,head);
- * q/out are [B,H*64].  kmask optional [B,n_keys].  Cross-attention form (no cache append). */
+ * q/out are [B,H*64].  kmask optional [B,n_keys].  Cross-attention form (no cache append).
+ * nsplit: waves per (clip, head) sharing the keys (1, 2, 4; 0 = automatic). */
 int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void* vcache, void* out, int B, int H,
-                        int Tmax, int n_keys, float scale, const uint8_t* kmask, void* stream);
+                        int Tmax, int n_keys, float scale, const uint8_t* kmask, int nsplit, void* stream);
 /* tokens = sampler(logits[R,512]) -- see dimx_generate. */
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise,
                    uint64_t seed, uint64_t step, int32_t* tokens, void* stream);

@@ -112,3 +112,33 @@ def test_c3_bf16_perf_mode(clips, full_f32):
     err = (lb - lf).abs()[valid].max().item()
     print("C3 bf16 vs f32: VQ index agreement %.4f, argmax agreement %.4f, max logit err %.4f" % (agree_idx, agree, err))
     assert agree_idx > 0.95 and agree > 0.97
+
+
+def test_c5_long_context_t1500(model_f32):
+    """BASELINE config C5's sequence length (T=1500 > one LDS K/V tile, decode cache of 1500 keys): the
+    KV-cached generation must reproduce the teacher-forced logits over its own output, and the VQ round trip
+    at T=1500 stays on the reference golden (tests/test_gpu_vq.py::test_encode_indices_bit_exact[1500])."""
+    from dimx import prng
+    dev = torch.device("cuda:0")
+    Bc, Tc = 2, 1500
+    v_s = torch.from_numpy(prng.normal(41, "c5.vs", (Bc, Tc, 56))).to(dev)
+    v_l = torch.from_numpy(prng.normal(41, "c5.vl", (Bc, Tc, 56))).to(dev)
+    v_a = torch.from_numpy(prng.normal(41, "c5.va", (Bc, Tc, 768))).to(dev)
+    mask = torch.ones(Bc, Tc, dtype=torch.bool, device=dev)
+    mask[1, 1203:] = False
+    eng = model_f32.engine(dev)
+    m8 = mask.to(torch.uint8).contiguous()
+    _, z_l = model_f32.forward_vq(v_s, v_l, mask, with_speaker=False)
+    assert (z_l[1, 1203:] == -100).all() and int(z_l[0].min()) >= 0
+    eng.encode_ctx(v_s, v_a, m8, True)
+    g_tok, g_logits = eng.generate(z_l[:, 0].contiguous(), m8, Tc, 0.0, 52, None, 0, return_logits=True)
+    seq = torch.cat([z_l[:, :1].to(torch.int32), g_tok], 1).contiguous()
+    eng.encode_ctx(v_s, v_a, m8, False)
+    tf_logits, _, tf_arg = eng.decode_tf(seq, m8, None)
+    assert torch.isfinite(g_logits).all()
+    assert (tf_logits - g_logits).abs().max() < 5e-3
+    top2 = tf_logits.topk(2, -1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-2
+    assert torch.equal(tf_arg[safe], g_tok[safe])
+    pred = eng.vq_decode(1, g_tok)
+    assert pred.shape == (Bc, Tc - 1, 56) and torch.isfinite(pred).all()

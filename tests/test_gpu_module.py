@@ -107,7 +107,8 @@ def test_decode_attention_kernel(model):
     s = torch.einsum("bhd,bhjd->bhj", q.view(B, H, 64).double(), k[:, :, :T].double()) * 0.125
     s = s.masked_fill(km[:, None, :] == 0, -1e300)
     ref = torch.einsum("bhj,bhjd->bhd", s.softmax(-1), v[:, :, :T].double()).reshape(B, H * 64)
-    out = engine.op_decode_attn(q.cuda(), k.cuda(), v.cuda(), T, 0.125, km.cuda())
-    assert (out.cpu().double() - ref).abs().max() < 2e-5
+    for ns in (0, 1, 2, 4):   # waves per (clip, head): the split-KV combine must not change the result
+        out = engine.op_decode_attn(q.cuda(), k.cuda(), v.cuda(), T, 0.125, km.cuda(), nsplit=ns)
+        assert (out.cpu().double() - ref).abs().max() < 2e-5, ns
     outb = engine.op_decode_attn(q.cuda().bfloat16(), k.cuda().bfloat16(), v.cuda().bfloat16(), T, 0.125, km.cuda())
     assert (outb.float().cpu().double() - ref).abs().max() < 5e-2
