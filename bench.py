@@ -139,6 +139,10 @@ def main():
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, device if world > 1 else None)
     assert gathered.shape == (world * B, T - 1) and torch.isfinite(pred).all()
 
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
     if rank != 0:
         return
     ms = elapsed / args.steps * 1e3
@@ -155,7 +159,7 @@ def main():
                    "code indices)" % world},
         "achieved_tflops_necessary_work": clips_s * GFLOP_PER_CLIP_T300 * (T / 300.0) / 1e3,
     }
-    if not args.no_roofline:
+    if world == 1 and not args.no_roofline:   # single-GPU runs only (the other ranks have left by now)
         from dimx import roofline
         out["roofline"] = roofline.dominant_kernel(eng, B, T, args.mode)
     if world == 1 and not args.no_cpu_baseline:

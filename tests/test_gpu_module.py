@@ -112,3 +112,37 @@ def test_decode_attention_kernel(model):
         assert (out.cpu().double() - ref).abs().max() < 2e-5, ns
     outb = engine.op_decode_attn(q.cuda().bfloat16(), k.cuda().bfloat16(), v.cuda().bfloat16(), T, 0.125, km.cuda())
     assert (outb.float().cpu().double() - ref).abs().max() < 5e-2
+
+
+def test_rccl_single_rank_allgather_path():
+    """The N > 1 collective path on the real backend: a 1-rank "nccl" (= RCCL) process group exercises
+    init_from_env / all_gather_rows / max_over_ranks / barrier exactly as bench.py --gpus N does per rank."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from dimx import dist as dd
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        t = torch.arange(12, dtype=torch.int32, device="cuda:0").view(4, 3)
+        out = torch.empty_like(t)
+        dist.all_gather_into_tensor(out, t)
+        assert torch.equal(out, t)
+        x = torch.tensor([3.5], dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        assert float(x) == 3.5
+        dist.barrier()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
