@@ -162,6 +162,7 @@ def main():
     if world == 1 and not args.no_roofline:   # single-GPU runs only (the other ranks have left by now)
         from dimx import roofline
         out["roofline"] = roofline.dominant_kernel(eng, B, T, args.mode)
+        out["cross_attn_mfma"] = roofline.cross_kv_gemm(B, T, args.mode, device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T)
     print(json.dumps(out))

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     constexpr int LPT = LA + LW;
     constexpr int TILE_BYTES = (BM + BN) * 128;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
-    static_assert((STAGES - 1) * LPT < 64, "vmcnt range");
+    static_assert(STAGES >= 1 && (STAGES - 1) * LPT < 64, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -459,13 +459,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
         if (s < nk && (ABL != 2 || s == 0)) issue(s, s);
 
     for (int it = 0; it < nk; ++it) {
-        // tile `it` has landed once at most min(STAGES-2, nk-1-it) younger tiles are still in flight
-        if (ABL == 2 || nk - 1 - it < STAGES - 2)
+        if (STAGES == 1) {
+            // single LDS buffer: latency is hidden by the other resident blocks (up to 5 per CU), not by a ring
+            if (it > 0) __builtin_amdgcn_s_barrier();  // everyone is done reading the previous tile
+            issue(it, 0);
             wait_vmcnt<0>();
-        else
-            wait_vmcnt<(STAGES - 2) * LPT>();
-        __builtin_amdgcn_s_barrier();
-        if (ABL != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+            __builtin_amdgcn_s_barrier();
+        } else {
+            // tile `it` has landed once at most min(STAGES-2, nk-1-it) younger tiles are still in flight
+            if (ABL == 2 || nk - 1 - it < STAGES - 2)
+                wait_vmcnt<0>();
+            else
+                wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LPT>();
+            __builtin_amdgcn_s_barrier();
+            if (ABL != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        }
         if (ABL == 1) continue;
         const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
         // all fragment reads of a group of k-steps are issued back to back; the MFMAs of k-step s start as
@@ -548,6 +556,13 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 17: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 144 KB ring
         case 18: return launch_glds<T, OutT, 256, 128, 4, 2, 2>(a, s);  // 8 waves, 96 KB ring
         case 19: return launch_glds<T, OutT, 256, 256, 4, 2, 2>(a, s);  // 8 waves, 128 KB ring
+        case 22: return launch_glds<T, OutT, 128, 128, 2, 2, 1>(a, s);  // single buffer, 32 KB: up to 5 blocks/CU
+        case 23: return launch_glds<T, OutT, 128, 128, 4, 2, 1>(a, s);  // 8 waves, single buffer
+        case 24: return launch_glds<T, OutT, 128, 64, 2, 2, 1>(a, s);   // single buffer, 24 KB
+        case 27: return launch_glds<T, OutT, 256, 128, 4, 2, 1>(a, s);  // 8 waves, single 48 KB buffer: 3 blocks/CU
+        case 28: return launch_glds<T, OutT, 256, 256, 4, 2, 1>(a, s);  // 8 waves, single 64 KB buffer: 2 blocks/CU
+        case 25: return launch_glds<T, OutT, 128, 128, 4, 2, 2, 1>(a, s);  // ablation of cfg 14: DMA only
+        case 26: return launch_glds<T, OutT, 128, 128, 4, 2, 2, 2>(a, s);  // ablation of cfg 14: compute only
         case 20: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 1>(a, s);  // ablation: DMA only
         case 21: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 2>(a, s);  // ablation: compute only
         default: break;
@@ -558,11 +573,11 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
 
 static inline void cfg_tile(int cfg, int& bm, int& bn) {
     switch (cfg) {
-        case 1: case 2: case 11: case 14: case 15: bm = 128; bn = 128; break;
-        case 6: case 7: case 12: case 13: bm = 128; bn = 64; break;
+        case 1: case 2: case 11: case 14: case 15: case 22: case 23: case 25: case 26: bm = 128; bn = 128; break;
+        case 6: case 7: case 12: case 13: case 24: bm = 128; bn = 64; break;
         case 16: bm = 256; bn = 64; break;
-        case 17: case 18: bm = 256; bn = 128; break;
-        case 19: bm = 256; bn = 256; break;
+        case 17: case 18: case 27: bm = 256; bn = 128; break;
+        case 19: case 28: bm = 256; bn = 256; break;
         case 8: bm = 64; bn = 128; break;
         default: bm = 64; bn = 64; break;
     }

@@ -82,6 +82,30 @@ def decode_gemm(B, mode, device, iters=40):
             "algorithmic_flops_per_launch": flops, "avg_launch_us": sec * 1e6}
 
 
+def cross_kv_gemm(B, T, mode, device, iters=12):
+    """The MFMA GEMM of the cross-attention bundle: K/V projection of the speaker context for one decoder
+    layer, [B*T, 1152] x [1536, 1152]^T (SURVEY.md section 8d "cross-attention GEMM").  BASELINE.json's
+    'cross-attn MFMA util %' is quoted on it: achieved TFLOP/s / dense MFMA peak of the operand type."""
+    from . import lib as L
+    lib = L.load()
+    M, N, K = B * T, 1536, 1152
+    bf = mode == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    a = torch.randn(M, K, device=device).to(dt)
+    w = [(torch.randn(N, K, device=device) / 34.0).to(dt) for _ in range(2)]
+    out = torch.empty(M, N, device=device, dtype=dt)
+
+    def run(i):
+        L.check(lib.dimx_op_gemm(L.BF16 if bf else L.F32, L.BF16 if bf else L.F32, L.ptr(a), K, L.ptr(w[i % 2]), K,
+                                 L.ptr(out), N, M, N, K, None, 0, None, 0, 0, None, 0, L.stream_ptr(device)), "gemm")
+    sec = _time_launches(run, 3, iters)
+    flops = 2.0 * M * N * K
+    tf = flops / sec / 1e12
+    peak = MFMA_PEAK_TFLOPS[mode]
+    return {"kernel": "gemm_glds_kernel (cross-attention K/V projection) M=%d N=%d K=%d" % (M, N, K), "bound": "mfma",
+            "achieved": tf, "peak": peak, "unit": "TFLOP/s", "util_pct": 100.0 * tf / peak, "avg_launch_us": sec * 1e6}
+
+
 def dominant_kernel(eng, B, T, mode):
     """Roofline object for bench.py: the kernel with the largest share of the decode loop, with the other
     candidate attached under 'secondary'."""
