@@ -1301,7 +1301,8 @@ int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, v
 }
 
 int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void* vcache, void* out, int B, int H,
-                        int Tmax, int n_keys, float scale, const uint8_t* kmask, int nsplit, void* stream) {
+                        int Tmax, int n_keys, float scale, const uint8_t* kmask, int nsplit, int q_is_f32,
+                        void* stream) {
     DecodeAttnArgs a;
     memset(&a, 0, sizeof(a));
     a.dtype = dtype;
@@ -1319,6 +1320,8 @@ int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void
     a.kmask_ld = n_keys;
     a.scale = scale;
     a.force_nsplit = nsplit;
+    a.q_f32 = q_is_f32 ? 1 : 0;
+    a.nslab = 1;
     return launch_decode_attn(a, (hipStream_t)stream);
 }
 

@@ -246,8 +246,10 @@ def op_decode_attn(q, kcache, vcache, n_keys, scale, kmask=None, nsplit=0):
     lib = L.load()
     B, H, Tmax, _ = kcache.shape
     bf = kcache.dtype == torch.bfloat16
-    out = torch.empty_like(q)
+    q_f32 = q.dtype == torch.float32 and bf      # f32 projection slab feeding a bf16 cache (generate's form)
+    out = torch.empty(q.shape, dtype=kcache.dtype, device=q.device)
     L.check(lib.dimx_op_decode_attn(L.BF16 if bf else L.F32, L.ptr(q), L.ptr(kcache), L.ptr(vcache), L.ptr(out), B, H,
-                                    Tmax, n_keys, float(scale), L.ptr(kmask), nsplit, L.stream_ptr(q.device)),
+                                    Tmax, n_keys, float(scale), L.ptr(kmask), nsplit, 1 if q_f32 else 0,
+                                    L.stream_ptr(q.device)),
             "dimx_op_decode_attn")
     return out

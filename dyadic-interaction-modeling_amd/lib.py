@@ -65,7 +65,7 @@ SIGNATURES = {
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                                   c_void_p]),
     "dimx_op_decode_attn": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                    c_float, c_void_p, c_int, c_void_p]),
+                                    c_float, c_void_p, c_int, c_int, c_void_p]),
     "dimx_op_sample": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p,
                                c_void_p]),
 }

@@ -41,7 +41,7 @@ def decode_attention(B, T, mode, device, iters=40):
     layers = 4
     kc = [torch.randn(B, H, Tp, 64, device=device).to(dt) for _ in range(layers)]
     vc = [torch.randn(B, H, Tp, 64, device=device).to(dt) for _ in range(layers)]
-    q = torch.randn(B, H * 64, device=device).to(dt)
+    q = torch.randn(B, H * 64, device=device)   # f32 projection slab, exactly what dimx_generate hands the kernel
     km = torch.ones(B, T, dtype=torch.uint8, device=device)   # the context mask dimx_generate passes
     sec = _time_launches(lambda i: E.op_decode_attn(q, kc[i % layers], vc[i % layers], T, 0.125, km), 8, iters)
     alg_bytes = B * H * T * 64 * 2 * es + 2 * B * H * 64 * es
@@ -51,7 +51,7 @@ def decode_attention(B, T, mode, device, iters=40):
     traffic = None
     if (B, T, mode) == (256, 300, "bf16"):
         traffic = (2 * 115430.8 + 384.0) * 1024
-    return {"kernel": "decode_attn_kernel<%s, false> (cross-attention form, %d keys)" % ("dimx::bf16" if mode == "bf16" else "float", T), "bound": "hbm",
+    return {"kernel": "decode_attn_kernel<%s, false, true, 1> (cross-attention form, %d keys)" % ("dimx::bf16" if mode == "bf16" else "float", T), "bound": "hbm",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sec * 1e6}
 

@@ -155,9 +155,11 @@ int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, v
                       int causal, const int32_t* lens, const uint8_t* kmask, void* stream);
 /* One-query (autoregressive step) attention over a [B,H,Tmax,64] K/V cache, n_keys keys per (clip,head);
  * q/out are [B,H*64].  kmask optional [B,n_keys].  Cross-attention form (no cache append).
- * nsplit: waves per (clip, head) sharing the keys (1, 2, 4; 0 = automatic). */
+ * nsplit: waves per (clip, head) sharing the keys (1, 2, 4; 0 = automatic).  q_is_f32: q is a single f32 slab
+ * (the form dimx_generate launches) instead of the cache's element type. */
 int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void* vcache, void* out, int B, int H,
-                        int Tmax, int n_keys, float scale, const uint8_t* kmask, int nsplit, void* stream);
+                        int Tmax, int n_keys, float scale, const uint8_t* kmask, int nsplit, int q_is_f32,
+                        void* stream);
 /* tokens = sampler(logits[R,512]) -- see dimx_generate. */
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise,
                    uint64_t seed, uint64_t step, int32_t* tokens, void* stream);
