@@ -142,6 +142,7 @@ struct GemmArgs {
     int rowadd_mode;      // 0 none, 1 row t, 2 row b + rowadd_off, 3 fixed row rowadd_off
     float rowadd_scale;
     int rowadd_off, ld_rowadd;
+    int rowadd_div;       // mode 2: table row = b / rowadd_div + rowadd_off (several samples per clip share a row)
     // rows decompose as m = b*rowT + t (rowT = 1 -> b = m, t = 0); used by rowadd and the output map
     int rowT;
     // output: N columns split into nseg equal segments of seg_width columns; element (m, n) of
@@ -200,6 +201,8 @@ struct DecodeAttnArgs {
     int nslab;
     long slab_stride;      // elements between slabs
     int force_nsplit;      // tests: waves per (clip, head) (0 = automatic)
+    int rows_per_clip;     // cross attention with several query rows per clip (multi-sample generation):
+                           // rows r*S .. r*S+S-1 of q/out share clip r's K/V cache and mask (0/1 = one row)
     const void* knew;      // self-attn: this step's k/v rows [B, *] (nullptr for cross attention)
     const void* vnew;
     int kv_ld;
@@ -237,7 +240,7 @@ int launch_sample(const float* logits, int ld_logits, int R, int top_k, float te
                   int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
                   hipStream_t s);
 int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
-                      const int32_t* step_dev, float* x, int B, hipStream_t s);
+                      const int32_t* step_dev, float* x, int B, int start_div, hipStream_t s);
 int launch_step_inc(int32_t* step_dev, hipStream_t s);
 int launch_copy_rows_step(const float* src, float* dst, int B, int V, int n, const int32_t* step_dev, hipStream_t s);
 int launch_mask_and(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, hipStream_t s);

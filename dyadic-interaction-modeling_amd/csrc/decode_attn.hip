@@ -258,6 +258,132 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
     }
 }
 
+
+// Multi-sample cross attention: SQ query rows (independent samples of the same clip) share one pass over
+// the clip's K/V cache -- the reference's best-of-10 protocol (code/x_engine_pt.py:257) re-reads the same
+// context ten times; here the cache is streamed once per (clip, head) and every key is scored against all SQ
+// queries.  q/out rows of clip b are b*SQ .. b*SQ+SQ-1; scores live in LDS as [SQ][n].
+template <typename T, int SQ, bool QF32>
+__global__ __launch_bounds__(256) void decode_attn_multi_kernel(const DecodeAttnArgs a) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int LPK = 64 / EPC;
+    constexpr int KPI = 64 / LPK;
+    constexpr int U = 4;
+    constexpr int KB = U * KPI;
+    extern __shared__ __attribute__((aligned(16))) float dyn_sc[];  // [4 waves][SQ][npad]
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + wave;
+    const bool active = pair < a.B * a.H;
+    const int b = active ? pair / a.H : 0, h = active ? pair % a.H : 0;   // b = clip
+    const int sub = lane / LPK, ch = lane % LPK;
+    const int n = a.n_keys;
+    const int npad = (n + 3) & ~3;
+    const float scale2 = a.scale * 1.4426950408889634f;
+    const T* kc = (const T*)a.kcache + ((size_t)(b * a.H + h) * a.Tmax) * 64 + ch * EPC;
+    const T* vc = (const T*)a.vcache + ((size_t)(b * a.H + h) * a.Tmax) * 64 + ch * EPC;
+    float* s = dyn_sc + (size_t)wave * SQ * npad;
+    const bool masked = a.kmask != nullptr;
+
+    auto load_batch = [&](const T* base, int j0, uint4 (&r)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * KPI + sub;
+            r[u] = *(const uint4*)(base + (size_t)(j < n ? j : n - 1) * 64);
+        }
+    };
+    uint4 cur[U], nxt[U];
+    load_batch(kc, 0, cur);
+    float qv[SQ][EPC];
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+        const size_t row = (size_t)b * SQ + q;
+        if (QF32)
+            load_f32_slabs<EPC>((const float*)a.q + row * a.q_ld + h * 64 + ch * EPC, a.nslab, a.slab_stride, qv[q]);
+        else
+            load_chunk<T, EPC>((const T*)a.q + row * a.q_ld + h * 64 + ch * EPC, qv[q]);
+    }
+    float mx[SQ];
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) mx[q] = kNegD;
+    for (int j0 = 0; j0 < n; j0 += KB) {
+        if (j0 + KB < n) load_batch(kc, j0 + KB, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * KPI + sub;
+            float kv[EPC];
+            cvt_chunk<T, EPC>(cur[u], kv);
+            const bool dead = masked && j < n && a.kmask[(size_t)b * a.kmask_ld + j] == 0;
+#pragma unroll
+            for (int q = 0; q < SQ; ++q) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) d = fmaf(qv[q][e], kv[e], d);
+#pragma unroll
+                for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o);
+                if (j < n) {
+                    const float sv = dead ? kNegD : d * scale2;
+                    if (ch == 0) s[q * npad + j] = sv;
+                    mx[q] = fmaxf(mx[q], sv);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+    load_batch(vc, 0, cur);
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) mx[q] = wave_max(mx[q]);
+    __syncthreads();
+    float lsum[SQ];
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+        float l = 0.f;
+        for (int j = lane; j < n; j += 64) {
+            const float p = exp2f(s[q * npad + j] - mx[q]);
+            s[q * npad + j] = p;
+            l += p;
+        }
+        lsum[q] = wave_sum(l);
+    }
+    __syncthreads();
+    float acc[SQ][EPC];
+#pragma unroll
+    for (int q = 0; q < SQ; ++q)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[q][e] = 0.f;
+    for (int j0 = 0; j0 < n; j0 += KB) {
+        if (j0 + KB < n) load_batch(vc, j0 + KB, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * KPI + sub;
+            float vv[EPC];
+            cvt_chunk<T, EPC>(cur[u], vv);
+#pragma unroll
+            for (int q = 0; q < SQ; ++q) {
+                const float p = j < n ? s[q * npad + j] : 0.f;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[q][e] = fmaf(p, vv[e], acc[q][e]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[q][e] += __shfl_xor(acc[q][e], o);
+        if (active && sub == 0) {
+            const float inv = lsum[q] > 0.f ? 1.0f / lsum[q] : 0.f;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[q][e] *= inv;
+            store_chunk<T, EPC>((T*)a.out + ((size_t)b * SQ + q) * a.o_ld + h * 64 + ch * EPC, acc[q]);
+        }
+    }
+}
+
 }  // namespace
 
 int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s) {
@@ -265,6 +391,41 @@ int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s) {
     DIMX_REQUIRE((a.knew == nullptr) == (a.vnew == nullptr), DIMX_ERR_ARG, "decode_attn: knew/vnew mismatch");
     DIMX_REQUIRE(a.knew == nullptr || a.step != nullptr, DIMX_ERR_ARG, "decode_attn: self attention needs a step counter");
     DIMX_REQUIRE(a.Tmax <= kMaxKeys && a.n_keys <= kMaxKeys, DIMX_ERR_ARG, "decode_attn: more than %d keys", kMaxKeys);
+    if (a.rows_per_clip > 1) {
+        // multi-sample cross attention: a.B = clips, rows = B * rows_per_clip
+        DIMX_REQUIRE(a.knew == nullptr, DIMX_ERR_ARG, "decode_attn: rows_per_clip applies to cross attention only");
+        const int S = a.rows_per_clip;
+        const int npad = (a.n_keys + 3) & ~3;
+        const size_t lds = (size_t)4 * S * npad * sizeof(float);
+        DIMX_REQUIRE(lds <= 150 * 1024, DIMX_ERR_ARG, "decode_attn: %d samples x %d keys do not fit the LDS score buffer", S,
+                     a.n_keys);
+        dim3 grid(ceil_div(a.B * a.H, 4)), block(256);
+#define DM(TT, SS, QQ)                                                                                          \
+    do {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)decode_attn_multi_kernel<TT, SS, QQ>,                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+        hipLaunchKernelGGL((decode_attn_multi_kernel<TT, SS, QQ>), grid, block, lds, s, a);                     \
+    } while (0)
+#define DM_S(TT, QQ)                         \
+    do {                                     \
+        switch (S) {                         \
+            case 2: DM(TT, 2, QQ); break;    \
+            case 4: DM(TT, 4, QQ); break;    \
+            case 5: DM(TT, 5, QQ); break;    \
+            case 8: DM(TT, 8, QQ); break;    \
+            case 10: DM(TT, 10, QQ); break;  \
+            default:                         \
+                set_error("decode_attn: rows_per_clip %d not in {2,4,5,8,10}", S); \
+                return DIMX_ERR_ARG;         \
+        }                                    \
+    } while (0)
+        if (a.dtype == DIMX_BF16) { if (a.q_f32) DM_S(bf16, true); else DM_S(bf16, false); }
+        else { if (a.q_f32) DM_S(float, true); else DM_S(float, false); }
+#undef DM_S
+#undef DM
+        DIMX_HIP(hipGetLastError());
+        return DIMX_OK;
+    }
     // waves per (clip, head): enough waves to cover the chip (~12 per CU) without splitting large batches
     const int pairs = a.B * a.H;
     int nsplit = 1;

@@ -246,10 +246,10 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const float* __restrict
                                                          const int32_t* __restrict__ start,
                                                          const int32_t* __restrict__ tokens, int tok_ld,
                                                          const int32_t* __restrict__ step_dev, float* __restrict__ x,
-                                                         int rows) {
+                                                         int rows, int start_div) {
     const int b = blockIdx.x;
     const int step = *step_dev;
-    int tok = step == 0 ? start[b] : tokens[(size_t)b * tok_ld + step - 1];
+    int tok = step == 0 ? start[b / start_div] : tokens[(size_t)b * tok_ld + step - 1];
     tok = tok < 0 ? 0 : (tok >= rows ? rows - 1 : tok);
     const float4* src = (const float4*)(table + (size_t)tok * C);
     float4* dst = (float4*)(x + (size_t)b * C);
@@ -357,10 +357,10 @@ int launch_sample(const float* logits, int ld_logits, int R, int top_k, float te
 }
 
 int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
-                      const int32_t* step_dev, float* x, int B, hipStream_t s) {
+                      const int32_t* step_dev, float* x, int B, int start_div, hipStream_t s) {
     DIMX_REQUIRE(C % 4 == 0, DIMX_ERR_ARG, "embed_step: C %% 4");
     hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, table, C, start, tokens, tok_ld, step_dev, x,
-                       rows);
+                       rows, start_div < 1 ? 1 : start_div);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -28,6 +28,7 @@ void gemm_args_init(GemmArgs& a) {
     a.nseg = 1;
     a.rowT = 1;
     a.splitk = 1;
+    a.rowadd_div = 1;
 }
 
 void gemm_set_plain_out(GemmArgs& a, void* C, int ldc) {
@@ -166,7 +167,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
                 }
                 float v = act_fn<ACT, FAST>(acc[i][j][r] + bias_v);
                 if (a.rowadd_mode) {
-                    const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b + a.rowadd_off : a.rowadd_off);
+                    const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b / a.rowadd_div + a.rowadd_off : a.rowadd_off);
                     v += a.rowadd[(size_t)ri * a.ld_rowadd + n] * a.rowadd_scale;
                 }
                 if (a.residual) v += a.residual[(size_t)m * a.ldr + n];

@@ -487,7 +487,7 @@ static int run_vq_blocks(const dimx_ctx* c, const VQBlock* blk, VQScratch& s, in
 // conv(k5, replicate) + LeakyReLU -> InstanceNorm -> Linear + bias + positional row -> s.h
 static int run_vq_front(const dimx_ctx* c, const void* x_in, int ld_in, const Linear& conv, const Linear& le,
                         const float* pe, int pe_mode, int row_off, VQScratch& s, int B, int T, const int32_t* lens,
-                        hipStream_t st) {
+                        hipStream_t st, int row_div = 1) {
     const int M = B * T, Hd = c->d.vq_hidden;
     GemmArgs g;
     gemm_lin(c, x_in, ld_in, conv, M, g);
@@ -506,6 +506,7 @@ static int run_vq_front(const dimx_ctx* c, const void* x_in, int ld_in, const Li
     g.ld_rowadd = Hd;
     g.rowadd_mode = pe_mode == 0 ? 3 : 2;
     g.rowadd_off = pe_mode == 0 ? 0 : row_off;
+    g.rowadd_div = row_div;
     gemm_set_plain_out(g, s.h, Hd);
     DIMX_TRY(launch_gemm(g, st));
     return DIMX_OK;
@@ -710,7 +711,7 @@ static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) 
     s.step = (int32_t*)ar.take(64 * dimx_ctx::kMaxGroups);  // one counter per clip group, 64 B apart
 }
 
-static size_t workspace_bytes(const dimx_ctx* c, int B, int T) {
+static size_t workspace_bytes(const dimx_ctx* c, int B, int T, int S = 1) {
     Arena p(nullptr, 0);
     CtxPersist cp;
     plan_persist(c, p, B, T, cp);
@@ -735,7 +736,7 @@ static size_t workspace_bytes(const dimx_ctx* c, int B, int T) {
         scratch = a.off > scratch ? a.off : scratch;
         Arena g(nullptr, 0);
         GenScratch gs;
-        plan_gen(c, g, B, T, gs);
+        plan_gen(c, g, B * S, T, gs);
         scratch = g.off > scratch ? g.off : scratch;
     }
     return persist + align_up(scratch, 256) + 4096;
@@ -791,12 +792,12 @@ static int run_xenc(const dimx_ctx* c, const XEnc& e, const void* x_in, int ld_i
     return DIMX_OK;
 }
 
-static int check_common(dimx_handle h, int B, int T, void* ws, size_t ws_bytes, int need) {
+static int check_common(dimx_handle h, int B, int T, void* ws, size_t ws_bytes, int need, int S = 1) {
     DIMX_REQUIRE(h, DIMX_ERR_ARG, "null handle");
     DIMX_REQUIRE(B >= 1 && T >= 1 && T <= h->d.max_seq_len, DIMX_ERR_ARG, "B=%d T=%d out of range (T <= %d)", B, T,
                  h->d.max_seq_len);
     DIMX_REQUIRE(ws && ((uintptr_t)ws % 256) == 0, DIMX_ERR_ARG, "workspace must be 256-byte aligned");
-    const size_t need_bytes = workspace_bytes(h, B, T);
+    const size_t need_bytes = workspace_bytes(h, B, T, S);
     DIMX_REQUIRE(ws_bytes >= need_bytes, DIMX_ERR_WORKSPACE, "workspace %zu < required %zu", ws_bytes, need_bytes);
     DIMX_HIP(hipSetDevice(h->device));
     DIMX_TRY(ensure_packed(h, need));
@@ -818,6 +819,11 @@ extern "C" {
 size_t dimx_workspace_bytes(dimx_handle h, int B, int T) {
     if (!h || B < 1 || T < 1) return 0;
     return workspace_bytes(h, B, T);
+}
+
+size_t dimx_workspace_bytes_samples(dimx_handle h, int B, int T, int n_samples) {
+    if (!h || B < 1 || T < 1 || n_samples < 1) return 0;
+    return workspace_bytes(h, B, T, n_samples);
 }
 
 int dimx_vq_argmin(dimx_handle h, int which, const float* z, int N, int32_t* idx, float* best_d, float* margin,
@@ -863,8 +869,8 @@ int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens
     return DIMX_OK;
 }
 
-int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset, float* out,
-                   void* ws, size_t ws_bytes, void* stream) {
+int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset, int rows_per_clip,
+                   float* out, void* ws, size_t ws_bytes, void* stream) {
     DIMX_REQUIRE(which == 0 || which == 1, DIMX_ERR_ARG, "vq_decode: which must be 0 or 1");
     DIMX_TRY(check_common(h, B, L, ws, ws_bytes, which == 0 ? COMP_VQ0 : COMP_VQ1));
     DIMX_REQUIRE(idx && out, DIMX_ERR_ARG, "vq_decode: null argument");
@@ -883,7 +889,8 @@ int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, i
     g.out_dtype = h->at;
     gemm_set_plain_out(g, s.h1, Hd);
     DIMX_TRY(launch_gemm(g, st));
-    DIMX_TRY(run_vq_front(h, s.h1, Hd, v.dconv, v.dle, v.pe_dec, 1, batch_row_offset, s, B, L, nullptr, st));
+    DIMX_REQUIRE(rows_per_clip >= 1, DIMX_ERR_ARG, "vq_decode: rows_per_clip must be >= 1");
+    DIMX_TRY(run_vq_front(h, s.h1, Hd, v.dconv, v.dle, v.pe_dec, 1, batch_row_offset, s, B, L, nullptr, st, rows_per_clip));
     DIMX_TRY(run_vq_blocks(h, v.dec, s, B, L, nullptr, st));
     DIMX_TRY(launch_cast_pad(h->at, s.h, Hd, nullptr, s.y, Hd, M, Hd, st));
     gemm_lin(h, s.y, Hd, v.rev, M, g);
@@ -1044,7 +1051,7 @@ namespace dimx {
 static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, const int32_t* start,
                     const uint8_t* ctx_mask, int row0, int B, int Btot, int grp, int T, float temperature, int top_k,
                     const float* noise, uint64_t seed, int32_t* tokens, float* logits_out, hipStream_t st,
-                    bool embed_only = false) {
+                    bool embed_only = false, int S = 1) {
     const int DD = h->d.dim + h->d.dim_a, heads = h->d.heads, D = h->d.dim_head, inner = heads * D;
     const int V = h->d.num_tokens, n = T - 1, Tp = tpad(T);
     const size_t es = es_of(h);
@@ -1061,12 +1068,14 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     s.f = boff(s0.f, (size_t)DD * h->d.ff_mult * es);
     s.logits = s0.logits + (size_t)row0 * V;
     s.step = s0.step + 16 * grp;
-    start += row0;
-    ctx_mask += (size_t)row0 * T;
+    // with S samples per clip, rows are samples (row = clip * S + sample); start / mask / cross K/V are per clip
+    const int clip0 = row0 / S, nclip = B / S;
+    start += clip0;
+    ctx_mask += (size_t)clip0 * T;
     tokens += (size_t)row0 * n;
     if (logits_out) logits_out += (size_t)row0 * n * V;
     if (embed_only) {  // step 0 input = embedding of the start token (later steps: fused into the sampler)
-        return launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, st);
+        return launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, S, st);
     }
     // Every projection whose output is a small [B, N] f32 matrix is a split-K GEMM writing per-split slabs;
     // the consumer (LayerNorm / attention / sampler) adds the slabs in order: deterministic, no atomics, and
@@ -1120,12 +1129,13 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         a.q_f32 = 1;
         a.nslab = ns;
         a.slab_stride = s0.st_qc;
-        a.kcache = boff(cp.ck[l], (size_t)heads * Tp * 64 * es);
-        a.vcache = boff(cp.cv[l], (size_t)heads * Tp * 64 * es);
+        a.kcache = (unsigned char*)cp.ck[l] + (size_t)clip0 * heads * Tp * 64 * es;
+        a.vcache = (unsigned char*)cp.cv[l] + (size_t)clip0 * heads * Tp * 64 * es;
         a.Tmax = Tp;
         a.out = s.o;
         a.o_ld = inner;
-        a.B = B;
+        a.B = S > 1 ? nclip : B;
+        a.rows_per_clip = S;
         a.H = heads;
         a.n_keys = T;
         a.kmask = ctx_mask;
@@ -1154,10 +1164,13 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
 
 extern "C" {
 
-int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T, float temperature,
-                  int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens, float* logits_out, void* ws,
-                  size_t ws_bytes, void* stream) {
-    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_DEC));
+int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T, int n_samples,
+                  float temperature, int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens, float* logits_out,
+                  void* ws, size_t ws_bytes, void* stream) {
+    const int S = n_samples < 1 ? 1 : n_samples;
+    DIMX_REQUIRE(S == 1 || S == 2 || S == 4 || S == 5 || S == 8 || S == 10, DIMX_ERR_ARG,
+                 "generate: n_samples %d not in {1,2,4,5,8,10}", n_samples);
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_DEC, S));
     DIMX_REQUIRE(start && ctx_mask && tokens && T >= 2, DIMX_ERR_ARG, "generate: null argument or T < 2");
     DIMX_REQUIRE(h->ctx_ready && h->ctx_B == B && h->ctx_T == T && h->ctx_ws == ws && h->ctx_for_generate,
                  DIMX_ERR_STATE, "generate: call dimx_encode_ctx(for_generate=1) with the same B, T, ws first");
@@ -1165,7 +1178,8 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     CtxPersist cp;
     Arena ar = scratch_arena(h, ws, ws_bytes, B, T, &cp);
     GenScratch s;
-    plan_gen(h, ar, B, T, s);
+    const int R = B * S;  // sequences generated in this call
+    plan_gen(h, ar, R, T, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "generate: workspace overflow");
     const int n = T - 1;
     DIMX_HIP(hipMemsetAsync(s.step, 0, 64 * dimx_ctx::kMaxGroups, st));
@@ -1175,8 +1189,9 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     // sampler's noise / counter-based RNG is indexed by the global clip row).
     int G = h->gen_groups < 1 ? 1 : h->gen_groups;
     if (G > B) G = B;
+    if (S > 1) G = 1;  // samples of a clip stay together (they share the clip's cross K/V pass)
     int lo[dimx_ctx::kMaxGroups + 1];
-    for (int g = 0; g <= G; ++g) lo[g] = (int)((long)B * g / G);
+    for (int g = 0; g <= G; ++g) lo[g] = (int)((long)R * g / G);
     hipStream_t gs[dimx_ctx::kMaxGroups];
     if (G == 1) {
         gs[0] = st;
@@ -1191,15 +1206,15 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
         }
     }
     for (int g = 0; g < G; ++g)
-        DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], B, g, T, temperature, top_k, exp_noise,
-                          seed, tokens, logits_out, gs[g], true));
+        DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], R, g, T, temperature, top_k, exp_noise,
+                          seed, tokens, logits_out, gs[g], true, S));
     if (!h->use_graph) {
         for (int t = 0; t < n; ++t)
             for (int g = 0; g < G; ++g)
-                DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], B, g, T, temperature, top_k,
-                                  exp_noise, seed, tokens, logits_out, gs[g]));
+                DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], R, g, T, temperature, top_k,
+                                  exp_noise, seed, tokens, logits_out, gs[g], false, S));
     } else {
-        GraphKey key{ws, B, T, top_k, temperature, exp_noise, seed, start, ctx_mask, tokens, logits_out, G};
+        GraphKey key{ws, B, T, top_k, temperature, exp_noise, seed, start, ctx_mask, tokens, logits_out, G * 100 + S};
         if (!(h->graph_valid && h->graph_key == key)) {
             h->graph_valid = false;
             if (!h->cap_stream) DIMX_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -1211,8 +1226,8 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
             for (int g = 0; g < G; ++g) {
                 hipGraph_t graph = nullptr;
                 DIMX_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-                const int rc = gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], B, g, T, temperature, top_k,
-                                        exp_noise, seed, tokens, logits_out, h->cap_stream);
+                const int rc = gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], R, g, T, temperature, top_k,
+                                        exp_noise, seed, tokens, logits_out, h->cap_stream, false, S);
                 const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
                 if (rc != DIMX_OK) {
                     if (graph) (void)hipGraphDestroy(graph);

@@ -63,8 +63,8 @@ class Engine:
         return self.lib.dimx_missing_weights(self.h)
 
     # ------------------------------------------------------------------ workspace
-    def workspace(self, B, T):
-        need = self.lib.dimx_workspace_bytes(self.h, B, T)
+    def workspace(self, B, T, n_samples=1):
+        need = self.lib.dimx_workspace_bytes_samples(self.h, B, T, n_samples)
         if need == 0:
             raise L.DimxError("dimx_workspace_bytes(%d,%d) = 0" % (B, T))
         if self._ws is None or self._ws_bytes < need:
@@ -105,23 +105,23 @@ class Engine:
                 "dimx_vq_argmin")
         return (idx, bd, mg) if with_stats else idx
 
-    def vq_decode(self, which, idx, row_offset=0):
+    def vq_decode(self, which, idx, row_offset=0, rows_per_clip=1):
         B, Lq = idx.shape
         idx = idx.to(torch.int32).contiguous()
         self._chk(idx)
         out = torch.empty(B, Lq, self.dims.vq_in_dim, dtype=torch.float32, device=self.device)
         ws, wsb = self.workspace(B, Lq)
-        L.check(self.lib.dimx_vq_decode(self.h, which, L.ptr(idx), B, Lq, row_offset, L.ptr(out), ws, wsb,
+        L.check(self.lib.dimx_vq_decode(self.h, which, L.ptr(idx), B, Lq, row_offset, rows_per_clip, L.ptr(out), ws, wsb,
                                         self._s()), "dimx_vq_decode")
         return out
 
-    def encode_ctx(self, v_speaker, v_audio, mask_u8, for_generate, return_x_s=False):
+    def encode_ctx(self, v_speaker, v_audio, mask_u8, for_generate, return_x_s=False, n_samples=1):
         B, T, _ = v_speaker.shape
         v_speaker = v_speaker.to(torch.float32).contiguous()
         v_audio = v_audio.to(torch.float32).contiguous()
         self._chk(v_speaker, v_audio, mask_u8)
         x_s = torch.empty(B, T, self.dims.dim, dtype=torch.float32, device=self.device) if return_x_s else None
-        ws, wsb = self.workspace(B, T)
+        ws, wsb = self.workspace(B, T, n_samples)   # the generate call that follows must see the same workspace
         L.check(self.lib.dimx_encode_ctx(self.h, L.ptr(v_speaker), L.ptr(v_audio), L.ptr(mask_u8), B, T,
                                          1 if for_generate else 0, L.ptr(x_s), ws, wsb, self._s()),
                 "dimx_encode_ctx")
@@ -140,18 +140,22 @@ class Engine:
                                         L.ptr(row_loss), L.ptr(amax), ws, wsb, self._s()), "dimx_decode_tf")
         return logits, row_loss, amax
 
-    def generate(self, start, mask_u8, T, temperature=1.0, top_k=52, noise=None, seed=0, return_logits=False):
+    def generate(self, start, mask_u8, T, temperature=1.0, top_k=52, noise=None, seed=0, return_logits=False,
+                 n_samples=1):
+        """n_samples S > 1: S sequences per clip in one pass (rows b*S+s), sharing the clip's context K/V."""
         B = start.shape[0]
+        R = B * n_samples
         start = start.to(torch.int32).contiguous()
         if noise is not None:
             noise = noise.to(torch.float32).contiguous()
-            assert tuple(noise.shape) == (T - 1, B, self.dims.num_tokens)
+            assert tuple(noise.shape) == (T - 1, R, self.dims.num_tokens)
         self._chk(start, mask_u8, noise)
-        tokens = torch.empty(B, T - 1, dtype=torch.int32, device=self.device)
-        lg = torch.empty(B, T - 1, self.dims.num_tokens, dtype=torch.float32, device=self.device) \
+        tokens = torch.empty(R, T - 1, dtype=torch.int32, device=self.device)
+        lg = torch.empty(R, T - 1, self.dims.num_tokens, dtype=torch.float32, device=self.device) \
             if return_logits else None
-        ws, wsb = self.workspace(B, T)
-        L.check(self.lib.dimx_generate(self.h, L.ptr(start), L.ptr(mask_u8), B, T, float(temperature), int(top_k),
+        ws, wsb = self.workspace(B, T, n_samples)
+        L.check(self.lib.dimx_generate(self.h, L.ptr(start), L.ptr(mask_u8), B, T, int(n_samples), float(temperature),
+                                       int(top_k),
                                        L.ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF, L.ptr(tokens), L.ptr(lg), ws,
                                        wsb, self._s()), "dimx_generate")
         return (tokens, lg) if return_logits else tokens

@@ -46,16 +46,17 @@ SIGNATURES = {
     "dimx_load_weights": (c_int, [c_void_p, POINTER(WeightDesc), c_int]),
     "dimx_missing_weights": (c_int, [c_void_p]),
     "dimx_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "dimx_workspace_bytes_samples": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "dimx_vq_encode": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int32,
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_vq_argmin": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dimx_vq_decode": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+    "dimx_vq_decode": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
     "dimx_encode_ctx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
     "dimx_decode_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dimx_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_uint64,
+    "dimx_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_uint64,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -89,7 +89,7 @@ class SLMFT(_EngineOwner):
 
     @torch.no_grad()
     def forward_decoder(self, x_s, z_l, x_a, mask, mode, v_speaker=None, noise=None, kv_mask=None, greedy=False,
-                        seed=None, temperature=1.0):
+                        seed=None, temperature=1.0, n_samples=1):
         """reference :444-452.  The encoder output lives inside the engine workspace, so this needs the
         speaker motion (``v_speaker``) rather than ``x_s`` to (re)build the context."""
         assert v_speaker is not None, "dimx keeps x_s on the device: pass v_speaker= to forward_decoder"
@@ -105,13 +105,13 @@ class SLMFT(_EngineOwner):
             logits, row_loss, _ = eng.decode_tf(z_l, m8, self._mask8(kv_mask) if kv_mask is not None else None)
             n_valid = (z_l[:, 1:] != -100).sum().clamp(min=1)
             return row_loss.sum() / n_valid, logits
-        eng.encode_ctx(v_speaker, x_a, m8, True)
+        eng.encode_ctx(v_speaker, x_a, m8, True, n_samples=n_samples)
         if greedy:
             temperature, seed_v = 0.0, 0
         else:
             seed_v = 0 if noise is not None else (seed if seed is not None else
                                                   int(torch.randint(1, 2 ** 62, (1,)).item()))
-        tokens = eng.generate(z_l[:, 0], m8, T, temperature, 52, noise, seed_v)
+        tokens = eng.generate(z_l[:, 0], m8, T, temperature, 52, noise, seed_v, n_samples=n_samples)
         return 0.0, tokens.long()
 
     def draw_kv_mask(self, B, T, device, generator=None):
@@ -124,10 +124,10 @@ class SLMFT(_EngineOwner):
         return ~torch.zeros(B, n, device=device).scatter(1, idx, 1.0).bool()
 
     @torch.no_grad()
-    def forward_vq_decoder(self, logits_l, mode="train", batch_row_offset=0):
+    def forward_vq_decoder(self, logits_l, mode="train", batch_row_offset=0, rows_per_clip=1):
         """reference :454-464: argmax (train) / tokens (val) -> codebook lookup -> listener_vq.decode."""
         pred_seq_l = torch.argmax(logits_l, dim=-1) if mode == "train" else logits_l
-        return self.engine(pred_seq_l.device).vq_decode(1, pred_seq_l, batch_row_offset)
+        return self.engine(pred_seq_l.device).vq_decode(1, pred_seq_l, batch_row_offset, rows_per_clip)
 
     def forward_continuous_loss(self, pred, target, mask):
         """reference :466-478."""
@@ -141,17 +141,31 @@ class SLMFT(_EngineOwner):
     @torch.no_grad()
     def forward(self, v_speaker, v_listener, v_audio, mask, mode="train", speaker_ids=None, listener_ids=None,
                 noise=None, kv_mask=None, greedy=False, seed=None, temperature=1.0, batch_row_offset=0,
-                return_tokens=False):
-        """reference :496-514 -> (total_loss, dict, pred_cont_seq_l [B,T-1,56])."""
+                return_tokens=False, n_samples=1):
+        """reference :496-514 -> (total_loss, dict, pred_cont_seq_l [B,T-1,56]).
+
+        ``n_samples`` S > 1 (mode 'val' only): S independent generations per clip in ONE pass -- what the
+        reference's evaluation loop obtains from S separate forward calls (code/x_engine_pt.py:257) -- sharing the
+        VQ encode, the encoder stack and the context K/V stream; pred is then [B,S,T-1,56], tokens [B,S,T-1]."""
         mask = mask.bool()
+        S = int(n_samples)
+        assert S == 1 or mode != "train", "n_samples applies to mode='val'"
         _, z_l = self.forward_vq(v_speaker, v_listener, mask, with_speaker=False)
         l_ce_l, px_l = self.forward_decoder(None, z_l, v_audio, mask, mode, v_speaker=v_speaker, noise=noise,
-                                            kv_mask=kv_mask, greedy=greedy, seed=seed, temperature=temperature)
-        pred = self.forward_vq_decoder(px_l, mode=mode, batch_row_offset=batch_row_offset)
-        l_cont_l = self.forward_continuous_loss(pred, v_listener, mask)
+                                            kv_mask=kv_mask, greedy=greedy, seed=seed, temperature=temperature,
+                                            n_samples=S)
+        pred = self.forward_vq_decoder(px_l, mode=mode, batch_row_offset=batch_row_offset, rows_per_clip=S)
+        if S > 1:
+            B, T = mask.shape
+            pred = pred.view(B, S, T - 1, -1)
+            l_cont_l = torch.stack([self.forward_continuous_loss(pred[:, i], v_listener, mask) for i in range(S)]).mean()
+        else:
+            l_cont_l = self.forward_continuous_loss(pred, v_listener, mask)
         total_loss = l_ce_l + l_cont_l
         d = {"l_ce_s": 0, "l_ce_l": l_ce_l, "l_cont_s": 0, "l_cont_l": l_cont_l, "nce": 0, "c_acc": 0}
         if return_tokens:
             tokens = px_l if mode != "train" else torch.argmax(px_l, dim=-1)
+            if S > 1:
+                tokens = tokens.view(mask.shape[0], S, -1)
             return total_loss, d, pred, tokens
         return total_loss, d, pred

@@ -52,10 +52,19 @@ def evaluate_finetune_epoch(model, loader, device):
     return y_trues_all, y_preds_all, x_all, data_ids_all
 
 
-def evaluate_test_epoch(model, loader, device, beam_size=10, **forward_kw):
-    """reference code/x_engine_pt.py:232-277 (autoregressive generation, best of ``beam_size`` by FD)."""
+BATCHED_SAMPLE_COUNTS = (2, 4, 5, 8, 10)
+
+
+def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=True, **forward_kw):
+    """reference code/x_engine_pt.py:232-277 (autoregressive generation, best of ``beam_size`` by FD).
+
+    ``batched_samples``: draw the ``beam_size`` generations of a clip in ONE forward pass (n_samples) instead of
+    ``beam_size`` passes -- same distribution (independent multinomial draws given the same inputs), but the VQ
+    encode, the encoder stack and the context K/V stream are shared.  Falls back to the reference's loop for
+    sample counts the kernels are not instantiated for."""
     y_trues_all, y_preds_all, x_all, data_ids_all = [], [], [], []
     model.eval()
+    batched = batched_samples and beam_size in BATCHED_SAMPLE_COUNTS
     with torch.no_grad():
         for batch in loader:
             src_s_v, src_s_a, tgt, mask, src_len, data_ids = _prepare(batch, device)
@@ -69,15 +78,23 @@ def evaluate_test_epoch(model, loader, device, beam_size=10, **forward_kw):
                 x_all.append(xs[j][:n])
             cur_best = [float("inf")] * B
             best = [None] * B
-            for _ in range(beam_size):
-                _, _, y_preds = model(src_s_v, tgt, src_s_a, mask, mode="val", **forward_kw)
-                yp = y_preds.cpu().numpy()
+
+            def consider(yp):           # yp [B, T-1, 56] numpy: one sample per clip
                 for j in range(B):
                     n = src_len[j] - 1
                     cfid = clip_fd(y_true[j][:n], yp[j][:n])
                     if cfid < cur_best[j]:
                         best[j] = yp[j][:n].copy()
                         cur_best[j] = cfid
+            if batched:
+                _, _, y_preds = model(src_s_v, tgt, src_s_a, mask, mode="val", n_samples=beam_size, **forward_kw)
+                yp_all = y_preds.cpu().numpy()          # [B, S, T-1, 56]
+                for s_i in range(beam_size):
+                    consider(yp_all[:, s_i])
+            else:
+                for _ in range(beam_size):
+                    _, _, y_preds = model(src_s_v, tgt, src_s_a, mask, mode="val", **forward_kw)
+                    consider(y_preds.cpu().numpy())
             y_preds_all.extend(best)
     return y_trues_all, y_preds_all, x_all, data_ids_all
 

@@ -84,6 +84,8 @@ int dimx_missing_weights(dimx_handle h);
 
 /* Bytes of caller-provided device workspace needed by any stage call at (B, T). */
 size_t dimx_workspace_bytes(dimx_handle h, int B, int T);
+/* same, when dimx_generate will draw n_samples sequences per clip */
+size_t dimx_workspace_bytes_samples(dimx_handle h, int B, int T, int n_samples);
 
 /* which: 0 = speaker VQ-VAE, 1 = listener VQ-VAE.
  * x: [B,T,56] f32, valid frames left-aligned; lens: [B] int32 device (NULL = all T).
@@ -100,9 +102,10 @@ int dimx_vq_argmin(dimx_handle h, int which, const float* z, int N, int32_t* idx
 
 /* idx: [B,L] int32 in [0,512).  Clip b is decoded with positional row b + batch_row_offset and
  * InstanceNorm / attention span the full L (reference behaviour on padded batches).
- * out: [B,L,56] f32. */
+ * rows_per_clip S > 1 (multi-sample generation): rows b*S .. b*S+S-1 are samples of clip b and all use
+ * positional row b + batch_row_offset, like S separate reference forwards would.  out: [B,L,56] f32. */
 int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset,
-                   float* out, void* ws, size_t ws_bytes, void* stream);
+                   int rows_per_clip, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* Speaker encoder stack + context assembly + cross-attention K/V projection for all decoder
  * layers.  v_speaker [B,T,56] f32, v_audio [B,T,768] f32, mask [B,T] uint8 (1 = valid frame).
@@ -125,8 +128,12 @@ int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, c
  * temperature <= 0 or exp_noise == NULL && seed == 0 -> greedy argmax.
  * exp_noise: [T-1,B,512] f32 Exp(1) samples (token = argmax softmax(top_k(logits)/temp)/noise);
  * if NULL and seed != 0 the noise is drawn on device from a counter-based generator.
- * tokens: [B,T-1] int32.  logits_out (optional): [B,T-1,512] f32 raw logits of every step. */
-int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T,
+ * n_samples S (1, 2, 4, 5, 8, 10): S independent samples per clip in one pass -- rows b*S+s of tokens /
+ * exp_noise / logits_out belong to clip b; the clip's context K/V is streamed once for all S samples (the
+ * reference's best-of-10 protocol, code/x_engine_pt.py:257, as one batched generation).  The workspace must
+ * come from dimx_workspace_bytes_samples(h, B, T, S).
+ * tokens: [B*S,T-1] int32.  logits_out (optional): [B*S,T-1,512] f32 raw logits of every step. */
+int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T, int n_samples,
                   float temperature, int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens,
                   float* logits_out, void* ws, size_t ws_bytes, void* stream);
 
