@@ -1,6 +1,7 @@
 // attention.hip -- flash-style softmax(Q K^T * scale + mask) V for the parallel (non-autoregressive)
 // attention blocks of the path:
-//   * VQ-VAE blocks, 8 heads x 48, scale hidden^-0.5, keys limited to the clip length
+//   * VQ-VAE blocks, 8 heads x 48 (listener / SLMFT speaker) or 8 x 96 (legacy speaker, hidden 768),
+//     scale hidden^-0.5, keys limited to the clip length
 //     (reference code/models/lib/base_models.py:125-146);
 //   * x-transformers encoder self-attention (causal + key padding mask), teacher-forced decoder
 //     self-attention (causal + random key mask) and cross-attention over the speaker context
@@ -40,17 +41,25 @@ template <> struct MmaT<float> {
 
 constexpr float kNeg = -3.0e38f;
 
-template <typename T, int NW>
+// DK = head-dim extent the kernel reduces over (64 for D in {48,64}; 96 for the 8 x 96 heads of the legacy
+// speaker VQ-VAE, hidden 768).  K rows are padded to DKP = 64 / 128 elements so the XOR swizzle stays a power
+// of two; the V^T tile has DK rows (NB = DK/32 output blocks) of 64 keys.
+template <typename T, int NW, int DK>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
     constexpr int ES = sizeof(T);
-    constexpr int EPC = 16 / ES;    // elements per 16-byte chunk
-    constexpr int ROWB = 64 * ES;   // bytes per LDS row (64 elements)
-    constexpr int CPR = ROWB / 16;  // 16-byte chunks per row: 8 (bf16) / 16 (f32)
-    constexpr int NKS = ROWB / 32;  // 32-byte k-steps over the head dim: 4 / 8
+    constexpr int EPC = 16 / ES;     // elements per 16-byte chunk
+    constexpr int DKP = DK == 64 ? 64 : 128;
+    constexpr int ROWBK = DKP * ES;  // bytes per K row in LDS
+    constexpr int CPRK = ROWBK / 16; // 16-byte chunks per K row: 8 / 16 / 32
+    constexpr int ROWB = 64 * ES;    // bytes per V^T row (64 keys)
+    constexpr int CPR = ROWB / 16;   // chunks per V^T row: 8 (bf16) / 16 (f32)
+    constexpr int NKS = DK * ES / 32;  // 32-byte k-steps over the head dim
+    constexpr int NB = DK / 32;      // 32-row output blocks
     constexpr int NT = NW * 64;
-    constexpr int UB = 4 * ES;      // bytes of a 4-key unit in the V^T tile
-    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * ROWB];
+    constexpr int UB = 4 * ES;       // bytes of a 4-key unit in the V^T tile
+    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * ROWBK];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[NB * 32 * ROWB];
+    auto swz = [](int row) { return CPRK == 8 ? ((row >> 1) & 7) : (row & (CPRK - 1)); };
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int half = lane >> 5, l31 = lane & 31;
@@ -82,9 +91,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
     const int ntiles = (kmax + 63) / 64;
 
     float m_run = kNeg, l_run = 0.f;
-    f32x16_t ot[2];
+    f32x16_t ot[NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
     const float scale2 = a.scale * 1.4426950408889634f;
@@ -94,17 +103,19 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
         __syncthreads();
         // ---- stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]
 #pragma unroll
-        for (int i = 0; i < 64 * CPR / NT; ++i) {
+        for (int i = 0; i < 64 * CPRK / NT; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx / CPRK, c = idx % CPRK;
+            int key = j0 + row;
+            key = key < a.Lk ? key : a.Lk - 1;
+            const uint4 v = (c * EPC < a.D) ? *(const uint4*)(K + (size_t)key * a.k_st + c * EPC)
+                                            : make_uint4(0, 0, 0, 0);
+            *(uint4*)(sK + row * ROWBK + ((c ^ swz(row)) << 4)) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB * 32 * CPR / NT; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / CPR, c = idx % CPR;
-            {
-                int key = j0 + row;
-                key = key < a.Lk ? key : a.Lk - 1;
-                const uint4 v = (c * EPC < a.D) ? *(const uint4*)(K + (size_t)key * a.k_st + c * EPC)
-                                                : make_uint4(0, 0, 0, 0);
-                const int sw = (CPR == 8) ? ((row >> 1) & 7) : (row & 15);
-                *(uint4*)(sK + row * ROWB + ((c ^ sw) << 4)) = v;
-            }
             {
                 const int d = row;
                 const int jj = j0 + c * EPC;
@@ -151,11 +162,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
             const int row = 32 * kt + l31;
-            const int sw = (CPR == 8) ? ((row >> 1) & 7) : (row & 15);
+            const int sw = swz(row);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const int c = 2 * ks + half;
-                const uint4 kf = *(const uint4*)(sK + row * ROWB + ((c ^ sw) << 4));
+                const uint4 kf = *(const uint4*)(sK + row * ROWBK + ((c ^ sw) << 4));
                 MmaT<T>::run(st[kt], kf, qf[ks]);
             }
         }
@@ -187,13 +198,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
 
         // ---- O^T += V^T . P^T
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NB; ++blk) {
             const int d = 32 * blk + l31;
             const unsigned char* vrow = sV + d * ROWB;
             if (ES == 2) {
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
     if (qi < a.Lq) {
         T* orow = (T*)a.o + (size_t)b * a.o_sb + (size_t)qi * a.o_st + (size_t)h * a.o_sh;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 32 * blk + 8 * g + 4 * half;
@@ -257,16 +268,22 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
 int launch_attention(const AttnArgs& a, hipStream_t s) {
     DIMX_REQUIRE(a.q && a.k && a.vt && a.o, DIMX_ERR_ARG, "attention: null operand");
     DIMX_REQUIRE(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, DIMX_ERR_ARG, "attention: empty shape");
-    DIMX_REQUIRE(a.D == 48 || a.D == 64, DIMX_ERR_ARG, "attention: head dim %d not in {48,64}", a.D);
+    DIMX_REQUIRE(a.D == 48 || a.D == 64 || a.D == 96, DIMX_ERR_ARG, "attention: head dim %d not in {48,64,96}", a.D);
     const int epc = a.dtype == DIMX_BF16 ? 8 : 4;
     DIMX_REQUIRE(a.v_sd % epc == 0 && a.v_sd >= a.Lk && a.q_st % epc == 0 && a.k_st % epc == 0 && a.o_st % 4 == 0,
                  DIMX_ERR_ARG, "attention: strides must keep 16-byte alignment (v_sd=%ld)", a.v_sd);
     constexpr int NW = 2;
     dim3 grid(ceil_div(a.Lq, 32 * NW), a.H, a.B), block(NW * 64);
-    if (a.dtype == DIMX_BF16)
-        hipLaunchKernelGGL((attn_kernel<bf16, NW>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((attn_kernel<float, NW>), grid, block, 0, s, a);
+    if (a.D == 96) {
+        if (a.dtype == DIMX_BF16)
+            hipLaunchKernelGGL((attn_kernel<bf16, NW, 96>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((attn_kernel<float, NW, 96>), grid, block, 0, s, a);
+    } else if (a.dtype == DIMX_BF16) {
+        hipLaunchKernelGGL((attn_kernel<bf16, NW, 64>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((attn_kernel<float, NW, 64>), grid, block, 0, s, a);
+    }
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -230,7 +230,8 @@ int launch_gather_rows(int out_dtype, const float* table, int ld_table, int rows
                        int ldy, int M, int C, hipStream_t s);
 int launch_context_concat(int out_dtype, const float* x_s, const float* patch, const float* audio, void* ctx,
                           int M, int dim, int dim_a, hipStream_t s);
-int launch_finalize_idx(int32_t* idx, const int32_t* lens, int B, int T, int32_t pad_value, hipStream_t s);
+int launch_finalize_idx(int32_t* idx, const int32_t* lens, int B, int T, int32_t pad_value, hipStream_t s,
+                        int fqn = 1);
 int launch_shift_tokens(const int32_t* z, int32_t* inp, int32_t* tgt, int B, int T, hipStream_t s);
 int launch_ce_argmax(const float* logits, const int32_t* target, float* row_loss, int32_t* argmax_tok, int R,
                      int V, hipStream_t s);
@@ -238,9 +239,14 @@ int launch_sample(const float* logits, int ld_logits, int R, int top_k, float te
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
                   int tok_col_from_step, int nslab, long slab_stride, float* logits_out, int logits_out_ld, int row0,
                   int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
-                  hipStream_t s);
+                  hipStream_t s, const float* pos_table = nullptr, float pos_scale = 0.f, int pos_rows = 0);
 int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
-                      const int32_t* step_dev, float* x, int B, int start_div, hipStream_t s);
+                      const int32_t* step_dev, float* x, int B, int start_div, hipStream_t s,
+                      const float* pos_table = nullptr, float pos_scale = 0.f);
+int launch_add_pos_rows(float* x, const float* pos, int M, int n, int C, float scale, hipStream_t s);
+int launch_mask_lens(const uint8_t* mask, int32_t* lens, int B, int T, hipStream_t s);
+int launch_legacy_scramble(int out_dtype, const float* E, const int32_t* idx, const int32_t* lens, void* out, int B,
+                           int T, int fqn, int zdim, int n_embed, hipStream_t s);
 int launch_step_inc(int32_t* step_dev, hipStream_t s);
 int launch_copy_rows_step(const float* src, float* dst, int B, int V, int n, const int32_t* step_dev, hipStream_t s);
 int launch_mask_and(const uint8_t* a, const uint8_t* b, uint8_t* out, int n, hipStream_t s);

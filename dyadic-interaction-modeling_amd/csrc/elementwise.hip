@@ -50,10 +50,11 @@ __global__ void context_concat_kernel(const float* __restrict__ x_s, const float
     }
 }
 
-__global__ void finalize_idx_kernel(int32_t* idx, const int32_t* lens, int B, int T, int32_t pad) {
+// fqn codes per frame (1 for the listener / SLMFT VQ-VAEs, 8 for the legacy speaker VQ-VAE)
+__global__ void finalize_idx_kernel(int32_t* idx, const int32_t* lens, int B, int T, int fqn, int32_t pad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * T) return;
-    const int b = i / T, t = i - b * T;
+    if (i >= B * T * fqn) return;
+    const int b = i / (T * fqn), t = (i - b * T * fqn) / fqn;
     if (lens && t >= lens[b]) idx[i] = pad;
 }
 
@@ -135,7 +136,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      int rows_total,
                                                      const float* __restrict__ emb_table, int emb_C,
                                                      float* __restrict__ x_next, int32_t* __restrict__ step_rw,
-                                                     unsigned* __restrict__ done_ctr) {
+                                                     unsigned* __restrict__ done_ctr,
+                                                     const float* __restrict__ pos_table, float pos_scale,
+                                                     int pos_rows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint64_t step = step_dev ? (uint64_t)*step_dev : step_host;
     if (row < R) {
@@ -225,7 +228,15 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     if (x_next) {  // next step's decoder input: token embedding row (fused embed_step)
         const float2* src = (const float2*)(emb_table + (size_t)tok * emb_C);
         float2* dst = (float2*)(x_next + (size_t)row * emb_C);
-        for (int i = lane; i < emb_C / 2; i += 64) dst[i] = src[i];
+        if (pos_table && (int)step + 1 < pos_rows) {  // legacy decoder: + pos_emb[next position] * dim^-0.5
+            const float2* pr = (const float2*)(pos_table + (size_t)(step + 1) * emb_C);
+            for (int i = lane; i < emb_C / 2; i += 64) {
+                const float2 e = src[i], q = pr[i];
+                dst[i] = make_float2(__fadd_rn(e.x, __fmul_rn(q.x, pos_scale)), __fadd_rn(e.y, __fmul_rn(q.y, pos_scale)));
+            }
+        } else {
+            for (int i = lane; i < emb_C / 2; i += 64) dst[i] = src[i];
+        }
     }
     }  // row < R
     // the block that finishes last advances the device step counter (every block has read it by then)
@@ -246,14 +257,70 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const float* __restrict
                                                          const int32_t* __restrict__ start,
                                                          const int32_t* __restrict__ tokens, int tok_ld,
                                                          const int32_t* __restrict__ step_dev, float* __restrict__ x,
-                                                         int rows, int start_div) {
+                                                         int rows, int start_div,
+                                                         const float* __restrict__ pos_table, float pos_scale) {
     const int b = blockIdx.x;
     const int step = *step_dev;
     int tok = step == 0 ? start[b / start_div] : tokens[(size_t)b * tok_ld + step - 1];
     tok = tok < 0 ? 0 : (tok >= rows ? rows - 1 : tok);
     const float4* src = (const float4*)(table + (size_t)tok * C);
     float4* dst = (float4*)(x + (size_t)b * C);
-    for (int i = threadIdx.x; i < C / 4; i += blockDim.x) dst[i] = src[i];
+    if (pos_table) {
+        const float4* pr = (const float4*)(pos_table + (size_t)step * C);
+        for (int i = threadIdx.x; i < C / 4; i += blockDim.x) {
+            const float4 e = src[i], q = pr[i];
+            dst[i] = make_float4(__fadd_rn(e.x, __fmul_rn(q.x, pos_scale)), __fadd_rn(e.y, __fmul_rn(q.y, pos_scale)),
+                                 __fadd_rn(e.z, __fmul_rn(q.z, pos_scale)), __fadd_rn(e.w, __fmul_rn(q.w, pos_scale)));
+        }
+    } else {
+        for (int i = threadIdx.x; i < C / 4; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// x[b*n + t, :] += pos[t, :] * scale   (TransformerWrapper abs. positional embedding of the legacy decoder,
+// code/seq2seq.py:39 -> x-transformers AbsolutePositionalEmbedding: emb(arange(n)) * dim^-0.5)
+__global__ void add_pos_rows_kernel(float* __restrict__ x, const float* __restrict__ pos, int M, int n, int C,
+                                    float scale) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C), c = (int)(i - (long)m * C);
+        x[i] = __fadd_rn(x[i], __fmul_rn(pos[(size_t)(m % n) * C + c], scale));
+    }
+}
+
+// lens[b] = number of set entries of mask[b, :]  (the reference indexes v_speaker[i][mask[i]], code/seq2seq.py:228)
+__global__ __launch_bounds__(64) void mask_lens_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ lens,
+                                                       int T) {
+    const int b = blockIdx.x;
+    int n = 0;
+    for (int t = threadIdx.x; t < T; t += 64) n += mask[(size_t)b * T + t] ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) n += __shfl_xor(n, o);
+    if (threadIdx.x == 0) lens[b] = n;
+}
+
+// ListenerGenerator's x_speaker (code/seq2seq.py:224-241): the per-clip code vectors live channel-major as
+// [zdim, len*fqn], are zero-padded along the LAST axis to T*fqn, and that memory is then re-read through
+// .view(B,-1,fqn,zdim).view(B,-1,fqn*zdim) -- a reinterpretation, not a transpose.  Output element f of clip b is
+// therefore channel c = f / (T*fqn), position p = f % (T*fqn) of the padded tensor.
+template <typename OutT>
+__global__ void legacy_scramble_kernel(const float* __restrict__ E, const int32_t* __restrict__ idx,
+                                       const int32_t* __restrict__ lens, OutT* __restrict__ out, int B, int T, int fqn,
+                                       int zdim, int n_embed) {
+    const long per = (long)T * fqn * zdim, total = (long)B * per;
+    const int P = T * fqn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const long f = i - (long)b * per;
+        const int c = (int)(f / P), p = (int)(f - (long)c * P);
+        float v = 0.f;
+        if (p < lens[b] * fqn) {
+            int r = idx[(size_t)b * P + p];
+            r = r < 0 ? 0 : (r >= n_embed ? n_embed - 1 : r);
+            v = E[(size_t)r * zdim + c];
+        }
+        store_from_f32<OutT>(out + i, v);
+    }
 }
 
 __global__ void step_inc_kernel(int32_t* step) { *step += 1; }
@@ -321,9 +388,10 @@ int launch_context_concat(int out_dtype, const float* x_s, const float* patch, c
     return DIMX_OK;
 }
 
-int launch_finalize_idx(int32_t* idx, const int32_t* lens, int B, int T, int32_t pad_value, hipStream_t s) {
+int launch_finalize_idx(int32_t* idx, const int32_t* lens, int B, int T, int32_t pad_value, hipStream_t s, int fqn) {
     if (!lens) return DIMX_OK;
-    hipLaunchKernelGGL(finalize_idx_kernel, dim3(ceil_div(B * T, 256)), dim3(256), 0, s, idx, lens, B, T, pad_value);
+    hipLaunchKernelGGL(finalize_idx_kernel, dim3(ceil_div(B * T * fqn, 256)), dim3(256), 0, s, idx, lens, B, T, fqn,
+                       pad_value);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
@@ -347,20 +415,53 @@ int launch_sample(const float* logits, int ld_logits, int R, int top_k, float te
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
                   int tok_col_from_step, int nslab, long slab_stride, float* logits_out, int logits_out_ld, int row0,
                   int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
-                  hipStream_t s) {
+                  hipStream_t s, const float* pos_table, float pos_scale, int pos_rows) {
     DIMX_REQUIRE(logits && tokens && R > 0, DIMX_ERR_ARG, "sample: bad arguments");
     hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, logits, ld_logits, R, top_k,
                        temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, nslab < 1 ? 1 : nslab,
-                       slab_stride, logits_out, logits_out_ld, row0, rows_total, emb_table, emb_C, x_next, step_rw, done_ctr);
+                       slab_stride, logits_out, logits_out_ld, row0, rows_total, emb_table, emb_C, x_next, step_rw, done_ctr,
+                       pos_table, pos_scale, pos_rows);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
 
 int launch_embed_step(const float* table, int C, int rows, const int32_t* start, const int32_t* tokens, int tok_ld,
-                      const int32_t* step_dev, float* x, int B, int start_div, hipStream_t s) {
+                      const int32_t* step_dev, float* x, int B, int start_div, hipStream_t s, const float* pos_table,
+                      float pos_scale) {
     DIMX_REQUIRE(C % 4 == 0, DIMX_ERR_ARG, "embed_step: C %% 4");
     hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, table, C, start, tokens, tok_ld, step_dev, x,
-                       rows, start_div < 1 ? 1 : start_div);
+                       rows, start_div < 1 ? 1 : start_div, pos_table, pos_scale);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_add_pos_rows(float* x, const float* pos, int M, int n, int C, float scale, hipStream_t s) {
+    DIMX_REQUIRE(x && pos && M > 0 && n > 0, DIMX_ERR_ARG, "add_pos_rows: bad arguments");
+    const long total = (long)M * C;
+    const int blocks = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+    hipLaunchKernelGGL(add_pos_rows_kernel, dim3(blocks), dim3(256), 0, s, x, pos, M, n, C, scale);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_mask_lens(const uint8_t* mask, int32_t* lens, int B, int T, hipStream_t s) {
+    DIMX_REQUIRE(mask && lens && B > 0 && T > 0, DIMX_ERR_ARG, "mask_lens: bad arguments");
+    hipLaunchKernelGGL(mask_lens_kernel, dim3(B), dim3(64), 0, s, mask, lens, T);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_legacy_scramble(int out_dtype, const float* E, const int32_t* idx, const int32_t* lens, void* out, int B,
+                           int T, int fqn, int zdim, int n_embed, hipStream_t s) {
+    DIMX_REQUIRE(E && idx && lens && out && B > 0 && T > 0, DIMX_ERR_ARG, "legacy_scramble: bad arguments");
+    const long total = (long)B * T * fqn * zdim;
+    const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    if (out_dtype == DIMX_BF16)
+        hipLaunchKernelGGL((legacy_scramble_kernel<bf16>), dim3(blocks), dim3(256), 0, s, E, idx, lens, (bf16*)out, B,
+                           T, fqn, zdim, n_embed);
+    else
+        hipLaunchKernelGGL((legacy_scramble_kernel<float>), dim3(blocks), dim3(256), 0, s, E, idx, lens, (float*)out,
+                           B, T, fqn, zdim, n_embed);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

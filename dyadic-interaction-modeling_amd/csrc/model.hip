@@ -117,8 +117,39 @@ static void xdec_keys(const dimx_dims& d, const std::string& pre, std::vector<Ke
     out.push_back({pre + "to_logits.weight", {d.num_tokens, D}});
 }
 
+// legacy variant: encoder half + codebook of VQSpeakerAutoEncoder (code/models/stage1_BIWI.py:140-157)
+static void legacy_speaker_vq_keys(const dimx_dims& d, std::vector<KeySpec>& out) {
+    dimx_dims t = d;
+    t.vq_in_dim = d.spk_in_dim;
+    t.vq_hidden = d.spk_hidden;
+    t.vq_heads = d.spk_heads;
+    t.vq_inter = d.spk_inter;
+    std::vector<KeySpec> all;
+    vq_keys(t, 0, all);
+    for (auto& k : all) {
+        if (k.name.find(".decoder.") != std::string::npos) continue;
+        if (k.name == "speaker_vq.encoder.encoder_linear_embedding_post.net.weight")
+            k.shape = {(int64_t)d.spk_face_quan_num * d.vq_zdim, d.spk_hidden};
+        if (k.name == "speaker_vq.encoder.encoder_linear_embedding_post.net.bias")
+            k.shape = {(int64_t)d.spk_face_quan_num * d.vq_zdim};
+        out.push_back(k);
+    }
+}
+
+static void legacy_keys(const dimx_dims& d, std::vector<KeySpec>& k) {
+    legacy_speaker_vq_keys(d, k);
+    vq_keys(d, 1, k);
+    xenc_keys(d, "generator.encoder.", (int64_t)d.spk_face_quan_num * d.vq_zdim, k);
+    xdec_keys(d, "generator.decoder.net.", k);
+    k.push_back({"generator.decoder.net.pos_emb.emb.weight", {d.max_seq_len, d.dim + d.dim_a}});
+}
+
 static std::vector<KeySpec> all_keys(const dimx_dims& d) {
     std::vector<KeySpec> k;
+    if (d.variant == 1) {
+        legacy_keys(d, k);
+        return k;
+    }
     vq_keys(d, 0, k);
     vq_keys(d, 1, k);
     xenc_keys(d, "encoder_s.", d.dim_in, k);
@@ -132,7 +163,10 @@ static std::vector<KeySpec> all_keys(const dimx_dims& d) {
 }
 
 static bool ignorable_key(const std::string& n) {
-    static const char* pre[] = {"encoder_l.", "norm_l.", "norm.", "patch_embed_l", "patch_embed_dec_l"};
+    static const char* pre[] = {"encoder_l.", "norm_l.", "norm.", "patch_embed_l", "patch_embed_dec_l",
+                                // legacy ListenerGenerator tensors that are not on the ids=None path
+                                "speaker_vq.decoder_v.", "speaker_vq.decoder_a.", "speaker_embeddings.",
+                                "listener_embeddings.", "fc_speaker.", "fc_listener."};
     for (const char* p : pre)
         if (n.rfind(p, 0) == 0) return true;
     const std::string suf = ".project_out.weight";
@@ -209,19 +243,22 @@ static int pack_linear(dimx_ctx* c, const std::vector<std::string>& parts, const
 
 static int pack_vq(dimx_ctx* c, int which) {
     VQNet& v = c->vq[which];
+    const VQGeom& vg = c->vqg[which];
     const std::string p = vq_prefix(which), e = p + "encoder.", d = p + "decoder.";
     DIMX_TRY(pack_linear(c, {e + "vertice_mapping.0.weight"}, e + "vertice_mapping.0.bias", false, &v.vm));
     DIMX_TRY(pack_linear(c, {e + "squasher.0.0.weight"}, e + "squasher.0.0.bias", true, &v.conv));
     DIMX_TRY(pack_linear(c, {e + "encoder_linear_embedding.net.weight"}, e + "encoder_linear_embedding.net.bias", false, &v.le));
     DIMX_TRY(pack_linear(c, {e + "encoder_linear_embedding_post.net.weight"}, e + "encoder_linear_embedding_post.net.bias", false, &v.post));
-    DIMX_TRY(pack_linear(c, {d + "decoder_linear_embedding_pre.net.weight"}, d + "decoder_linear_embedding_pre.net.bias", false, &v.pre));
-    DIMX_TRY(pack_linear(c, {d + "expander.0.0.weight"}, d + "expander.0.0.bias", true, &v.dconv));
-    DIMX_TRY(pack_linear(c, {d + "decoder_linear_embedding.net.weight"}, d + "decoder_linear_embedding.net.bias", false, &v.dle));
-    DIMX_TRY(pack_linear(c, {d + "vertice_map_reverse.weight"}, "", false, &v.rev));
-    for (int s = 0; s < 2; ++s) {
+    if (vg.has_decoder) {
+        DIMX_TRY(pack_linear(c, {d + "decoder_linear_embedding_pre.net.weight"}, d + "decoder_linear_embedding_pre.net.bias", false, &v.pre));
+        DIMX_TRY(pack_linear(c, {d + "expander.0.0.weight"}, d + "expander.0.0.bias", true, &v.dconv));
+        DIMX_TRY(pack_linear(c, {d + "decoder_linear_embedding.net.weight"}, d + "decoder_linear_embedding.net.bias", false, &v.dle));
+        DIMX_TRY(pack_linear(c, {d + "vertice_map_reverse.weight"}, "", false, &v.rev));
+    }
+    for (int s = 0; s < (vg.has_decoder ? 2 : 1); ++s) {
         const std::string pre = s == 0 ? e + "encoder_transformer." : d + "decoder_transformer.";
         VQBlock* blk = s == 0 ? v.enc : v.dec;
-        for (int i = 0; i < c->d.vq_layers; ++i) {
+        for (int i = 0; i < vg.layers; ++i) {
             const std::string a = pre + "net." + std::to_string(2 * i) + ".fn.";
             const std::string m = pre + "net." + std::to_string(2 * i + 1) + ".fn.";
             DIMX_TRY(upload_f32(c, a + "norm.weight", &blk[i].ln1_g));
@@ -235,11 +272,11 @@ static int pack_vq(dimx_ctx* c, int which) {
         }
     }
     DIMX_TRY(upload_f32(c, e + "encoder_pos_embedding.pe", &v.pe_enc));
-    DIMX_TRY(upload_f32(c, d + "decoder_pos_embedding.pe", &v.pe_dec));
+    if (vg.has_decoder) DIMX_TRY(upload_f32(c, d + "decoder_pos_embedding.pe", &v.pe_dec));
     DIMX_TRY(upload_f32(c, p + "quantize.embedding.weight", &v.E));
     // k-major codebook + squared norms (k-ascending fmaf chain, mirrored by oracle/vq_argmin.c)
     const HostTensor& E = c->host[p + "quantize.embedding.weight"];
-    const int ne = c->d.vq_n_embed, zd = c->d.vq_zdim;
+    const int ne = vg.n_embed, zd = vg.zdim;
     std::vector<float> Et((size_t)zd * ne), ee(ne);
     for (int j = 0; j < ne; ++j) {
         float s = 0.f;
@@ -278,7 +315,7 @@ static int pack_xff(dimx_ctx* c, const std::string& p, XFF* f) {
 static int pack_xenc(dimx_ctx* c, const std::string& pre, XEnc* e) {
     DIMX_TRY(pack_linear(c, {pre + "project_in.weight"}, "", false, &e->proj_in));
     DIMX_TRY(upload_f32(c, pre + "pos_emb.emb.weight", &e->pos_emb));
-    for (int i = 0; i < c->d.enc_depth; ++i) {
+    for (int i = 0; i < c->encg[0].depth; ++i) {
         DIMX_TRY(pack_xattn(c, xl(pre, 2 * i), false, &e->attn[i]));
         DIMX_TRY(pack_xff(c, xl(pre, 2 * i + 1), &e->ff[i]));
     }
@@ -296,6 +333,16 @@ enum { COMP_VQ0 = 1, COMP_VQ1 = 2, COMP_ENC = 4, COMP_DEC = 8, COMP_ALL = 15 };
 
 static std::vector<KeySpec> comp_keys(const dimx_dims& d, int comp) {
     std::vector<KeySpec> k;
+    if (d.variant == 1) {
+        if (comp == COMP_VQ0) legacy_speaker_vq_keys(d, k);
+        if (comp == COMP_VQ1) vq_keys(d, 1, k);
+        if (comp == COMP_ENC) xenc_keys(d, "generator.encoder.", (int64_t)d.spk_face_quan_num * d.vq_zdim, k);
+        if (comp == COMP_DEC) {
+            xdec_keys(d, "generator.decoder.net.", k);
+            k.push_back({"generator.decoder.net.pos_emb.emb.weight", {d.max_seq_len, d.dim + d.dim_a}});
+        }
+        return k;
+    }
     if (comp == COMP_VQ0) vq_keys(d, 0, k);
     if (comp == COMP_VQ1) vq_keys(d, 1, k);
     if (comp == COMP_ENC) {
@@ -327,7 +374,9 @@ static int ensure_packed(dimx_ctx* c, int need) {
                      first.c_str());
         if (comp == COMP_VQ0) DIMX_TRY(pack_vq(c, 0));
         if (comp == COMP_VQ1) DIMX_TRY(pack_vq(c, 1));
-        if (comp == COMP_ENC) {
+        if (comp == COMP_ENC && c->variant == 1) {
+            DIMX_TRY(pack_xenc(c, "generator.encoder.", &c->enc_s));
+        } else if (comp == COMP_ENC) {
             DIMX_TRY(pack_xenc(c, "encoder_s.", &c->enc_s));
             DIMX_TRY(pack_xenc(c, "encoder_joint.", &c->enc_joint));
             DIMX_TRY(upload_f32(c, "patch_embed_s", &c->patch_s));
@@ -336,9 +385,10 @@ static int ensure_packed(dimx_ctx* c, int need) {
             DIMX_TRY(upload_f32(c, "norm_s.bias", &c->norm_s_b));
         }
         if (comp == COMP_DEC) {
-            const std::string dp = "decoder_joint.net.";
+            const std::string dp = c->variant == 1 ? "generator.decoder.net." : "decoder_joint.net.";
+            if (c->decg.abs_pos) DIMX_TRY(upload_f32(c, dp + "pos_emb.emb.weight", &c->dec.pos_emb));
             DIMX_TRY(upload_f32(c, dp + "token_emb.emb.weight", &c->dec.tok_emb));
-            for (int i = 0; i < c->d.dec_depth; ++i) {
+            for (int i = 0; i < c->decg.depth; ++i) {
                 DIMX_TRY(pack_xattn(c, xl(dp, 3 * i), false, &c->dec.self_[i]));
                 DIMX_TRY(pack_xattn(c, xl(dp, 3 * i + 1), true, &c->dec.cross[i]));
                 DIMX_TRY(pack_xff(c, xl(dp, 3 * i + 2), &c->dec.ff[i]));
@@ -428,10 +478,10 @@ struct VQScratch {
     int32_t* idx_tmp;
 };
 
-static void plan_vq(const dimx_ctx* c, Arena& ar, int B, int T, VQScratch& s) {
+static void plan_vq(const dimx_ctx* c, const VQGeom& vg, Arena& ar, int B, int T, VQScratch& s) {
     const size_t M = (size_t)B * T, es = es_of(c);
-    const int H = c->d.vq_hidden, I = c->d.vq_inter, Tp = tpad(T);
-    s.xa = ar.take(M * 128 * es);  // padded input (56 -> 64) or codebook rows (128)
+    const int H = vg.hidden, I = vg.inter, Tp = tpad(T);
+    s.xa = ar.take(M * (vg.in_pad > 128 ? vg.in_pad : 128) * es);  // padded input or codebook rows (128)
     s.h1 = ar.take(M * H * es);
     s.conv = (float*)ar.take(M * H * 4);
     s.y = ar.take(M * H * es);
@@ -441,15 +491,15 @@ static void plan_vq(const dimx_ctx* c, Arena& ar, int B, int T, VQScratch& s) {
     s.vt = ar.take((size_t)B * H * Tp * es);
     s.o = ar.take(M * H * es);
     s.f = ar.take(M * I * es);
-    s.z = (float*)ar.take(M * c->d.vq_zdim * 4);
-    s.idx_tmp = (int32_t*)ar.take(M * 4);
+    s.z = (float*)ar.take(M * vg.out_dim * 4);
+    s.idx_tmp = (int32_t*)ar.take(M * vg.fqn * 4);
 }
 
-static int run_vq_blocks(const dimx_ctx* c, const VQBlock* blk, VQScratch& s, int B, int T, const int32_t* lens,
-                         hipStream_t st) {
-    const int M = B * T, Hd = c->d.vq_hidden, heads = c->d.vq_heads, D = Hd / heads, Tp = tpad(T);
+static int run_vq_blocks(const dimx_ctx* c, const VQGeom& vg, const VQBlock* blk, VQScratch& s, int B, int T,
+                         const int32_t* lens, hipStream_t st) {
+    const int M = B * T, Hd = vg.hidden, heads = vg.heads, D = Hd / heads, Tp = tpad(T);
     const float scale = 1.0f / sqrtf((float)Hd);  // hidden^-0.5 (code/models/lib/base_models.py:116)
-    for (int l = 0; l < c->d.vq_layers; ++l) {
+    for (int l = 0; l < vg.layers; ++l) {
         const VQBlock& b = blk[l];
         GemmArgs g;
         DIMX_TRY(launch_layernorm(c->at, s.h, s.y, b.ln1_g, b.ln1_b, M, Hd, st));
@@ -472,9 +522,9 @@ static int run_vq_blocks(const dimx_ctx* c, const VQBlock* blk, VQScratch& s, in
         gemm_lin(c, s.y, Hd, b.l1, M, g);
         g.out_dtype = c->at;
         g.act = ACT_GELU_TANH;
-        gemm_set_plain_out(g, s.f, c->d.vq_inter);
+        gemm_set_plain_out(g, s.f, vg.inter);
         DIMX_TRY(launch_gemm(g, st));
-        gemm_lin(c, s.f, c->d.vq_inter, b.l2, M, g);
+        gemm_lin(c, s.f, vg.inter, b.l2, M, g);
         g.out_dtype = DIMX_F32;
         g.residual = s.h;
         g.ldr = Hd;
@@ -485,10 +535,10 @@ static int run_vq_blocks(const dimx_ctx* c, const VQBlock* blk, VQScratch& s, in
 }
 
 // conv(k5, replicate) + LeakyReLU -> InstanceNorm -> Linear + bias + positional row -> s.h
-static int run_vq_front(const dimx_ctx* c, const void* x_in, int ld_in, const Linear& conv, const Linear& le,
-                        const float* pe, int pe_mode, int row_off, VQScratch& s, int B, int T, const int32_t* lens,
-                        hipStream_t st, int row_div = 1) {
-    const int M = B * T, Hd = c->d.vq_hidden;
+static int run_vq_front(const dimx_ctx* c, const VQGeom& vg, const void* x_in, int ld_in, const Linear& conv,
+                        const Linear& le, const float* pe, int pe_mode, int row_off, VQScratch& s, int B, int T,
+                        const int32_t* lens, hipStream_t st, int row_div = 1) {
+    const int M = B * T, Hd = vg.hidden;
     GemmArgs g;
     gemm_lin(c, x_in, ld_in, conv, M, g);
     g.conv_T = T;
@@ -512,6 +562,32 @@ static int run_vq_front(const dimx_ctx* c, const void* x_in, int ld_in, const Li
     return DIMX_OK;
 }
 
+// features -> z [B*T, out_dim] -> nearest codebook row of every zdim-wide group: idx [B*T*fqn]
+// (code/models/stage1_BIWI.py:152-157 speaker, :282-302 listener; quantizer.py:52-60)
+static int run_vq_encode(const dimx_ctx* c, int which, const float* x, const int32_t* lens, int B, int T, int pe_mode,
+                         int row_off, VQScratch& s, float* z, int32_t* idx, hipStream_t st) {
+    const VQGeom& vg = c->vqg[which];
+    const VQNet& v = c->vq[which];
+    const int M = B * T, Hd = vg.hidden;
+    DIMX_TRY(launch_cast_pad(c->at, x, vg.in_dim, nullptr, s.xa, vg.in_pad, M, vg.in_dim, st));
+    GemmArgs g;
+    gemm_lin(c, s.xa, vg.in_pad, v.vm, M, g);
+    g.out_dtype = c->at;
+    g.act = ACT_LEAKY;
+    gemm_set_plain_out(g, s.h1, Hd);
+    DIMX_TRY(launch_gemm(g, st));
+    DIMX_TRY(run_vq_front(c, vg, s.h1, Hd, v.conv, v.le, v.pe_enc, pe_mode, row_off, s, B, T, lens, st));
+    DIMX_TRY(run_vq_blocks(c, vg, v.enc, s, B, T, lens, st));
+    // post projection consumes the f32 residual stream directly (no final norm in this stack)
+    DIMX_TRY(launch_cast_pad(c->at, s.h, Hd, nullptr, s.y, Hd, M, Hd, st));
+    gemm_lin(c, s.y, Hd, v.post, M, g);
+    g.out_dtype = DIMX_F32;
+    gemm_set_plain_out(g, z, vg.out_dim);
+    DIMX_TRY(launch_gemm(g, st));
+    DIMX_TRY(launch_vq_argmin(z, M * vg.fqn, v.Et, v.ee, idx, nullptr, nullptr, st));
+    return DIMX_OK;
+}
+
 }  // namespace dimx
 
 using namespace dimx;
@@ -522,8 +598,18 @@ extern "C" {
 int dimx_version(void) { return 100; }
 const char* dimx_last_error(void) { return get_error(); }
 
+void dimx_legacy_dims(dimx_dims* d) {
+    if (!d) return;
+    dimx_default_dims(d);
+    d->variant = 1;
+    d->dim_in = 1024; d->dim = 512; d->dim_a = 0; d->enc_depth = 6; d->dec_depth = 6; d->heads = 8;
+    d->max_seq_len = 1024;
+    d->spk_in_dim = 824; d->spk_hidden = 768; d->spk_heads = 8; d->spk_inter = 1536; d->spk_face_quan_num = 8;
+}
+
 void dimx_default_dims(dimx_dims* d) {
     if (!d) return;
+    memset(d, 0, sizeof(*d));
     d->vq_in_dim = 56; d->vq_hidden = 384; d->vq_layers = 6; d->vq_heads = 8; d->vq_inter = 1536;
     d->vq_n_embed = 512; d->vq_zdim = 128;
     d->dim_in = 56; d->dim = 384; d->dim_a = 768; d->enc_depth = 4; d->dec_depth = 4; d->heads = 12;
@@ -539,9 +625,16 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     if (dims) d = *dims;
     DIMX_REQUIRE(d.vq_hidden == 384 && d.vq_heads == 8 && d.vq_zdim == 128 && d.vq_n_embed == 512 && d.vq_in_dim == 56,
                  DIMX_ERR_ARG, "dimx_create: only the DIM-Listener VQ geometry (56/384/8/128/512) is built");
-    DIMX_REQUIRE(d.dim == 384 && d.dim_a == 768 && d.dim_head == 64 && d.heads == 12 && d.num_tokens == 512 &&
-                     d.vq_layers <= 8 && d.enc_depth <= 8 && d.dec_depth <= 8 && d.max_seq_len <= 2048,
-                 DIMX_ERR_ARG, "dimx_create: only the SLMFT geometry (384+768, 12x64, 512 tokens) is built");
+    if (d.variant == 0) {
+        DIMX_REQUIRE(d.dim == 384 && d.dim_a == 768 && d.dim_head == 64 && d.heads == 12 && d.num_tokens == 512 &&
+                         d.vq_layers <= 8 && d.enc_depth <= 8 && d.dec_depth <= 8 && d.max_seq_len <= 2048,
+                     DIMX_ERR_ARG, "dimx_create: only the SLMFT geometry (384+768, 12x64, 512 tokens) is built");
+    } else {
+        DIMX_REQUIRE(d.variant == 1 && d.dim == 512 && d.dim_a == 0 && d.dim_head == 64 && d.heads == 8 &&
+                         d.num_tokens == 512 && d.enc_depth <= 8 && d.dec_depth <= 8 && d.max_seq_len <= 2048 &&
+                         d.spk_hidden == 768 && d.spk_heads == 8 && d.spk_in_dim == 824 && d.spk_face_quan_num == 8,
+                     DIMX_ERR_ARG, "dimx_create: only the legacy ListenerGenerator geometry (824/768 VQ, 512, 8x64) is built");
+    }
     int ndev = 0;
     DIMX_HIP(hipGetDeviceCount(&ndev));
     DIMX_REQUIRE(device_id >= 0 && device_id < ndev, DIMX_ERR_ARG, "dimx_create: device %d of %d", device_id, ndev);
@@ -551,6 +644,21 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     c->d = d;
     c->mode = numeric_mode;
     c->at = numeric_mode == DIMX_MODE_PERF_BF16 ? DIMX_BF16 : DIMX_F32;
+    c->variant = d.variant;
+    const VQGeom lvq = {d.vq_in_dim, 64, d.vq_hidden, d.vq_heads, d.vq_inter, d.vq_layers, d.vq_zdim, 1, d.vq_zdim,
+                        d.vq_n_embed, true};
+    c->vqg[0] = c->vqg[1] = lvq;
+    if (d.variant == 1) {
+        c->vqg[0] = {d.spk_in_dim, (d.spk_in_dim + 63) / 64 * 64, d.spk_hidden, d.spk_heads, d.spk_inter, d.vq_layers,
+                     d.spk_face_quan_num * d.vq_zdim, d.spk_face_quan_num, d.vq_zdim, d.vq_n_embed, false};
+        const int din = d.spk_face_quan_num * d.vq_zdim;
+        c->encg[0] = c->encg[1] = {din, din, d.dim, d.heads, d.dim_head, d.enc_depth, d.ff_mult, 0};
+        c->decg = {d.dim, d.heads, d.dim_head, d.dec_depth, d.ff_mult, 1, d.num_tokens, d.dim};
+    } else {
+        c->encg[0] = {d.dim_in, 64, d.dim, d.heads, d.dim_head, d.enc_depth, d.ff_mult, 1};
+        c->encg[1] = {d.dim, d.dim, d.dim, d.heads, d.dim_head, d.enc_depth, d.ff_mult, 1};
+        c->decg = {d.dim + d.dim_a, d.heads, d.dim_head, d.dec_depth, d.ff_mult, 0, d.num_tokens, d.dim + d.dim_a};
+    }
     for (const auto& k : all_keys(d)) c->required.push_back(k.name);
     const char* ng = getenv("DIMX_NO_GRAPH");
     c->use_graph = (ng && ng[0] == '1') ? 0 : 1;
@@ -653,16 +761,18 @@ struct GenScratch {
 
 static void plan_persist(const dimx_ctx* c, Arena& ar, int B, int T, CtxPersist& p) {
     const size_t es = es_of(c);
-    const size_t per = (size_t)B * c->d.heads * c->d.dim_head * tpad(T) * es;
-    for (int l = 0; l < c->d.dec_depth; ++l) {
+    const size_t per = (size_t)B * c->decg.heads * c->decg.dim_head * tpad(T) * es;
+    for (int l = 0; l < c->decg.depth; ++l) {
         p.ck[l] = ar.take(per);
         p.cv[l] = ar.take(per);
     }
 }
 static void plan_enc(const dimx_ctx* c, Arena& ar, int B, int T, EncScratch& s) {
     const size_t M = (size_t)B * T, es = es_of(c);
-    const int dim = c->d.dim, inner = c->d.heads * c->d.dim_head, Tp = tpad(T);
-    s.xa = ar.take(M * (c->d.dim + c->d.dim_a) * es);  // padded input, later the 1152-wide context
+    const EncGeom& eg = c->encg[0];
+    const int dim = eg.dim, inner = eg.heads * eg.dim_head, Tp = tpad(T);
+    const int wide = c->decg.ctx_dim > eg.in_pad ? c->decg.ctx_dim : eg.in_pad;
+    s.xa = ar.take(M * wide * es);  // padded encoder input, later the decoder's cross-attention context
     s.h = (float*)ar.take(M * dim * 4);
     s.tmp = (float*)ar.take(M * dim * 4);
     s.y = ar.take(M * dim * es);
@@ -670,28 +780,31 @@ static void plan_enc(const dimx_ctx* c, Arena& ar, int B, int T, EncScratch& s) 
     s.k = ar.take(M * inner * es);
     s.vt = ar.take((size_t)B * inner * Tp * es);
     s.o = ar.take(M * inner * es);
-    s.f = ar.take(M * dim * c->d.ff_mult * es);
+    s.f = ar.take(M * dim * eg.ff_mult * es);
 }
+// number of decoder positions: SLMFT feeds / generates T-1 tokens (code/seq2seq_pretrain.py:469,500);
+// the legacy generator is teacher-forced on T-1 tokens but generates seq_len = T (code/seq2seq.py:256,300)
+static inline int gen_steps(const dimx_ctx* c, int T) { return c->variant == 1 ? T : T - 1; }
 static void plan_dec(const dimx_ctx* c, Arena& ar, int B, int T, DecScratch& s) {
     const int n = T - 1;
     const size_t M = (size_t)B * n, es = es_of(c);
-    const int D = c->d.dim + c->d.dim_a, inner = c->d.heads * c->d.dim_head, np = tpad(n);
+    const int D = c->decg.dim, inner = c->decg.heads * c->decg.dim_head, np = tpad(n);
     s.h = (float*)ar.take(M * D * 4);
     s.y = ar.take(M * D * es);
     s.q = ar.take(M * inner * es);
     s.k = ar.take(M * inner * es);
     s.vt = ar.take((size_t)B * inner * np * es);
     s.o = ar.take(M * inner * es);
-    s.f = ar.take(M * D * c->d.ff_mult * es);
+    s.f = ar.take(M * D * c->decg.ff_mult * es);
     s.inp = (int32_t*)ar.take(M * 4);
     s.tgt = (int32_t*)ar.take(M * 4);
     s.kvm = (uint8_t*)ar.take(M);
 }
 static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) {
     const size_t es = es_of(c);
-    const int D = c->d.dim + c->d.dim_a, inner = c->d.heads * c->d.dim_head;
+    const int D = c->decg.dim, inner = c->decg.heads * c->decg.dim_head;
     const size_t per = (size_t)B * inner * T * es;
-    for (int l = 0; l < c->d.dec_depth; ++l) {
+    for (int l = 0; l < c->decg.depth; ++l) {
         s.sk[l] = ar.take(per);
         s.sv[l] = ar.take(per);
     }
@@ -701,13 +814,13 @@ static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) 
     s.st_qkv = (long)B * 3 * inner;
     s.st_qc = (long)B * inner;
     s.st_xr = (long)B * D;
-    s.st_lg = (long)B * c->d.num_tokens;
+    s.st_lg = (long)B * c->decg.num_tokens;
     s.qkv = (float*)ar.take((size_t)kMaxSlabs * s.st_qkv * 4);
     s.qc = (float*)ar.take((size_t)kMaxSlabs * s.st_qc * 4);
     s.xr = (float*)ar.take((size_t)kMaxSlabs * s.st_xr * 4);
     s.o = ar.take((size_t)B * inner * es);
-    s.f = ar.take((size_t)B * D * c->d.ff_mult * es);
-    s.logits = (float*)ar.take((size_t)kMaxSlabs * B * c->d.num_tokens * 4);
+    s.f = ar.take((size_t)B * D * c->decg.ff_mult * es);
+    s.logits = (float*)ar.take((size_t)kMaxSlabs * B * c->decg.num_tokens * 4);
     s.step = (int32_t*)ar.take(64 * dimx_ctx::kMaxGroups);  // one counter per clip group, 64 B apart
 }
 
@@ -717,16 +830,21 @@ static size_t workspace_bytes(const dimx_ctx* c, int B, int T, int S = 1) {
     plan_persist(c, p, B, T, cp);
     const size_t persist = align_up(p.off, 256);
     size_t scratch = 0;
-    {
+    for (int w = 0; w < 2; ++w) {
         Arena a(nullptr, 0);
         VQScratch s;
-        plan_vq(c, a, B, T, s);
+        plan_vq(c, c->vqg[w], a, B, T, s);
         scratch = a.off > scratch ? a.off : scratch;
     }
     {
         Arena a(nullptr, 0);
         EncScratch s;
         plan_enc(c, a, B, T, s);
+        if (c->variant == 1) {  // the speaker VQ-VAE runs inside encode_ctx, next to the encoder buffers
+            VQScratch v;
+            plan_vq(c, c->vqg[0], a, B, T, v);
+            a.take((size_t)B * 4);
+        }
         scratch = a.off > scratch ? a.off : scratch;
     }
     if (T >= 2) {
@@ -743,9 +861,9 @@ static size_t workspace_bytes(const dimx_ctx* c, int B, int T, int S = 1) {
 }
 
 // x-transformers encoder stack (ContinuousTransformerWrapper, return_embeddings=True)
-static int run_xenc(const dimx_ctx* c, const XEnc& e, const void* x_in, int ld_in, EncScratch& s, int B, int T,
-                    const uint8_t* mask, int out_dtype, void* out, hipStream_t st) {
-    const int M = B * T, dim = c->d.dim, heads = c->d.heads, D = c->d.dim_head, inner = heads * D, Tp = tpad(T);
+static int run_xenc(const dimx_ctx* c, const EncGeom& eg, const XEnc& e, const void* x_in, int ld_in, EncScratch& s,
+                    int B, int T, const uint8_t* mask, int out_dtype, void* out, hipStream_t st) {
+    const int M = B * T, dim = eg.dim, heads = eg.heads, D = eg.dim_head, inner = heads * D, Tp = tpad(T);
     GemmArgs g;
     gemm_lin(c, x_in, ld_in, e.proj_in, M, g);
     g.out_dtype = DIMX_F32;
@@ -756,7 +874,7 @@ static int run_xenc(const dimx_ctx* c, const XEnc& e, const void* x_in, int ld_i
     g.rowadd_scale = 1.0f / sqrtf((float)dim);
     gemm_set_plain_out(g, s.h, dim);
     DIMX_TRY(launch_gemm(g, st));
-    for (int l = 0; l < c->d.enc_depth; ++l) {
+    for (int l = 0; l < eg.depth; ++l) {
         DIMX_TRY(launch_layernorm(c->at, s.h, s.y, e.attn[l].ln_g, nullptr, M, dim, st));
         gemm_lin(c, s.y, dim, e.attn[l].qkv, M, g);
         g.out_dtype = c->at;
@@ -765,7 +883,7 @@ static int run_xenc(const dimx_ctx* c, const XEnc& e, const void* x_in, int ld_i
         AttnArgs a;
         set_attn_packed(a, c->at, s.q, s.k, s.vt, s.o, B, heads, T, T, D, Tp);
         a.scale = 1.0f / sqrtf((float)D);
-        a.causal = 1;
+        a.causal = eg.causal;
         a.kmask = mask;
         a.kmask_ld = T;
         DIMX_TRY(launch_attention(a, st));
@@ -779,9 +897,9 @@ static int run_xenc(const dimx_ctx* c, const XEnc& e, const void* x_in, int ld_i
         gemm_lin(c, s.y, dim, e.ff[l].f1, M, g);
         g.out_dtype = c->at;
         g.act = ACT_GELU_ERF;
-        gemm_set_plain_out(g, s.f, dim * c->d.ff_mult);
+        gemm_set_plain_out(g, s.f, dim * eg.ff_mult);
         DIMX_TRY(launch_gemm(g, st));
-        gemm_lin(c, s.f, dim * c->d.ff_mult, e.ff[l].f2, M, g);
+        gemm_lin(c, s.f, dim * eg.ff_mult, e.ff[l].f2, M, g);
         g.out_dtype = DIMX_F32;
         g.residual = s.h;
         g.ldr = dim;
@@ -803,6 +921,12 @@ static int check_common(dimx_handle h, int B, int T, void* ws, size_t ws_bytes, 
     DIMX_TRY(ensure_packed(h, need));
     return DIMX_OK;
 }
+
+int project_cross_kv(dimx_handle h, const void* ctx, const CtxPersist& cp, int B, int T, int for_generate,
+                     hipStream_t st);
+int legacy_encode_ctx(dimx_handle h, const float* v_speaker, const uint8_t* mask, int B, int T, int for_generate,
+                      float* enc_out, float* x_speaker_out, int32_t* idx_out, void* ws, size_t ws_bytes,
+                      hipStream_t st);
 
 static Arena scratch_arena(const dimx_ctx* c, void* ws, size_t ws_bytes, int B, int T, CtxPersist* cp) {
     Arena p(ws, ws_bytes);
@@ -842,30 +966,13 @@ int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens
     DIMX_REQUIRE(x && idx, DIMX_ERR_ARG, "vq_encode: null argument");
     DIMX_REQUIRE(pe_mode == 0 || B + batch_row_offset <= 5000, DIMX_ERR_ARG, "vq_encode: positional row out of range");
     hipStream_t st = (hipStream_t)stream;
-    const VQNet& v = h->vq[which];
+    const VQGeom& vg = h->vqg[which];
     Arena ar = scratch_arena(h, ws, ws_bytes, B, T, nullptr);
     VQScratch s;
-    plan_vq(h, ar, B, T, s);
+    plan_vq(h, vg, ar, B, T, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_encode: workspace overflow");
-    const int M = B * T, Hd = h->d.vq_hidden;
-    DIMX_TRY(launch_cast_pad(h->at, x, h->d.vq_in_dim, nullptr, s.xa, 64, M, h->d.vq_in_dim, st));
-    GemmArgs g;
-    gemm_lin(h, s.xa, 64, v.vm, M, g);
-    g.out_dtype = h->at;
-    g.act = ACT_LEAKY;
-    gemm_set_plain_out(g, s.h1, Hd);
-    DIMX_TRY(launch_gemm(g, st));
-    DIMX_TRY(run_vq_front(h, s.h1, Hd, v.conv, v.le, v.pe_enc, pe_mode, batch_row_offset, s, B, T, lens, st));
-    DIMX_TRY(run_vq_blocks(h, v.enc, s, B, T, lens, st));
-    // post projection consumes the f32 residual stream directly (no final norm in this stack)
-    DIMX_TRY(launch_cast_pad(h->at, s.h, Hd, nullptr, s.y, Hd, M, Hd, st));
-    gemm_lin(h, s.y, Hd, v.post, M, g);
-    g.out_dtype = DIMX_F32;
-    float* z = z_out ? z_out : s.z;
-    gemm_set_plain_out(g, z, h->d.vq_zdim);
-    DIMX_TRY(launch_gemm(g, st));
-    DIMX_TRY(launch_vq_argmin(z, M, v.Et, v.ee, idx, nullptr, nullptr, st));
-    DIMX_TRY(launch_finalize_idx(idx, lens, B, T, pad_value, st));
+    DIMX_TRY(run_vq_encode(h, which, x, lens, B, T, pe_mode, batch_row_offset, s, z_out ? z_out : s.z, idx, st));
+    DIMX_TRY(launch_finalize_idx(idx, lens, B, T, pad_value, st, vg.fqn));
     return DIMX_OK;
 }
 
@@ -878,30 +985,36 @@ int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, i
                  "vq_decode: positional row %d out of range", B + batch_row_offset);
     hipStream_t st = (hipStream_t)stream;
     const VQNet& v = h->vq[which];
+    const VQGeom& vg = h->vqg[which];
+    DIMX_REQUIRE(vg.has_decoder, DIMX_ERR_ARG, "vq_decode: this variant's VQ-VAE %d has no decoder on the path", which);
     Arena ar = scratch_arena(h, ws, ws_bytes, B, L, nullptr);
     VQScratch s;
-    plan_vq(h, ar, B, L, s);
+    plan_vq(h, vg, ar, B, L, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_decode: workspace overflow");
-    const int M = B * L, Hd = h->d.vq_hidden, zd = h->d.vq_zdim;
-    DIMX_TRY(launch_gather_rows(h->at, v.E, zd, h->d.vq_n_embed, idx, s.xa, zd, M, zd, st));
+    const int M = B * L, Hd = vg.hidden, zd = vg.zdim;
+    DIMX_TRY(launch_gather_rows(h->at, v.E, zd, vg.n_embed, idx, s.xa, zd, M, zd, st));
     GemmArgs g;
     gemm_lin(h, s.xa, zd, v.pre, M, g);
     g.out_dtype = h->at;
     gemm_set_plain_out(g, s.h1, Hd);
     DIMX_TRY(launch_gemm(g, st));
     DIMX_REQUIRE(rows_per_clip >= 1, DIMX_ERR_ARG, "vq_decode: rows_per_clip must be >= 1");
-    DIMX_TRY(run_vq_front(h, s.h1, Hd, v.dconv, v.dle, v.pe_dec, 1, batch_row_offset, s, B, L, nullptr, st, rows_per_clip));
-    DIMX_TRY(run_vq_blocks(h, v.dec, s, B, L, nullptr, st));
+    DIMX_TRY(run_vq_front(h, vg, s.h1, Hd, v.dconv, v.dle, v.pe_dec, 1, batch_row_offset, s, B, L, nullptr, st,
+                          rows_per_clip));
+    DIMX_TRY(run_vq_blocks(h, vg, v.dec, s, B, L, nullptr, st));
     DIMX_TRY(launch_cast_pad(h->at, s.h, Hd, nullptr, s.y, Hd, M, Hd, st));
     gemm_lin(h, s.y, Hd, v.rev, M, g);
     g.out_dtype = DIMX_F32;
-    gemm_set_plain_out(g, out, h->d.vq_in_dim);
+    gemm_set_plain_out(g, out, vg.in_dim);
     DIMX_TRY(launch_gemm(g, st));
     return DIMX_OK;
 }
 
 int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio, const uint8_t* mask, int B, int T,
                     int for_generate, float* x_s_out, void* ws, size_t ws_bytes, void* stream) {
+    if (h && h->variant == 1)
+        return legacy_encode_ctx(h, v_speaker, mask, B, T, for_generate, x_s_out, nullptr, nullptr, ws, ws_bytes,
+                                 (hipStream_t)stream);
     DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_ENC | COMP_DEC));
     DIMX_REQUIRE(v_speaker && v_audio && mask, DIMX_ERR_ARG, "encode_ctx: null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -910,11 +1023,11 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
     EncScratch s;
     plan_enc(h, ar, B, T, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "encode_ctx: workspace overflow");
-    const int M = B * T, dim = h->d.dim, dim_a = h->d.dim_a, D = h->d.dim_head, heads = h->d.heads, Tp = tpad(T);
+    const int M = B * T, dim = h->d.dim, dim_a = h->d.dim_a;
     // v_speaker + patch_embed_s, padded 56 -> 64
     DIMX_TRY(launch_cast_pad(h->at, v_speaker, h->d.dim_in, h->patch_s, s.xa, 64, M, h->d.dim_in, st));
-    DIMX_TRY(run_xenc(h, h->enc_s, s.xa, 64, s, B, T, mask, h->at, s.xa, st));  // encoder_s output reuses xa
-    DIMX_TRY(run_xenc(h, h->enc_joint, s.xa, dim, s, B, T, mask, DIMX_F32, s.tmp, st));
+    DIMX_TRY(run_xenc(h, h->encg[0], h->enc_s, s.xa, 64, s, B, T, mask, h->at, s.xa, st));  // output reuses xa
+    DIMX_TRY(run_xenc(h, h->encg[1], h->enc_joint, s.xa, dim, s, B, T, mask, DIMX_F32, s.tmp, st));
     float* x_s = x_s_out ? x_s_out : s.tmp;
     // norm_s = nn.LayerNorm(dim) with bias (code/seq2seq_pretrain.py:411,441); in place when no copy is wanted
     {
@@ -923,9 +1036,34 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
         x_s = dst;
     }
     DIMX_TRY(launch_context_concat(h->at, x_s, h->patch_dec_s, v_audio, s.xa, M, dim, dim_a, st));
-    for (int l = 0; l < h->d.dec_depth; ++l) {
+    DIMX_TRY(project_cross_kv(h, s.xa, cp, B, T, for_generate, st));
+    h->ctx_ready = true;
+    h->ctx_B = B;
+    h->ctx_T = T;
+    h->ctx_for_generate = for_generate ? 1 : 0;
+    h->ctx_ws = ws;
+    return DIMX_OK;
+}
+
+int dimx_legacy_speaker_features(dimx_handle h, const float* v_speaker, const uint8_t* mask, int B, int T,
+                                 float* x_speaker_out, int32_t* idx_out, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(h && h->variant == 1, DIMX_ERR_ARG, "legacy_speaker_features: handle is not the legacy variant");
+    DIMX_REQUIRE(x_speaker_out || idx_out, DIMX_ERR_ARG, "legacy_speaker_features: no output requested");
+    return legacy_encode_ctx(h, v_speaker, mask, B, T, -1, nullptr, x_speaker_out, idx_out, ws, ws_bytes,
+                             (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace dimx {
+
+// K / V of every decoder layer's cross-attention from the [B*T, ctx_dim] context (row-major, operand type)
+int project_cross_kv(dimx_handle h, const void* ctx, const CtxPersist& cp, int B, int T, int for_generate,
+                     hipStream_t st) {
+    const int M = B * T, D = h->decg.dim_head, heads = h->decg.heads, Tp = tpad(T);
+    for (int l = 0; l < h->decg.depth; ++l) {
         GemmArgs g;
-        gemm_lin(h, s.xa, dim + dim_a, h->dec.cross[l].kv, M, g);
+        gemm_lin(h, ctx, h->decg.ctx_dim, h->dec.cross[l].kv, M, g);
         g.out_dtype = h->at;
         g.rowT = T;
         g.nseg = 2;
@@ -955,6 +1093,44 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
         }
         DIMX_TRY(launch_gemm(g, st));
     }
+    return DIMX_OK;
+}
+
+// Legacy ListenerGenerator context (code/seq2seq.py:224-249): per-clip speaker VQ-VAE encode of the valid
+// frames -> code vectors -> the channel-major re-view -> 6-layer bidirectional encoder -> cross K/V.
+// for_generate < 0: stop after x_speaker (test hook behind dimx_legacy_speaker_features).
+int legacy_encode_ctx(dimx_handle h, const float* v_speaker, const uint8_t* mask, int B, int T, int for_generate,
+                      float* enc_out, float* x_speaker_out, int32_t* idx_out, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, for_generate < 0 ? COMP_VQ0 : (COMP_VQ0 | COMP_ENC | COMP_DEC)));
+    DIMX_REQUIRE(v_speaker && mask, DIMX_ERR_ARG, "encode_ctx: null argument");
+    CtxPersist cp;
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, T, &cp);
+    EncScratch s;
+    VQScratch v;
+    plan_enc(h, ar, B, T, s);
+    plan_vq(h, h->vqg[0], ar, B, T, v);
+    int32_t* lens = (int32_t*)ar.take((size_t)B * 4);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "encode_ctx: workspace overflow");
+    const VQGeom& vg = h->vqg[0];
+    const EncGeom& eg = h->encg[0];
+    const int M = B * T;
+    DIMX_TRY(launch_mask_lens(mask, lens, B, T, st));
+    // batch-1 encodes in the reference -> positional row 0 for every clip (pe_mode 0)
+    DIMX_TRY(run_vq_encode(h, 0, v_speaker, lens, B, T, 0, 0, v, v.z, v.idx_tmp, st));
+    if (idx_out) {
+        DIMX_HIP(hipMemcpyAsync(idx_out, v.idx_tmp, (size_t)M * vg.fqn * 4, hipMemcpyDeviceToDevice, st));
+        DIMX_TRY(launch_finalize_idx(idx_out, lens, B, T, -100, st, vg.fqn));
+    }
+    if (x_speaker_out)
+        DIMX_TRY(launch_legacy_scramble(DIMX_F32, h->vq[0].E, v.idx_tmp, lens, x_speaker_out, B, T, vg.fqn, vg.zdim,
+                                        vg.n_embed, st));
+    if (for_generate < 0) return DIMX_OK;
+    DIMX_TRY(launch_legacy_scramble(h->at, h->vq[0].E, v.idx_tmp, lens, s.xa, B, T, vg.fqn, vg.zdim, vg.n_embed, st));
+    // encoder output (final-normed) is the decoder context; keep an f32 copy for the caller if asked
+    DIMX_TRY(run_xenc(h, eg, h->enc_s, s.xa, eg.in_pad, s, B, T, mask, h->at, s.y, st));
+    if (enc_out) DIMX_TRY(launch_layernorm(DIMX_F32, s.h, enc_out, h->enc_s.final_g, nullptr, M, eg.dim, st));
+    DIMX_TRY(project_cross_kv(h, s.y, cp, B, T, for_generate, st));
     h->ctx_ready = true;
     h->ctx_B = B;
     h->ctx_T = T;
@@ -962,6 +1138,10 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
     h->ctx_ws = ws;
     return DIMX_OK;
 }
+
+}  // namespace dimx
+
+extern "C" {
 
 int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, const uint8_t* kv_mask, int B, int T,
                    float* logits, float* row_loss, int32_t* argmax_tok, void* ws, size_t ws_bytes, void* stream) {
@@ -975,12 +1155,14 @@ int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, c
     DecScratch s;
     plan_dec(h, ar, B, T, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "decode_tf: workspace overflow");
-    const int n = T - 1, M = B * n, DD = h->d.dim + h->d.dim_a, heads = h->d.heads, D = h->d.dim_head;
-    const int inner = heads * D, np = tpad(n), Tp = tpad(T), V = h->d.num_tokens;
+    const DecGeom& dg = h->decg;
+    const int n = T - 1, M = B * n, DD = dg.dim, heads = dg.heads, D = dg.dim_head;
+    const int inner = heads * D, np = tpad(n), Tp = tpad(T), V = dg.num_tokens;
     DIMX_TRY(launch_shift_tokens(z_l, s.inp, s.tgt, B, T, st));
     DIMX_TRY(launch_gather_rows(DIMX_F32, h->dec.tok_emb, DD, V, s.inp, s.h, DD, M, DD, st));
+    if (dg.abs_pos) DIMX_TRY(launch_add_pos_rows(s.h, h->dec.pos_emb, M, n, DD, 1.0f / sqrtf((float)DD), st));
     const float scale = 1.0f / sqrtf((float)D);
-    for (int l = 0; l < h->d.dec_depth; ++l) {
+    for (int l = 0; l < dg.depth; ++l) {
         GemmArgs g;
         AttnArgs a;
         // causal self attention (+ AutoregressiveWrapper's random key mask)
@@ -1023,9 +1205,9 @@ int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, c
         gemm_lin(h, s.y, DD, h->dec.ff[l].f1, M, g);
         g.out_dtype = h->at;
         g.act = ACT_GELU_ERF;
-        gemm_set_plain_out(g, s.f, DD * h->d.ff_mult);
+        gemm_set_plain_out(g, s.f, DD * dg.ff_mult);
         DIMX_TRY(launch_gemm(g, st));
-        gemm_lin(h, s.f, DD * h->d.ff_mult, h->dec.ff[l].f2, M, g);
+        gemm_lin(h, s.f, DD * dg.ff_mult, h->dec.ff[l].f2, M, g);
         g.out_dtype = DIMX_F32;
         g.residual = s.h;
         g.ldr = DD;
@@ -1052,8 +1234,11 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
                     const uint8_t* ctx_mask, int row0, int B, int Btot, int grp, int T, float temperature, int top_k,
                     const float* noise, uint64_t seed, int32_t* tokens, float* logits_out, hipStream_t st,
                     bool embed_only = false, int S = 1) {
-    const int DD = h->d.dim + h->d.dim_a, heads = h->d.heads, D = h->d.dim_head, inner = heads * D;
-    const int V = h->d.num_tokens, n = T - 1, Tp = tpad(T);
+    const DecGeom& dg = h->decg;
+    const int DD = dg.dim, heads = dg.heads, D = dg.dim_head, inner = heads * D;
+    const int V = dg.num_tokens, n = gen_steps(h, T), Tp = tpad(T);
+    const float* pos = dg.abs_pos ? h->dec.pos_emb : nullptr;
+    const float pos_scale = 1.0f / sqrtf((float)DD);
     const size_t es = es_of(h);
     const float scale = 1.0f / sqrtf((float)D);
     // this group's slices of every per-clip buffer
@@ -1065,7 +1250,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     s.qc = s0.qc + (size_t)row0 * inner;
     s.xr = s0.xr + (size_t)row0 * DD;
     s.o = boff(s0.o, inner * es);
-    s.f = boff(s0.f, (size_t)DD * h->d.ff_mult * es);
+    s.f = boff(s0.f, (size_t)DD * dg.ff_mult * es);
     s.logits = s0.logits + (size_t)row0 * V;
     s.step = s0.step + 16 * grp;
     // with S samples per clip, rows are samples (row = clip * S + sample); start / mask / cross K/V are per clip
@@ -1075,7 +1260,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     tokens += (size_t)row0 * n;
     if (logits_out) logits_out += (size_t)row0 * n * V;
     if (embed_only) {  // step 0 input = embedding of the start token (later steps: fused into the sampler)
-        return launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, S, st);
+        return launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, S, st, pos, pos_scale);
     }
     // Every projection whose output is a small [B, N] f32 matrix is a split-K GEMM writing per-split slabs;
     // the consumer (LayerNorm / attention / sampler) adds the slabs in order: deterministic, no atomics, and
@@ -1092,7 +1277,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         return launch_gemm(g, st);
     };
     int pending = 0;  // slabs of the previous residual projection not yet folded into x
-    for (int l = 0; l < h->d.dec_depth; ++l) {
+    for (int l = 0; l < dg.depth; ++l) {
         GemmArgs g;
         DecodeAttnArgs a;
         int ns = 0;
@@ -1148,15 +1333,16 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         gemm_lin(h, s.y, DD, h->dec.ff[l].f1, B, g);
         g.out_dtype = h->at;
         g.act = ACT_GELU_ERF;
-        gemm_set_plain_out(g, s.f, DD * h->d.ff_mult);
+        gemm_set_plain_out(g, s.f, DD * dg.ff_mult);
         DIMX_TRY(launch_gemm(g, st));
-        DIMX_TRY(slab_gemm(s.f, DD * h->d.ff_mult, h->dec.ff[l].f2, s.xr, s0.st_xr, &pending));
+        DIMX_TRY(slab_gemm(s.f, DD * dg.ff_mult, h->dec.ff[l].f2, s.xr, s0.st_xr, &pending));
     }
     DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.final_g, B, DD, st));
     int nlg = 0;
     DIMX_TRY(slab_gemm(s.y, DD, h->dec.logits, s.logits, s0.st_lg, &nlg));
     DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, nlg, s0.st_lg,
-                           logits_out, n, row0, Btot, h->dec.tok_emb, DD, s.x, s.step, (unsigned*)(s.step + 8), st));
+                           logits_out, n, row0, Btot, h->dec.tok_emb, DD, s.x, s.step, (unsigned*)(s.step + 8), st, pos,
+                           pos_scale, n));
     return DIMX_OK;
 }
 
@@ -1181,7 +1367,7 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     const int R = B * S;  // sequences generated in this call
     plan_gen(h, ar, R, T, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "generate: workspace overflow");
-    const int n = T - 1;
+    const int n = gen_steps(h, T);
     DIMX_HIP(hipMemsetAsync(s.step, 0, 64 * dimx_ctx::kMaxGroups, st));
     // Independent clip groups run as separate step graphs on separate streams: every decode kernel is
     // latency-bound at these sizes, so two groups in flight let one group's GEMM/LayerNorm chain overlap the

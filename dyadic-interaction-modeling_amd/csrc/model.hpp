@@ -50,10 +50,23 @@ struct XEnc {
 };
 struct XDec {
     const float* tok_emb = nullptr;  // [num_tokens][dec_dim]
+    const float* pos_emb = nullptr;  // [max_seq_len][dec_dim] (legacy decoder: use_abs_pos_emb=True)
     XAttn self_[8], cross[8];
     XFF ff[8];
     const float* final_g = nullptr;
     Linear logits;
+};
+
+// geometry of the three network families of a handle (variant 0 = SLMFT, 1 = legacy ListenerGenerator)
+struct VQGeom {
+    int in_dim, in_pad, hidden, heads, inter, layers, out_dim, fqn, zdim, n_embed;
+    bool has_decoder;
+};
+struct EncGeom {
+    int dim_in, in_pad, dim, heads, dim_head, depth, ff_mult, causal;
+};
+struct DecGeom {
+    int dim, heads, dim_head, depth, ff_mult, abs_pos, num_tokens, ctx_dim;
 };
 
 struct HostTensor {
@@ -97,6 +110,10 @@ struct GraphKey {
 struct dimx_ctx {
     int device = 0;
     dimx_dims d;
+    int variant = 0;
+    dimx::VQGeom vqg[2];
+    dimx::EncGeom encg[2];  // SLMFT: encoder_s, encoder_joint; legacy: generator.encoder only
+    dimx::DecGeom decg;
     int mode = 0;
     int at = DIMX_F32;  // operand storage type of GEMM/attention inputs
     std::map<std::string, dimx::HostTensor> host;

@@ -1,4 +1,4 @@
-// norm.hip -- LayerNorm (rows of 384 / 1152 f32) and InstanceNorm1d over time.
+// norm.hip -- LayerNorm (rows of 384 / 512 / 768 / 1152 f32) and InstanceNorm1d over time.
 //
 // LayerNorm: reference nn.LayerNorm(eps=1e-5) in code/models/lib/base_models.py:13 (VQ blocks, with
 // bias) and x-transformers' bias-free LayerNorm (pre-norms / final_norm of every encoder/decoder
@@ -117,14 +117,18 @@ __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restr
 int launch_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
                                const float* gamma, int M, int C, hipStream_t s) {
     DIMX_REQUIRE(x && y && gamma && M > 0 && (nslab == 0 || slabs), DIMX_ERR_ARG, "add_slabs_layernorm: null operand");
-    DIMX_REQUIRE(C == 1152 || C == 384, DIMX_ERR_ARG, "add_slabs_layernorm: C=%d", C);
+    DIMX_REQUIRE(C == 1152 || C == 384 || C == 512 || C == 768, DIMX_ERR_ARG, "add_slabs_layernorm: C=%d", C);
     dim3 grid(ceil_div(M, 4)), block(256);
 #define ASL(OT, CC) hipLaunchKernelGGL((add_slabs_layernorm_kernel<OT, CC>), grid, block, 0, s, x, slabs, nslab, slab_stride, (OT*)y, gamma, M)
-    if (out_dtype == DIMX_BF16) {
-        if (C == 384) ASL(bf16, 384); else ASL(bf16, 1152);
-    } else {
-        if (C == 384) ASL(float, 384); else ASL(float, 1152);
-    }
+#define ASL_C(OT)                      \
+    do {                               \
+        if (C == 384) ASL(OT, 384);    \
+        else if (C == 512) ASL(OT, 512); \
+        else if (C == 768) ASL(OT, 768); \
+        else ASL(OT, 1152);            \
+    } while (0)
+    if (out_dtype == DIMX_BF16) ASL_C(bf16); else ASL_C(float);
+#undef ASL_C
 #undef ASL
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
@@ -133,14 +137,19 @@ int launch_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int 
 int launch_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta, int M, int C,
                      hipStream_t s) {
     DIMX_REQUIRE(x && y && gamma && M > 0, DIMX_ERR_ARG, "layernorm: null operand");
-    DIMX_REQUIRE(C == 384 || C == 1152, DIMX_ERR_ARG, "layernorm: C=%d not in {384,1152}", C);
+    DIMX_REQUIRE(C == 384 || C == 1152 || C == 512 || C == 768, DIMX_ERR_ARG,
+                 "layernorm: C=%d not in {384,512,768,1152}", C);
     dim3 grid(ceil_div(M, 4)), block(256);
 #define LN_LAUNCH(OT, CC) hipLaunchKernelGGL((layernorm_kernel<OT, CC>), grid, block, 0, s, x, (OT*)y, gamma, beta, M)
-    if (out_dtype == DIMX_BF16) {
-        if (C == 384) LN_LAUNCH(bf16, 384); else LN_LAUNCH(bf16, 1152);
-    } else {
-        if (C == 384) LN_LAUNCH(float, 384); else LN_LAUNCH(float, 1152);
-    }
+#define LN_C(OT)                             \
+    do {                                     \
+        if (C == 384) LN_LAUNCH(OT, 384);    \
+        else if (C == 512) LN_LAUNCH(OT, 512); \
+        else if (C == 768) LN_LAUNCH(OT, 768); \
+        else LN_LAUNCH(OT, 1152);            \
+    } while (0)
+    if (out_dtype == DIMX_BF16) LN_C(bf16); else LN_C(float);
+#undef LN_C
 #undef LN_LAUNCH
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;

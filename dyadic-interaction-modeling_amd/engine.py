@@ -13,7 +13,9 @@ from . import lib as L
 
 
 class Engine:
-    def __init__(self, device=None, mode=L.MODE_PARITY_F32):
+    def __init__(self, device=None, mode=L.MODE_PARITY_F32, variant="slmft"):
+        """variant: "slmft" (DIM-Listener, code/seq2seq_pretrain.py) or "legacy" (ListenerGenerator,
+        code/seq2seq.py)."""
         if not torch.cuda.is_available():
             raise L.DimxError("dimx needs a ROCm GPU (torch.cuda.is_available() is False); "
                               "there is no CPU fallback")
@@ -22,7 +24,9 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = L.load()
         self.mode = mode
-        self.dims = L.default_dims()
+        assert variant in ("slmft", "legacy")
+        self.variant = variant
+        self.dims = L.default_dims() if variant == "slmft" else L.legacy_dims()
         h = ctypes.c_void_p()
         L.check(self.lib.dimx_create(ctypes.byref(h), self.device.index, ctypes.byref(self.dims), mode),
                 "dimx_create")
@@ -88,8 +92,9 @@ class Engine:
         B, T, _ = x.shape
         x = x.to(torch.float32).contiguous()
         self._chk(x, lens)
-        idx = torch.empty(B, T, dtype=torch.int32, device=self.device)
-        z = torch.empty(B, T, self.dims.vq_zdim, dtype=torch.float32, device=self.device) if return_z else None
+        fqn = self.dims.spk_face_quan_num if (self.variant == "legacy" and which == 0) else 1
+        idx = torch.empty(B, T * fqn, dtype=torch.int32, device=self.device)
+        z = torch.empty(B, T, fqn * self.dims.vq_zdim, dtype=torch.float32, device=self.device) if return_z else None
         ws, wsb = self.workspace(B, T)
         L.check(self.lib.dimx_vq_encode(self.h, which, L.ptr(x), L.ptr(lens), B, T, pe_mode, row_offset,
                                         pad_value, L.ptr(idx), L.ptr(z), ws, wsb, self._s()), "dimx_vq_encode")
@@ -118,7 +123,9 @@ class Engine:
     def encode_ctx(self, v_speaker, v_audio, mask_u8, for_generate, return_x_s=False, n_samples=1):
         B, T, _ = v_speaker.shape
         v_speaker = v_speaker.to(torch.float32).contiguous()
-        v_audio = v_audio.to(torch.float32).contiguous()
+        v_audio = v_audio.to(torch.float32).contiguous() if v_audio is not None else None
+        if self.variant == "slmft" and v_audio is None:
+            raise L.DimxError("encode_ctx: the SLMFT variant needs v_audio")
         self._chk(v_speaker, v_audio, mask_u8)
         x_s = torch.empty(B, T, self.dims.dim, dtype=torch.float32, device=self.device) if return_x_s else None
         ws, wsb = self.workspace(B, T, n_samples)   # the generate call that follows must see the same workspace
@@ -126,6 +133,25 @@ class Engine:
                                          1 if for_generate else 0, L.ptr(x_s), ws, wsb, self._s()),
                 "dimx_encode_ctx")
         return x_s
+
+    def legacy_speaker_features(self, v_speaker, mask_u8, return_idx=False):
+        """x_speaker [B,T,1024] of ListenerGenerator.forward (code/seq2seq.py:224-241); v_speaker must hold each
+        clip's valid frames first."""
+        B, T, _ = v_speaker.shape
+        v_speaker = v_speaker.to(torch.float32).contiguous()
+        self._chk(v_speaker, mask_u8)
+        fqn = self.dims.spk_face_quan_num
+        x = torch.empty(B, T, fqn * self.dims.vq_zdim, dtype=torch.float32, device=self.device)
+        idx = torch.empty(B, T * fqn, dtype=torch.int32, device=self.device) if return_idx else None
+        ws, wsb = self.workspace(B, T)
+        L.check(self.lib.dimx_legacy_speaker_features(self.h, L.ptr(v_speaker), L.ptr(mask_u8), B, T, L.ptr(x),
+                                                      L.ptr(idx), ws, wsb, self._s()),
+                "dimx_legacy_speaker_features")
+        return (x, idx) if return_idx else x
+
+    def n_gen(self, T):
+        """tokens generated per sequence: T-1 (SLMFT) / T (legacy, code/seq2seq.py:300)."""
+        return T if self.variant == "legacy" else T - 1
 
     def decode_tf(self, z_l, mask_u8, kv_mask_u8=None):
         B, T = z_l.shape
@@ -148,10 +174,11 @@ class Engine:
         start = start.to(torch.int32).contiguous()
         if noise is not None:
             noise = noise.to(torch.float32).contiguous()
-            assert tuple(noise.shape) == (T - 1, R, self.dims.num_tokens)
+            assert tuple(noise.shape) == (self.n_gen(T), R, self.dims.num_tokens)
         self._chk(start, mask_u8, noise)
-        tokens = torch.empty(R, T - 1, dtype=torch.int32, device=self.device)
-        lg = torch.empty(R, T - 1, self.dims.num_tokens, dtype=torch.float32, device=self.device) \
+        n = self.n_gen(T)
+        tokens = torch.empty(R, n, dtype=torch.int32, device=self.device)
+        lg = torch.empty(R, n, self.dims.num_tokens, dtype=torch.float32, device=self.device) \
             if return_logits else None
         ws, wsb = self.workspace(B, T, n_samples)
         L.check(self.lib.dimx_generate(self.h, L.ptr(start), L.ptr(mask_u8), B, T, int(n_samples), float(temperature),

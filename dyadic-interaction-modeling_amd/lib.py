@@ -28,7 +28,8 @@ class Dims(ctypes.Structure):
     _fields_ = [(n, c_int) for n in (
         "vq_in_dim", "vq_hidden", "vq_layers", "vq_heads", "vq_inter", "vq_n_embed", "vq_zdim",
         "dim_in", "dim", "dim_a", "enc_depth", "dec_depth", "heads", "dim_head", "num_tokens",
-        "max_seq_len", "ff_mult")]
+        "max_seq_len", "ff_mult", "variant", "spk_in_dim", "spk_hidden", "spk_heads", "spk_inter",
+        "spk_face_quan_num")]
 
 
 class WeightDesc(ctypes.Structure):
@@ -40,6 +41,7 @@ SIGNATURES = {
     "dimx_version": (c_int, []),
     "dimx_last_error": (c_char_p, []),
     "dimx_default_dims": (None, [POINTER(Dims)]),
+    "dimx_legacy_dims": (None, [POINTER(Dims)]),
     "dimx_create": (c_int, [POINTER(c_void_p), c_int, POINTER(Dims), c_int]),
     "dimx_destroy": (c_int, [c_void_p]),
     "dimx_numeric_mode": (c_int, [c_void_p]),
@@ -54,6 +56,8 @@ SIGNATURES = {
                                c_void_p]),
     "dimx_encode_ctx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
+    "dimx_legacy_speaker_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                             c_void_p, c_size_t, c_void_p]),
     "dimx_decode_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_uint64,
@@ -115,4 +119,10 @@ def stream_ptr(device=None):
 def default_dims():
     d = Dims()
     load().dimx_default_dims(ctypes.byref(d))
+    return d
+
+
+def legacy_dims():
+    d = Dims()
+    load().dimx_legacy_dims(ctypes.byref(d))
     return d

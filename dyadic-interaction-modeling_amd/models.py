@@ -36,6 +36,8 @@ def build_param_tree(root: nn.Module, spec, tensors, buffers=("pe",)):
 class _EngineOwner(nn.Module):
     """Keeps one Engine per (device, numeric mode) and re-uploads weights when they changed."""
 
+    engine_variant = "slmft"     # which handle geometry the module computes on ("slmft" / "legacy")
+
     def __init__(self, numeric_mode):
         super().__init__()
         self.numeric_mode = numeric_mode
@@ -58,7 +60,7 @@ class _EngineOwner(nn.Module):
                               "(there is no CPU path; the CPU oracle under oracle/ is test infrastructure)")
         ver = self._weights_version()
         if self._engine is None or self._engine.device != device:
-            self._engine = Engine(device, self.numeric_mode)
+            self._engine = Engine(device, self.numeric_mode, self.engine_variant)
             self._engine_version = None
         if self._engine_version != ver:
             self._engine.load_state_dict(self._engine_state_dict())

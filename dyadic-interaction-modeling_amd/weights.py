@@ -111,6 +111,89 @@ def vq_spec(d: VQDims = VQDims(), prefix=""):
     return s
 
 
+@dataclass(frozen=True)
+class LegacyDims:
+    """Hard-coded constructor values of the legacy ListenerGenerator (reference code/seq2seq.py:183-198) and its
+    speaker VQ-VAE (reference code/config_speaker_old.yaml:15-30, arch stage1_BIWI_speaker)."""
+    spk_in_dim: int = 824
+    spk_hidden: int = 768
+    spk_layers: int = 6
+    spk_heads: int = 8
+    spk_inter: int = 1536
+    spk_face_quan_num: int = 8
+    zdim: int = 128
+    n_embed: int = 512
+    dim: int = 512
+    depth: int = 6
+    heads: int = 8
+    dim_head: int = 64
+    num_tokens: int = 512
+    max_seq_len: int = 1024
+    ff_mult: int = 4
+
+    @property
+    def dim_in(self):
+        return self.spk_face_quan_num * self.zdim
+
+    @property
+    def inner(self):
+        return self.heads * self.dim_head
+
+
+def legacy_speaker_vq_spec(d: LegacyDims = LegacyDims(), prefix="speaker_vq."):
+    """Encoder + codebook of VQSpeakerAutoEncoder (reference code/models/stage1_BIWI.py:140-162); the two
+    decoders (decoder_v / decoder_a) are not on the ListenerGenerator path and are accepted but ignored."""
+    H = d.spk_hidden
+    e = prefix + "encoder."
+    vd = VQDims(in_dim=d.spk_in_dim, hidden=H, layers=d.spk_layers, heads=d.spk_heads, inter=d.spk_inter,
+                n_embed=d.n_embed, zdim=d.zdim)
+    s = [(e + "vertice_mapping.0.weight", (H, d.spk_in_dim), "w", d.spk_in_dim),
+         (e + "vertice_mapping.0.bias", (H,), "b", d.spk_in_dim),
+         (e + "squasher.0.0.weight", (H, H, 5), "w", H * 5),
+         (e + "squasher.0.0.bias", (H,), "b", H * 5)]
+    s += _vq_stack_spec(e, "encoder_transformer", vd)
+    s += [(e + "encoder_pos_embedding.pe", (vd.pe_len, 1, H), "pe", 0),
+          (e + "encoder_linear_embedding.net.weight", (H, H), "w", H),
+          (e + "encoder_linear_embedding.net.bias", (H,), "b", H),
+          (e + "encoder_linear_embedding_post.net.weight", (d.dim_in, H), "w", H),
+          (e + "encoder_linear_embedding_post.net.bias", (d.dim_in,), "b", H)]
+    s += [(prefix + "quantize.embedding.weight", (d.n_embed, d.zdim), "codebook", 0)]
+    return s
+
+
+def legacy_generator_spec(d: LegacyDims = LegacyDims(), prefix="generator."):
+    """seq2seq.Transformer (reference code/seq2seq.py:13-52): x-tf encoder (dim_in 1024 -> 512, depth 6, heads 8)
+    and cross-attending decoder WITH absolute positional embedding."""
+    e = prefix + "encoder."
+    s = [(e + "project_in.weight", (d.dim, d.dim_in), "w", d.dim_in),
+         (e + "pos_emb.emb.weight", (d.max_seq_len, d.dim), "pos_emb", 0)]
+    for i in range(d.depth):
+        s += _xt_attn(e, 2 * i, d.dim, d.inner)
+        s += _xt_ff(e, 2 * i + 1, d.dim, d.ff_mult)
+    s += [(e + "attn_layers.final_norm.weight", (d.dim,), "ln_w", 0),
+          (e + "project_out.weight", (d.dim, d.dim), "w", d.dim)]
+    c = prefix + "decoder.net."
+    s += [(c + "token_emb.emb.weight", (d.num_tokens, d.dim), "tok_emb", 0),
+          (c + "pos_emb.emb.weight", (d.max_seq_len, d.dim), "pos_emb", 0)]
+    for i in range(d.depth):
+        s += _xt_attn(c, 3 * i, d.dim, d.inner)
+        s += _xt_attn(c, 3 * i + 1, d.dim, d.inner)
+        s += _xt_ff(c, 3 * i + 2, d.dim, d.ff_mult)
+    s += [(c + "attn_layers.final_norm.weight", (d.dim,), "ln_w", 0),
+          (c + "to_logits.weight", (d.num_tokens, d.dim), "w", d.dim)]
+    return s
+
+
+def listener_generator_spec(vq: VQDims = VQDims(), d: LegacyDims = LegacyDims()):
+    """Every tensor of ListenerGenerator().state_dict() that the hot path uses plus the id-embedding layers
+    (reference code/seq2seq.py:139-202); speaker_vq decoders are omitted (not built)."""
+    s = legacy_speaker_vq_spec(d, "speaker_vq.") + vq_spec(vq, "listener_vq.") + legacy_generator_spec(d, "generator.")
+    s += [("speaker_embeddings.weight", (100, 256), "tok_emb", 0), ("listener_embeddings.weight", (100, 256), "tok_emb", 0),
+          ("fc_speaker.weight", (1024, 256), "w", 256), ("fc_speaker.bias", (1024,), "b", 256),
+          ("fc_listener.weight", (512, 256), "w", 256), ("fc_listener.bias", (512,), "b", 256)]
+    return s
+
+
 def _xt_attn(prefix, li, dim, inner):
     p = "{}attn_layers.layers.{}.".format(prefix, li)
     return [(p + "0.0.weight", (dim,), "ln_w", 0),

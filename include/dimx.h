@@ -56,6 +56,12 @@ typedef struct {
     int vq_in_dim, vq_hidden, vq_layers, vq_heads, vq_inter, vq_n_embed, vq_zdim;
     /* seq2seq (reference code/seq2seq_pretrain.py:369-418) */
     int dim_in, dim, dim_a, enc_depth, dec_depth, heads, dim_head, num_tokens, max_seq_len, ff_mult;
+    /* 0 = DIM-Listener SLMFT (code/seq2seq_pretrain.py:325); 1 = legacy ListenerGenerator (code/seq2seq.py:138,
+     * driven by code/x_engine.py): speaker VQ 824->768 with 8 codes per frame, x-tf encoder/decoder dim 512,
+     * depth 6, heads 8, decoder with absolute positional embedding */
+    int variant;
+    /* speaker VQ-VAE geometry of variant 1 (reference code/config_speaker_old.yaml:15-30) */
+    int spk_in_dim, spk_hidden, spk_heads, spk_inter, spk_face_quan_num;
 } dimx_dims;
 
 typedef struct {
@@ -68,6 +74,8 @@ typedef struct {
 int dimx_version(void);
 const char* dimx_last_error(void);
 void dimx_default_dims(dimx_dims* d);
+/* the legacy ListenerGenerator geometry (variant 1) */
+void dimx_legacy_dims(dimx_dims* d);
 
 int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeric_mode);
 int dimx_destroy(dimx_handle h);
@@ -115,6 +123,19 @@ int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, i
 int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio, const uint8_t* mask,
                     int B, int T, int for_generate, float* x_s_out, void* ws, size_t ws_bytes,
                     void* stream);
+/* Variant 1 (legacy ListenerGenerator, reference code/seq2seq.py:220-249) gives the same entry point this
+ * meaning: v_speaker [B,T,824] f32 with the valid frames of each clip FIRST (the reference indexes
+ * v_speaker[i][mask[i]]; the host compacts), v_audio ignored (may be NULL), mask [B,T] uint8 with
+ * popcount(mask[b]) = number of valid frames; the speaker VQ-VAE encoder (batch-1 per clip, positional row 0),
+ * the quantiser, the reference's channel-major re-view and the 6-layer bidirectional encoder run inside;
+ * x_s_out (optional): [B,T,512] f32 encoder output.  dimx_decode_tf then takes kv_mask = NULL and
+ * dimx_generate produces T (not T-1) tokens per sequence: tokens [B*S, T], logits_out [B*S, T, 512]. */
+
+/* Test hook for variant 1: the x_speaker tensor of code/seq2seq.py:224-241 ([B,T,1024] f32, optional) and
+ * the speaker code indices ([B,T*8] int32, -100 beyond the clip length, optional). */
+int dimx_legacy_speaker_features(dimx_handle h, const float* v_speaker, const uint8_t* mask, int B, int T,
+                                 float* x_speaker_out, int32_t* idx_out, void* ws, size_t ws_bytes,
+                                 void* stream);
 
 /* Teacher-forced decoder pass.  z_l [B,T] int32 (-100 = ignore), ctx_mask [B,T] uint8,
  * kv_mask [B,T-1] uint8 keep-mask for self-attention keys (NULL = keep all).

@@ -402,3 +402,95 @@ def slmft_forward(sd, v_speaker, v_listener, v_audio, mask, mode="train", noise=
     if return_aux:
         return total, d, pred, {"z_l": z_l, "x_s": x_s, "ctx": ctx, "logits": logits, "tokens": tokens}
     return total, d, pred
+
+
+# ----------------------------------------------------------------------------
+# legacy ListenerGenerator (code/seq2seq.py) -- SURVEY.md section 8(f1); x-transformers half unpinned as above
+# ----------------------------------------------------------------------------
+
+def speaker_vq_encode_quant(sd, x, prefix="speaker_vq.", heads=8, layers=6, fqn=8, zdim=128):
+    """VQSpeakerAutoEncoder.encode(x)[0] (code/models/stage1_BIWI.py:152-157): encoder features [B,L,fqn*zdim]
+    viewed as [B, L*fqn, zdim], quantised, returned as the codebook vectors permuted to [B, zdim, L*fqn]
+    (quantizer.py:65).  Also returns the indices [B, L*fqn]."""
+    B, L, _ = x.shape
+    h = vq_encode_features(sd, x, heads, layers, prefix, True, 0)      # [B, L, fqn*zdim]
+    z = h.view(B, L * fqn, zdim)
+    E = sd[prefix + "quantize.embedding.weight"]
+    idx, d = vq_quantize(z.reshape(B * L * fqn, zdim), E)
+    quant = E[idx].view(B, L * fqn, zdim).permute(0, 2, 1).contiguous()
+    return quant, idx.view(B, L * fqn), d
+
+
+def legacy_speaker_features(sd, v_speaker, mask, fqn=8, zdim=128):
+    """The x_speaker construction of ListenerGenerator.forward / .generate (code/seq2seq.py:224-241): per-sample
+    batch-1 encode of the valid frames, zero-pad of the [1,128,len*8] code-vector tensor along its LAST axis to
+    T*8, then a raw .view(B,-1,8,128).view(B,-1,1024) of that channel-major memory (a reinterpretation, not a
+    transpose -- reproduced literally)."""
+    B, T, _ = v_speaker.shape
+    xs = []
+    for i in range(B):
+        q, _, _ = speaker_vq_encode_quant(sd, v_speaker[i][mask[i]].unsqueeze(0), "speaker_vq.", fqn=fqn, zdim=zdim)
+        xs.append(F.pad(q, (0, T * fqn - q.shape[-1]), value=0))
+    x = torch.cat(xs, dim=0)                                          # [B, 128, T*8] contiguous
+    x = x.view(B, -1, fqn, zdim).contiguous()
+    return x.view(B, -1, fqn * zdim).contiguous()                     # [B, T, 1024]
+
+
+def legacy_decoder_embed(sd, tokens, prefix="generator.decoder.net."):
+    """TransformerWrapper with use_abs_pos_emb=True (code/seq2seq.py:39): token emb + pos_emb[0:n] * dim^-0.5."""
+    n = tokens.shape[1]
+    h = sd[prefix + "token_emb.emb.weight"][tokens]
+    return h + sd[prefix + "pos_emb.emb.weight"][:n] * (h.shape[-1] ** -0.5)
+
+
+def legacy_decoder_logits(sd, tokens, context, context_mask, prefix="generator.decoder.net.", depth=6, heads=8):
+    n = tokens.shape[1]
+    h = legacy_decoder_embed(sd, tokens, prefix)
+    causal = ~torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1)
+    h = xt_decoder_layers(sd, prefix, h, context, context_mask, causal, None, depth, heads)
+    return F.linear(h, sd[prefix + "to_logits.weight"])
+
+
+def legacy_generate(sd, start, seq_len, context, context_mask, noise=None, temperature=1.0, k=52,
+                    prefix="generator.decoder.net.", depth=6, heads=8):
+    """AutoregressiveWrapper.generate for the legacy decoder (positional embedding of the absolute position);
+    uncached recomputation per step would be O(T^2) -- this keeps the KV cache like the library."""
+    B = start.shape[0]
+    out = start.view(B, 1)
+    cache = [dict() for _ in range(depth)]
+    pos = sd[prefix + "pos_emb.emb.weight"]
+    for t in range(seq_len):
+        h = sd[prefix + "token_emb.emb.weight"][out[:, -1:]]
+        h = h + pos[t:t + 1] * (h.shape[-1] ** -0.5)
+        h = xt_decoder_layers(sd, prefix, h, context, context_mask, None, None, depth, heads, cache)
+        logits = F.linear(h[:, -1], sd[prefix + "to_logits.weight"])
+        tok = sample_tokens(logits, None if noise is None else noise[t], temperature, k)
+        out = torch.cat([out, tok.view(B, 1)], dim=1)
+    return out[:, 1:]
+
+
+def listener_generator_forward(sd, v_speaker, v_listener, mask):
+    """ListenerGenerator.forward(v_speaker[B,T,824], v_listener[B,T,56], mask) with speaker_ids = listener_ids =
+    None (the call x_engine.evaluate_epoch makes, code/x_engine.py:76) -> (loss, pred_cont_seq [B,T-1,56]).
+    code/seq2seq.py:220-278."""
+    x_speaker = legacy_speaker_features(sd, v_speaker, mask)
+    _, z_l = forward_vq(sd, v_speaker, v_listener, mask, with_speaker=False)
+    enc = xt_encoder(sd, "generator.encoder.", x_speaker, mask, causal=False, depth=6, heads=8)
+    inp, target = z_l[:, :-1], z_l[:, 1:]
+    inp = torch.where(inp == -100, torch.zeros_like(inp), inp)
+    logits = legacy_decoder_logits(sd, inp, enc, mask)
+    loss = F.cross_entropy(logits.permute(0, 2, 1), target, ignore_index=-100)
+    pred_seq = logits.argmax(dim=-1)
+    pred = vq_decode(sd, pred_seq, "listener_vq.")
+    loss_cont = continuous_loss(pred, v_listener, mask)
+    return loss + loss_cont, pred, {"x_speaker": x_speaker, "enc": enc, "logits": logits, "z_l": z_l}
+
+
+def listener_generator_generate(sd, v_speaker, v_listener, mask, noise=None):
+    """ListenerGenerator.generate (code/seq2seq.py:280-306): seq_len = T generated tokens from the ground-truth
+    first listener code -> (z_pred [B,T], z_listener [B,T])."""
+    x_speaker = legacy_speaker_features(sd, v_speaker, mask)
+    _, z_l = forward_vq(sd, v_speaker, v_listener, mask, with_speaker=False)
+    enc = xt_encoder(sd, "generator.encoder.", x_speaker, mask, causal=False, depth=6, heads=8)
+    z_pred = legacy_generate(sd, z_l[:, 0], z_l.shape[1], enc, mask, noise)
+    return z_pred, z_l

@@ -184,5 +184,56 @@ def main():
     print(json.dumps(report, indent=1, sort_keys=True))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--legacy" not in sys.argv:
     main()
+
+
+def legacy_fixtures():
+    """VQSpeakerAutoEncoder (arch stage1_BIWI_speaker, config_speaker_old.yaml) imported from the
+    reference: the x_speaker construction of seq2seq.ListenerGenerator (per-sample encode, pad, raw view)."""
+    import torch.nn.functional as F
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from base import config as ref_config
+        from models import get_model
+        cfg = ref_config.load_cfg_from_cfg_file("./config_speaker_old.yaml")
+        spk = get_model(cfg).eval()
+    finally:
+        os.chdir(cwd)
+    spec = weights.legacy_speaker_vq_spec(prefix="speaker_vq.")
+    sd = weights.synth_state_dict(spec, SEED, strip_prefix="speaker_vq.")
+    ref_sd = spk.state_dict()
+    for k, v in sd.items():
+        assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(v.shape), k
+    missing, unexpected = spk.load_state_dict(sd, strict=False)      # decoder_v / decoder_a stay at their init
+    assert not unexpected and all(m.startswith("decoder_") for m in missing), (missing[:3], unexpected[:3])
+    full = weights.synth_state_dict(spec, SEED)
+    B, T = 3, 24
+    lens = [24, 17, 5]
+    v = torch.from_numpy(prng.normal(SEED, "golden.legacy.vs", (B, T, 824)))
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    for j, n in enumerate(lens):
+        mask[j, :n] = True
+    xs, idxs, margins = [], [], []
+    for i in range(B):
+        quant, _, info = spk.encode(v[i][mask[i]].unsqueeze(0))
+        xs.append(F.pad(quant, (0, T * 8 - quant.shape[-1]), value=0))
+        idxs.append(F.pad(info[2].view(-1), (0, T * 8 - info[2].numel()), value=-1))
+        _, _, d = ref_cpu.speaker_vq_encode_quant(full, v[i][mask[i]].unsqueeze(0))
+        margins.append(ref_cpu.vq_margins(d).min().item())
+    x = torch.cat(xs, 0)
+    x = x.view(B, -1, 8, 128).contiguous().view(B, -1, 1024).contiguous()
+    o_x = ref_cpu.legacy_speaker_features(full, v, mask)
+    assert min(margins) >= 1e-4, margins
+    err = (x - o_x).abs().max().item()
+    assert err < 1e-6, err
+    np.savez_compressed(os.path.join(HERE, "legacy_speaker_features.npz"), v_speaker=v.numpy(),
+                        lens=np.array(lens, np.int32), x_speaker=x.numpy().astype(np.float32),
+                        idx=torch.stack(idxs).numpy().astype(np.int16))
+    print("legacy_speaker_features: oracle vs reference err", err, "min margin", min(margins))
+
+
+if __name__ == "__main__" and "--legacy" in sys.argv:
+    legacy_fixtures()
