@@ -23,6 +23,11 @@ Parity status
   Appendix A.2); it is pinned only by self-consistency properties (cached ==
   uncached == teacher-forced, masking invariance) and can be compared with the real
   wheel via ``tools/verify_against_xtransformers.py`` wherever that wheel exists.
+* Legacy ``ListenerGenerator`` (``code/seq2seq.py:138-306``): the speaker VQ-VAE encoder ->
+  quantiser -> ``x_speaker`` construction is PINNED by ``tests/golden/legacy_speaker_features.npz`` (reference
+  ``VQSpeakerAutoEncoder`` imported by ``tests/golden/make_golden.py --legacy``; checked by
+  ``tests/test_oracle_legacy.py``).  Its x-transformers encoder/decoder (dim 512, absolute positional embedding)
+  shares the PARITY UNPINNED status and the self-consistency pins of the stage above.
 """
 import math
 
