@@ -75,7 +75,7 @@ if which in ("decode", "all"):
               ("cross_q N768 K1152", 768, 1152, False, False, 0, True), ("ff1 N4608 K1152", 4608, 1152, True, False, 3, False),
               ("ff2 N1152 K4608", 1152, 4608, False, True, 0, False), ("logits N512 K1152", 512, 1152, False, False, 0, True)]
     for name, N, K, obf, inpl, act, accum in shapes:
-        for cfg in (4, 7, 13, 14, 15, 16):
+        for cfg in (4, 14):
             for sp in ((1, 2, 4, 8) if (inpl or accum) else (0,)):
                 run(name, 256, N, K, obf, inpl, cfg, sp, act, accumulate=accum)
 if which in ("prefill", "all"):
@@ -84,6 +84,13 @@ if which in ("prefill", "all"):
               ("xe_qkv N2304 K384", 2304, 384, True, False, 0), ("xe_out N384 K768", 384, 768, False, True, 0),
               ("ckv N1536 K1152", 1536, 1152, True, False, 0)]
     for name, N, K, obf, inpl, act in shapes:
-        for cfg in (14, 27, 28):
+        for cfg in (14, 18, 19):
             run(name, 76800, N, K, obf, inpl, cfg, 0, act, iters=6, ncopies=2)
+if which == "kscan":
+    # main-loop rate vs fixed (prologue + epilogue) cost: same M, N at two K; plus a square reference shape
+    for name, M, N, K, obf in (("ckv K1152 bf16", 76800, 1536, 1152, True), ("ckv K4608 bf16", 76800, 1536, 4608, True),
+                               ("ckv K1152 f32", 76800, 1536, 1152, False), ("sq 8192 bf16", 8192, 8192, 8192, True),
+                               ("sq 4096 bf16", 4096, 4096, 4096, True)):
+        for cfg in (1, 14, 18, 19):
+            run(name, M, N, K, obf, False, cfg, 0, 0, iters=5, ncopies=2)
 json.dump(plan, open(plan_path, "w"))
