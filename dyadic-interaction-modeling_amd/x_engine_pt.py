@@ -26,8 +26,8 @@ def _mask_from_lens(src, src_len, device):
 
 def _prepare(batch, device):
     src, tgt, src_len, _, data_ids = batch
-    src = src.to(device)
-    tgt = tgt.to(device)
+    src = src.to(device, non_blocking=True)     # pinned host batches (dimx.dataset.data_loader) copy asynchronously
+    tgt = tgt.to(device, non_blocking=True)
     src_s_v, src_s_a = torch.split(src, [56, 768], dim=2)
     mask = _mask_from_lens(src, src_len, device)
     return src_s_v.contiguous(), src_s_a.contiguous(), tgt, mask, list(src_len), data_ids

@@ -184,7 +184,7 @@ def main():
     print(json.dumps(report, indent=1, sort_keys=True))
 
 
-if __name__ == "__main__" and "--legacy" not in sys.argv:
+if __name__ == "__main__" and "--legacy" not in sys.argv and "--mymetrics" not in sys.argv:
     main()
 
 
@@ -237,3 +237,38 @@ def legacy_fixtures():
 
 if __name__ == "__main__" and "--legacy" in sys.argv:
     legacy_fixtures()
+
+
+def mymetrics_fixture():
+    """print_metrics / print_metrics_full of the reference (code/mymetrics.py:7-130) on seeded synthetic per-clip
+    lists; the printed numbers are captured from stdout.  (The reference loader module cannot be imported here:
+    it needs librosa, which this image lacks -- pad_collate is tested against its documented behaviour instead.)"""
+    import contextlib
+    import io
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import mymetrics as ref_mm
+    finally:
+        os.chdir(cwd)
+    lens = [40, 33, 57, 21, 64, 48]
+    gts = [prng.normal(SEED, "golden.mm.gt%d" % i, (n, 56)).astype(np.float64) for i, n in enumerate(lens)]
+    prs = [g + 0.3 * prng.normal(SEED, "golden.mm.pr%d" % i, g.shape) for i, g in enumerate(gts)]
+    xs = [prng.normal(SEED, "golden.mm.x%d" % i, (n, 56)).astype(np.float64) for i, n in enumerate(lens)]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ret = ref_mm.print_metrics(gts, prs, xs)
+        ref_mm.print_metrics_full(gts, prs, xs)
+    out = {}
+    for line in buf.getvalue().strip().splitlines():
+        k, v = line.split(":")
+        out[k.strip()] = [float(t) for t in v.split()]
+    out["return"] = [float(ret[0]), float(ret[1])]
+    with open(os.path.join(HERE, "mymetrics_small.json"), "w") as f:
+        json.dump({"lens": lens, "expected": out}, f, indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__" and "--mymetrics" in sys.argv:
+    mymetrics_fixture()
