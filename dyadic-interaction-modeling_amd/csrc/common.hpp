@@ -228,7 +228,7 @@ int launch_vq_argmin(const float* z, int N, const float* Et /*[128][512]*/, cons
 
 // elementwise helpers (elementwise.hip)
 int launch_cast_pad(int out_dtype, const float* x, int ldx, const float* coladd, void* y, int ldy, int M, int K,
-                    hipStream_t s);
+                    hipStream_t s, const uint8_t* zero_rows = nullptr);
 int launch_gather_rows(int out_dtype, const float* table, int ld_table, int rows, const int32_t* idx, void* y,
                        int ldy, int M, int C, hipStream_t s);
 int launch_context_concat(int out_dtype, const float* x_s, const float* patch, const float* audio, void* ctx,

@@ -9,12 +9,12 @@ namespace {
 // y[m, 0:ldy) = x[m, 0:K) (+ coladd) zero-padded; x is f32 [M, ldx]
 template <typename OutT>
 __global__ void cast_pad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ coladd,
-                                OutT* __restrict__ y, int ldy, int M, int K) {
+                                OutT* __restrict__ y, int ldy, int M, int K, const uint8_t* __restrict__ zero_rows) {
     const long total = (long)M * ldy;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / ldy), k = (int)(i - (long)m * ldy);
         float v = 0.f;
-        if (k < K) {
+        if (k < K && !(zero_rows && zero_rows[m])) {  // zero_rows: SLM's masked frames (seq2seq_pretrain.py:211-212)
             v = x[(size_t)m * ldx + k];
             if (coladd) v += coladd[k];
         }
@@ -349,13 +349,13 @@ inline int ew_blocks(long total) {
 }  // namespace
 
 int launch_cast_pad(int out_dtype, const float* x, int ldx, const float* coladd, void* y, int ldy, int M, int K,
-                    hipStream_t s) {
+                    hipStream_t s, const uint8_t* zero_rows) {
     DIMX_REQUIRE(x && y && M > 0 && K > 0 && ldy >= K, DIMX_ERR_ARG, "cast_pad: bad arguments");
     const int g = ew_blocks((long)M * ldy);
     if (out_dtype == DIMX_BF16)
-        hipLaunchKernelGGL(cast_pad_kernel<bf16>, dim3(g), dim3(256), 0, s, x, ldx, coladd, (bf16*)y, ldy, M, K);
+        hipLaunchKernelGGL(cast_pad_kernel<bf16>, dim3(g), dim3(256), 0, s, x, ldx, coladd, (bf16*)y, ldy, M, K, zero_rows);
     else
-        hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(g), dim3(256), 0, s, x, ldx, coladd, (float*)y, ldy, M, K);
+        hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(g), dim3(256), 0, s, x, ldx, coladd, (float*)y, ldy, M, K, zero_rows);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -144,6 +144,20 @@ static void legacy_keys(const dimx_dims& d, std::vector<KeySpec>& k) {
     k.push_back({"generator.decoder.net.pos_emb.emb.weight", {d.max_seq_len, d.dim + d.dim_a}});
 }
 
+// what SLM (code/seq2seq_pretrain.py:58-165) uses on top of the SLMFT tensors; which: 1 encoder side, 2 decoder side
+static void slm_extra_keys(const dimx_dims& d, std::vector<KeySpec>& k, int which) {
+    if (which & 1) {
+        xenc_keys(d, "encoder_l.", d.dim_in, k);
+        k.push_back({"patch_embed_l", {1, 1, d.dim_in}});
+        k.push_back({"patch_embed_dec_l", {1, 1, d.dim}});
+        for (const char* n : {"norm_l", "norm"}) {
+            k.push_back({std::string(n) + ".weight", {d.dim}});
+            k.push_back({std::string(n) + ".bias", {d.dim}});
+        }
+    }
+    if (which & 2) k.push_back({"decoder_joint.net.pos_emb.emb.weight", {d.max_seq_len, d.dim + d.dim_a}});
+}
+
 static std::vector<KeySpec> all_keys(const dimx_dims& d) {
     std::vector<KeySpec> k;
     if (d.variant == 1) {
@@ -159,6 +173,7 @@ static std::vector<KeySpec> all_keys(const dimx_dims& d) {
     k.push_back({"patch_embed_dec_s", {1, 1, d.dim}});
     k.push_back({"norm_s.weight", {d.dim}});
     k.push_back({"norm_s.bias", {d.dim}});
+    if (d.variant == 2) slm_extra_keys(d, k, 3);
     return k;
 }
 
@@ -352,8 +367,12 @@ static std::vector<KeySpec> comp_keys(const dimx_dims& d, int comp) {
         k.push_back({"patch_embed_dec_s", {1, 1, d.dim}});
         k.push_back({"norm_s.weight", {d.dim}});
         k.push_back({"norm_s.bias", {d.dim}});
+        if (d.variant == 2) slm_extra_keys(d, k, 1);
     }
-    if (comp == COMP_DEC) xdec_keys(d, "decoder_joint.net.", k);
+    if (comp == COMP_DEC) {
+        xdec_keys(d, "decoder_joint.net.", k);
+        if (d.variant == 2) slm_extra_keys(d, k, 2);
+    }
     return k;
 }
 
@@ -383,6 +402,15 @@ static int ensure_packed(dimx_ctx* c, int need) {
             DIMX_TRY(upload_f32(c, "patch_embed_dec_s", &c->patch_dec_s));
             DIMX_TRY(upload_f32(c, "norm_s.weight", &c->norm_s_g));
             DIMX_TRY(upload_f32(c, "norm_s.bias", &c->norm_s_b));
+            if (c->variant == 2) {
+                DIMX_TRY(pack_xenc(c, "encoder_l.", &c->enc_l));
+                DIMX_TRY(upload_f32(c, "patch_embed_l", &c->patch_l));
+                DIMX_TRY(upload_f32(c, "patch_embed_dec_l", &c->patch_dec_l));
+                DIMX_TRY(upload_f32(c, "norm_l.weight", &c->norm_l_g));
+                DIMX_TRY(upload_f32(c, "norm_l.bias", &c->norm_l_b));
+                DIMX_TRY(upload_f32(c, "norm.weight", &c->norm_j_g));
+                DIMX_TRY(upload_f32(c, "norm.bias", &c->norm_j_b));
+            }
         }
         if (comp == COMP_DEC) {
             const std::string dp = c->variant == 1 ? "generator.decoder.net." : "decoder_joint.net.";
@@ -625,7 +653,7 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     if (dims) d = *dims;
     DIMX_REQUIRE(d.vq_hidden == 384 && d.vq_heads == 8 && d.vq_zdim == 128 && d.vq_n_embed == 512 && d.vq_in_dim == 56,
                  DIMX_ERR_ARG, "dimx_create: only the DIM-Listener VQ geometry (56/384/8/128/512) is built");
-    if (d.variant == 0) {
+    if (d.variant == 0 || d.variant == 2) {
         DIMX_REQUIRE(d.dim == 384 && d.dim_a == 768 && d.dim_head == 64 && d.heads == 12 && d.num_tokens == 512 &&
                          d.vq_layers <= 8 && d.enc_depth <= 8 && d.dec_depth <= 8 && d.max_seq_len <= 2048,
                      DIMX_ERR_ARG, "dimx_create: only the SLMFT geometry (384+768, 12x64, 512 tokens) is built");
@@ -655,9 +683,12 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
         c->encg[0] = c->encg[1] = {din, din, d.dim, d.heads, d.dim_head, d.enc_depth, d.ff_mult, 0};
         c->decg = {d.dim, d.heads, d.dim_head, d.dec_depth, d.ff_mult, 1, d.num_tokens, d.dim};
     } else {
-        c->encg[0] = {d.dim_in, 64, d.dim, d.heads, d.dim_head, d.enc_depth, d.ff_mult, 1};
-        c->encg[1] = {d.dim, d.dim, d.dim, d.heads, d.dim_head, d.enc_depth, d.ff_mult, 1};
-        c->decg = {d.dim + d.dim_a, d.heads, d.dim_head, d.dec_depth, d.ff_mult, 0, d.num_tokens, d.dim + d.dim_a};
+        // SLMFT: causal encoders (attn_mask, :435), decoder without positional embedding (:386);
+        // SLM (variant 2): mask-only (bidirectional) encoders (:213-218), decoder with abs. pos. embedding (:131)
+        const int causal = d.variant == 2 ? 0 : 1, abs_pos = d.variant == 2 ? 1 : 0;
+        c->encg[0] = {d.dim_in, 64, d.dim, d.heads, d.dim_head, d.enc_depth, d.ff_mult, causal};
+        c->encg[1] = {d.dim, d.dim, d.dim, d.heads, d.dim_head, d.enc_depth, d.ff_mult, causal};
+        c->decg = {d.dim + d.dim_a, d.heads, d.dim_head, d.dec_depth, d.ff_mult, abs_pos, d.num_tokens, d.dim + d.dim_a};
     }
     for (const auto& k : all_keys(d)) c->required.push_back(k.name);
     const char* ng = getenv("DIMX_NO_GRAPH");
@@ -824,6 +855,22 @@ static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) 
     s.step = (int32_t*)ar.take(64 * dimx_ctx::kMaxGroups);  // one counter per clip group, 64 B apart
 }
 
+// SLM.forward_encoder: the encoder scratch is sized for the joint 2T pass; xs / xl keep the two first-stage
+// outputs (operand type), xj their time-concatenation, m2 the doubled padding mask
+struct SlmScratch {
+    EncScratch e;
+    void *xs, *xl, *xj;
+    uint8_t* m2;
+};
+static void plan_slm(const dimx_ctx* c, Arena& ar, int B, int T, SlmScratch& s) {
+    const size_t es = es_of(c);
+    plan_enc(c, ar, B, 2 * T, s.e);
+    s.xs = ar.take((size_t)B * T * c->encg[0].dim * es);
+    s.xl = ar.take((size_t)B * T * c->encg[0].dim * es);
+    s.xj = ar.take((size_t)B * 2 * T * c->encg[0].dim * es);
+    s.m2 = (uint8_t*)ar.take((size_t)B * 2 * T);
+}
+
 static size_t workspace_bytes(const dimx_ctx* c, int B, int T, int S = 1) {
     Arena p(nullptr, 0);
     CtxPersist cp;
@@ -845,6 +892,12 @@ static size_t workspace_bytes(const dimx_ctx* c, int B, int T, int S = 1) {
             plan_vq(c, c->vqg[0], a, B, T, v);
             a.take((size_t)B * 4);
         }
+        scratch = a.off > scratch ? a.off : scratch;
+    }
+    if (c->variant == 2) {
+        Arena a(nullptr, 0);
+        SlmScratch s;
+        plan_slm(c, a, B, T, s);
         scratch = a.off > scratch ? a.off : scratch;
     }
     if (T >= 2) {
@@ -1012,6 +1065,8 @@ int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, i
 
 int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio, const uint8_t* mask, int B, int T,
                     int for_generate, float* x_s_out, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(!h || h->variant != 2, DIMX_ERR_ARG,
+                 "encode_ctx: the SLM variant builds its contexts with dimx_slm_encode + dimx_set_context");
     if (h && h->variant == 1)
         return legacy_encode_ctx(h, v_speaker, mask, B, T, for_generate, x_s_out, nullptr, nullptr, ws, ws_bytes,
                                  (hipStream_t)stream);
@@ -1051,6 +1106,76 @@ int dimx_legacy_speaker_features(dimx_handle h, const float* v_speaker, const ui
     DIMX_REQUIRE(x_speaker_out || idx_out, DIMX_ERR_ARG, "legacy_speaker_features: no output requested");
     return legacy_encode_ctx(h, v_speaker, mask, B, T, -1, nullptr, x_speaker_out, idx_out, ws, ws_bytes,
                              (hipStream_t)stream);
+}
+
+// SLM.forward_encoder (code/seq2seq_pretrain.py:200-221).  mask_speaker / mask_listener: 1 = frame masked
+// (input row zeroed after the patch embedding is added).  Outputs f32: x_s, x_l [B,T,384], x_joint [B,2T,384].
+int dimx_slm_encode(dimx_handle h, const float* v_speaker, const float* v_listener, const uint8_t* mask,
+                    const uint8_t* mask_speaker, const uint8_t* mask_listener, int B, int T, float* x_s, float* x_l,
+                    float* x_joint, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(h && h->variant == 2, DIMX_ERR_ARG, "slm_encode: handle is not the SLM variant");
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_ENC));
+    DIMX_REQUIRE(2 * T <= h->d.max_seq_len, DIMX_ERR_ARG, "slm_encode: 2T=%d exceeds max_seq_len", 2 * T);
+    DIMX_REQUIRE(v_speaker && v_listener && mask && x_s && x_l && x_joint, DIMX_ERR_ARG, "slm_encode: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, T, nullptr);
+    SlmScratch s;
+    plan_slm(h, ar, B, T, s);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "slm_encode: workspace overflow");
+    const int M = B * T, dim = h->encg[0].dim;
+    const size_t es = es_of(h), rowb = (size_t)T * dim * es;
+    const EncGeom& e0 = h->encg[0];
+    const EncGeom& e1 = h->encg[1];
+    // first stage: encoder_s / encoder_l on the patch-embedded, randomly zeroed streams
+    DIMX_TRY(launch_cast_pad(h->at, v_speaker, h->d.dim_in, h->patch_s, s.e.xa, e0.in_pad, M, h->d.dim_in, st, mask_speaker));
+    DIMX_TRY(run_xenc(h, e0, h->enc_s, s.e.xa, e0.in_pad, s.e, B, T, mask, h->at, s.xs, st));
+    DIMX_TRY(launch_cast_pad(h->at, v_listener, h->d.dim_in, h->patch_l, s.e.xa, e0.in_pad, M, h->d.dim_in, st, mask_listener));
+    DIMX_TRY(run_xenc(h, e0, h->enc_l, s.e.xa, e0.in_pad, s.e, B, T, mask, h->at, s.xl, st));
+    // joint pass over cat([x_s, x_l], time) with cat([mask, mask])
+    DIMX_HIP(hipMemcpy2DAsync(s.xj, 2 * rowb, s.xs, rowb, rowb, B, hipMemcpyDeviceToDevice, st));
+    DIMX_HIP(hipMemcpy2DAsync((unsigned char*)s.xj + rowb, 2 * rowb, s.xl, rowb, rowb, B, hipMemcpyDeviceToDevice, st));
+    DIMX_HIP(hipMemcpy2DAsync(s.m2, 2 * T, mask, T, T, B, hipMemcpyDeviceToDevice, st));
+    DIMX_HIP(hipMemcpy2DAsync(s.m2 + T, 2 * T, mask, T, T, B, hipMemcpyDeviceToDevice, st));
+    DIMX_TRY(run_xenc(h, e1, h->enc_joint, s.xj, dim, s.e, B, 2 * T, s.m2, DIMX_F32, s.e.tmp, st));
+    DIMX_TRY(launch_layernorm(DIMX_F32, s.e.tmp, x_joint, h->norm_j_g, h->norm_j_b, 2 * M, dim, st));
+    // encoder_joint on each stream alone
+    DIMX_TRY(run_xenc(h, e1, h->enc_joint, s.xl, dim, s.e, B, T, mask, DIMX_F32, s.e.tmp, st));
+    DIMX_TRY(launch_layernorm(DIMX_F32, s.e.tmp, x_l, h->norm_l_g, h->norm_l_b, M, dim, st));
+    DIMX_TRY(run_xenc(h, e1, h->enc_joint, s.xs, dim, s.e, B, T, mask, DIMX_F32, s.e.tmp, st));
+    DIMX_TRY(launch_layernorm(DIMX_F32, s.e.tmp, x_s, h->norm_s_g, h->norm_s_b, M, dim, st));
+    h->ctx_ready = false;
+    return DIMX_OK;
+}
+
+// context = cat(x + patch_embed_dec_{s|l}, audio) -> cross K/V of every decoder layer
+// (SLM.forward_decoder, code/seq2seq_pretrain.py:223-229; SLMFT :445-446).  x: [B,T,dim] f32 with row stride ldx.
+int dimx_set_context(dimx_handle h, const float* x, int ldx_rows, int which_patch, const float* v_audio, int B, int T,
+                     int for_generate, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(h && h->variant != 1, DIMX_ERR_ARG, "set_context: not available for the legacy variant");
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_ENC | COMP_DEC));
+    DIMX_REQUIRE(x && v_audio && (which_patch == 0 || (which_patch == 1 && h->variant == 2)) && ldx_rows >= T,
+                 DIMX_ERR_ARG, "set_context: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    CtxPersist cp;
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, T, &cp);
+    EncScratch s;
+    plan_enc(h, ar, B, T, s);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "set_context: workspace overflow");
+    const int M = B * T, dim = h->d.dim, dim_a = h->d.dim_a;
+    const float* xr = x;
+    if (ldx_rows != T) {  // a [B, ldx_rows, dim] tensor of which the first T rows per clip are used (x_joint halves)
+        DIMX_HIP(hipMemcpy2DAsync(s.h, (size_t)T * dim * 4, x, (size_t)ldx_rows * dim * 4, (size_t)T * dim * 4, B,
+                                  hipMemcpyDeviceToDevice, st));
+        xr = s.h;
+    }
+    DIMX_TRY(launch_context_concat(h->at, xr, which_patch ? h->patch_dec_l : h->patch_dec_s, v_audio, s.xa, M, dim, dim_a, st));
+    DIMX_TRY(project_cross_kv(h, s.xa, cp, B, T, for_generate, st));
+    h->ctx_ready = true;
+    h->ctx_B = B;
+    h->ctx_T = T;
+    h->ctx_for_generate = for_generate ? 1 : 0;
+    h->ctx_ws = ws;
+    return DIMX_OK;
 }
 
 }  // extern "C"

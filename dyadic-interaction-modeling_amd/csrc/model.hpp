@@ -57,7 +57,8 @@ struct XDec {
     Linear logits;
 };
 
-// geometry of the three network families of a handle (variant 0 = SLMFT, 1 = legacy ListenerGenerator)
+// geometry of the three network families of a handle (variant 0 = SLMFT, 1 = legacy ListenerGenerator,
+// 2 = SLM pre-training model: SLMFT's dims, bidirectional encoders + encoder_l, decoder with abs. pos. embedding)
 struct VQGeom {
     int in_dim, in_pad, hidden, heads, inter, layers, out_dim, fqn, zdim, n_embed;
     bool has_decoder;
@@ -121,9 +122,11 @@ struct dimx_ctx {
     int packed_mask = 0;  // COMP_* bits of the components whose packed device copies are current
     std::vector<void*> dev_allocs;
     dimx::VQNet vq[2];  // 0 speaker, 1 listener
-    dimx::XEnc enc_s, enc_joint;
+    dimx::XEnc enc_s, enc_joint, enc_l;  // enc_l: SLM pre-training variant only
     dimx::XDec dec;
     const float *patch_s = nullptr, *patch_dec_s = nullptr, *norm_s_g = nullptr, *norm_s_b = nullptr;
+    const float *patch_l = nullptr, *patch_dec_l = nullptr, *norm_l_g = nullptr, *norm_l_b = nullptr;  // SLM
+    const float *norm_j_g = nullptr, *norm_j_b = nullptr;                                              // SLM `norm`
     // encode_ctx -> decode hand-off
     bool ctx_ready = false;
     int ctx_B = 0, ctx_T = 0, ctx_for_generate = 0;

@@ -24,9 +24,9 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = L.load()
         self.mode = mode
-        assert variant in ("slmft", "legacy")
+        assert variant in ("slmft", "legacy", "slm")
         self.variant = variant
-        self.dims = L.default_dims() if variant == "slmft" else L.legacy_dims()
+        self.dims = {"slmft": L.default_dims, "legacy": L.legacy_dims, "slm": L.slm_dims}[variant]()
         h = ctypes.c_void_p()
         L.check(self.lib.dimx_create(ctypes.byref(h), self.device.index, ctypes.byref(self.dims), mode),
                 "dimx_create")
@@ -133,6 +133,34 @@ class Engine:
                                          1 if for_generate else 0, L.ptr(x_s), ws, wsb, self._s()),
                 "dimx_encode_ctx")
         return x_s
+
+    def slm_encode(self, v_speaker, v_listener, mask_u8, mask_speaker_u8=None, mask_listener_u8=None):
+        """SLM.forward_encoder -> (x_s, x_l [B,T,384], x_joint [B,2T,384]) f32."""
+        B, T, _ = v_speaker.shape
+        v_speaker = v_speaker.to(torch.float32).contiguous()
+        v_listener = v_listener.to(torch.float32).contiguous()
+        self._chk(v_speaker, v_listener, mask_u8, mask_speaker_u8, mask_listener_u8)
+        dim = self.dims.dim
+        x_s = torch.empty(B, T, dim, dtype=torch.float32, device=self.device)
+        x_l = torch.empty(B, T, dim, dtype=torch.float32, device=self.device)
+        x_j = torch.empty(B, 2 * T, dim, dtype=torch.float32, device=self.device)
+        ws, wsb = self.workspace(B, T)
+        L.check(self.lib.dimx_slm_encode(self.h, L.ptr(v_speaker), L.ptr(v_listener), L.ptr(mask_u8),
+                                         L.ptr(mask_speaker_u8), L.ptr(mask_listener_u8), B, T, L.ptr(x_s), L.ptr(x_l),
+                                         L.ptr(x_j), ws, wsb, self._s()), "dimx_slm_encode")
+        return x_s, x_l, x_j
+
+    def set_context(self, x, v_audio, which_patch=0, for_generate=False, T=None, n_samples=1):
+        """context = cat(x[:, :T] + patch_embed_dec_{s|l}, v_audio) + cross K/V; x [B, rows>=T, dim] f32."""
+        B, rows, _ = x.shape
+        T = T or rows
+        x = x.to(torch.float32)
+        v_audio = v_audio.to(torch.float32).contiguous()
+        assert x.stride(2) == 1 and x.stride(1) == x.shape[2], "x rows must be dense"
+        ldx_rows = x.stride(0) // x.shape[2]
+        ws, wsb = self.workspace(B, T, n_samples)
+        L.check(self.lib.dimx_set_context(self.h, ctypes.c_void_p(x.data_ptr()), ldx_rows, which_patch, L.ptr(v_audio),
+                                          B, T, 1 if for_generate else 0, ws, wsb, self._s()), "dimx_set_context")
 
     def legacy_speaker_features(self, v_speaker, mask_u8, return_idx=False):
         """x_speaker [B,T,1024] of ListenerGenerator.forward (code/seq2seq.py:224-241); v_speaker must hold each

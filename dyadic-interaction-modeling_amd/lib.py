@@ -58,6 +58,10 @@ SIGNATURES = {
                                 c_void_p, c_size_t, c_void_p]),
     "dimx_legacy_speaker_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                              c_void_p, c_size_t, c_void_p]),
+    "dimx_slm_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dimx_set_context": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
+                                 c_void_p]),
     "dimx_decode_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_uint64,
@@ -119,6 +123,12 @@ def stream_ptr(device=None):
 def default_dims():
     d = Dims()
     load().dimx_default_dims(ctypes.byref(d))
+    return d
+
+
+def slm_dims():
+    d = default_dims()
+    d.variant = 2
     return d
 
 

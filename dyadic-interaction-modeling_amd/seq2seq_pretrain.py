@@ -169,3 +169,127 @@ class SLMFT(_EngineOwner):
                 tokens = tokens.view(mask.shape[0], S, -1)
             return total_loss, d, pred, tokens
         return total_loss, d, pred
+
+
+class SLM(_EngineOwner):
+    """Drop-in ``SLM`` (the pre-training model, reference ``code/seq2seq_pretrain.py:58-323``), forward pass only:
+    ``forward(v_speaker, v_listener, v_audio, mask, ...) -> (total_loss, dict, None)`` with the reference's six
+    dict entries.  The random frame masks of ``random_masking_unstructured`` (:170-183) are injectable
+    (``mask_speaker`` / ``mask_listener`` bool [B,T], True = masked); by default they are drawn like the reference.
+    The InfoNCE term (:270-289) is a handful of [B,384] torch ops on the engine's encoder outputs.
+    Backward / optimiser steps are out of scope."""
+    engine_variant = "slm"
+
+    def __init__(self, config_path=None, vq_speaker_ckpt=None, vq_listener_ckpt=None, synthetic_seed=20260928,
+                 numeric_mode=L.MODE_PARITY_F32):
+        super().__init__(numeric_mode)
+        config_path = config_path or ("./config.yaml" if os.path.isfile("./config.yaml") else _config.DEFAULT_CONFIG)
+        cfg = _config.load_cfg_from_cfg_file(config_path)
+        self.vq_dims = W.VQDims.from_cfg(cfg)
+        self.s2s = W.S2SDims()
+        self.speaker_face_quan_num = cfg.face_quan_num
+        self.speaker_zquant_dim = cfg.zquant_dim
+        spec = W.slm_spec(self.vq_dims, self.s2s)
+        build_param_tree(self, spec, W.synth_state_dict(spec, synthetic_seed))
+        for pre, ck in (("speaker_vq.", vq_speaker_ckpt), ("listener_vq.", vq_listener_ckpt)):
+            if ck is not None:
+                sd = torch.load(ck, map_location="cpu")["state_dict"]
+                own = self.state_dict()
+                self.load_state_dict({pre + k.replace("module.", "", 1): v for k, v in sd.items()
+                                      if pre + k.replace("module.", "", 1) in own}, strict=False)
+        self.eval()
+
+    def _engine_state_dict(self):
+        return self.state_dict()
+
+    @staticmethod
+    def random_masking_unstructured(x, mask, mask_ratio, generator=None):
+        """reference :170-183 -> bool [N,L], True = masked."""
+        N, L_ = mask.shape
+        out = torch.zeros(N, L_, dtype=torch.bool)
+        lens = mask.sum(1).tolist()
+        for i, n in enumerate(lens):
+            idx = torch.randperm(int(n), generator=generator)[:int(n * mask_ratio)]
+            out[i, :int(n)][idx] = True
+        return out.to(mask.device)
+
+    @torch.no_grad()
+    def forward_vq(self, v_speaker, v_listener, mask):
+        eng = self.engine(v_speaker.device)
+        xl, lens = compact_by_mask(v_listener, mask)
+        xs, _ = compact_by_mask(v_speaker, mask)
+        z_l = eng.vq_encode(1, xl.contiguous(), lens, pe_mode=0, pad_value=-100).long()
+        z_s = eng.vq_encode(0, xs.contiguous(), lens, pe_mode=0, pad_value=0).long()
+        return z_s, z_l
+
+    @torch.no_grad()
+    def forward_encoder(self, v_speaker, v_listener, mask, mask_ratio=0.15, mask_speaker=None, mask_listener=None):
+        if mask_speaker is None:
+            mask_speaker = self.random_masking_unstructured(v_speaker, mask, mask_ratio)
+        if mask_listener is None:
+            mask_listener = self.random_masking_unstructured(v_listener, mask, mask_ratio)
+        eng = self.engine(v_speaker.device)
+        u8 = lambda m: m.to(torch.uint8).contiguous()
+        x_s, x_l, x_joint = eng.slm_encode(v_speaker, v_listener, u8(mask), u8(mask_speaker), u8(mask_listener))
+        return x_s, x_l, x_joint, mask_speaker, mask_listener
+
+    @staticmethod
+    def forward_contrastive(s_rep, l_rep, mask, bidirect_contrast=False):
+        """reference :270-298."""
+        valid = mask[..., None].to(s_rep.dtype)
+        n = valid.sum(1)
+        s = F.normalize((s_rep * valid).sum(1) / n, dim=-1)
+        l_ = F.normalize((l_rep * valid).sum(1) / n, dim=-1)
+        total = s @ l_.t() / 0.05
+        ar = torch.arange(total.shape[0], device=total.device)
+
+        def one(t):
+            return (-torch.mean(torch.diag(F.log_softmax(t, dim=0))),
+                    (F.softmax(t, dim=0).argmax(0) == ar).sum() / t.shape[0])
+        nce, acc = one(total)
+        if bidirect_contrast:
+            n2, a2 = one(total.t())
+            nce, acc = (nce + n2) / 2, (acc + a2) / 2
+        return nce, acc
+
+    @torch.no_grad()
+    def _decode_tf(self, eng, x_joint, half, patch, z, v_audio, m8):
+        T = z.shape[1]
+        eng.set_context(x_joint[:, half * T:], v_audio, which_patch=patch, T=T)
+        logits, row_loss, amax = eng.decode_tf(z, m8, None)
+        n_valid = (z[:, 1:] != -100).sum().clamp(min=1)
+        return row_loss.sum() / n_valid, logits, amax
+
+    def forward_continuous_loss(self, pred, target, mask):
+        target = target[:, 1:, :]
+        m = mask[:, 1:].reshape(-1)
+        p = pred.reshape(-1, pred.shape[-1])[m]
+        t = target.reshape(-1, target.shape[-1])[m]
+        return torch.mean(F.pairwise_distance(p[:, 6:], t[:, 6:])) + torch.mean(F.pairwise_distance(p[:, 0:6], t[:, 0:6]))
+
+    @torch.no_grad()
+    def forward(self, v_speaker, v_listener, v_audio, mask, speaker_ids=None, listener_ids=None, mode="train",
+                mask_speaker=None, mask_listener=None, return_aux=False):
+        """reference :300-323 -> (total_loss, d, None)."""
+        mask = mask.bool()
+        eng = self.engine(v_speaker.device)
+        z_s, z_l = self.forward_vq(v_speaker, v_listener, mask)
+        x_s, x_l, x_joint, mask_speaker, mask_listener = self.forward_encoder(
+            v_speaker, v_listener, mask, mask_speaker=mask_speaker, mask_listener=mask_listener)
+        nce, c_acc = self.forward_contrastive(x_s, x_l, mask)
+        z_s = torch.where(mask_speaker, z_s, torch.full_like(z_s, -100))
+        z_l = torch.where(mask_listener, z_l, torch.full_like(z_l, -100))
+        m8 = mask.to(torch.uint8).contiguous()
+        # z_s is predicted from the listener half of x_joint, z_l from the speaker half (:227-228)
+        l_ce_s, px_s, am_s = self._decode_tf(eng, x_joint, 1, 1, z_s, v_audio, m8)
+        l_ce_l, px_l, am_l = self._decode_tf(eng, x_joint, 0, 0, z_l, v_audio, m8)
+        pred_s = eng.vq_decode(0, am_s, 0)
+        pred_l = eng.vq_decode(1, am_l, 0)
+        l_cont_s = self.forward_continuous_loss(pred_s, v_speaker, mask_speaker)
+        l_cont_l = self.forward_continuous_loss(pred_l, v_listener, mask_listener)
+        total_loss = l_ce_s + l_ce_l + l_cont_s + l_cont_l + nce
+        d = {"l_ce_s": l_ce_s, "l_ce_l": l_ce_l, "l_cont_s": l_cont_s, "l_cont_l": l_cont_l, "nce": nce, "c_acc": c_acc}
+        if return_aux:
+            return total_loss, d, None, {"x_s": x_s, "x_l": x_l, "x_joint": x_joint, "px_s": px_s, "px_l": px_l,
+                                         "pred_s": pred_s, "pred_l": pred_l}
+        return total_loss, d, None

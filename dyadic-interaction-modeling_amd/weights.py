@@ -249,6 +249,12 @@ def slmft_spec(vq: VQDims = VQDims(), d: S2SDims = S2SDims()):
     return s
 
 
+def slm_spec(vq: VQDims = VQDims(), d: S2SDims = S2SDims()):
+    """Every tensor of ``SLM().state_dict()`` (reference code/seq2seq_pretrain.py:58-165): the SLMFT set plus the
+    decoder's absolute positional embedding (``use_abs_pos_emb`` defaults to True there, :131)."""
+    return slmft_spec(vq, d) + [("decoder_joint.net.pos_emb.emb.weight", (d.max_seq_len, d.dec_dim), "pos_emb", 0)]
+
+
 # ----------------------------------------------------------------------------
 # synthetic initialisation
 # ----------------------------------------------------------------------------

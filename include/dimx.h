@@ -131,6 +131,24 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
  * x_s_out (optional): [B,T,512] f32 encoder output.  dimx_decode_tf then takes kv_mask = NULL and
  * dimx_generate produces T (not T-1) tokens per sequence: tokens [B*S, T], logits_out [B*S, T, 512]. */
 
+/* Variant 2 = the SLM pre-training model (reference code/seq2seq_pretrain.py:58-323; dims of the default
+ * geometry with dimx_dims.variant = 2): bidirectional encoders incl. encoder_l, decoder with absolute positional
+ * embedding.  dimx_slm_encode replaces SLM.forward_encoder (:200-221): v_speaker / v_listener [B,T,56] f32,
+ * mask [B,T] uint8 (1 = valid), mask_speaker / mask_listener [B,T] uint8 (1 = frame masked out: its input row is
+ * zeroed after the patch embedding was added; NULL = none); outputs f32 x_s, x_l [B,T,384], x_joint [B,2T,384]
+ * (speaker half first).  2T must not exceed max_seq_len. */
+int dimx_slm_encode(dimx_handle h, const float* v_speaker, const float* v_listener, const uint8_t* mask,
+                    const uint8_t* mask_speaker, const uint8_t* mask_listener, int B, int T, float* x_s,
+                    float* x_l, float* x_joint, void* ws, size_t ws_bytes, void* stream);
+
+/* Cross-attention context from a given encoder output (SLM.forward_decoder :223-229, SLMFT :445-446):
+ * context = cat(x + patch_embed_dec_{s (which_patch 0) | l (1, variant 2 only)}, v_audio) and the K/V projection
+ * of every decoder layer.  x: f32 [B, ldx_rows, 384] of which the first T rows of every clip are used
+ * (ldx_rows = T for a plain [B,T,384]; 2T to address a half of x_joint).  Then dimx_decode_tf / dimx_generate
+ * as after dimx_encode_ctx. */
+int dimx_set_context(dimx_handle h, const float* x, int ldx_rows, int which_patch, const float* v_audio, int B,
+                     int T, int for_generate, void* ws, size_t ws_bytes, void* stream);
+
 /* Test hook for variant 1: the x_speaker tensor of code/seq2seq.py:224-241 ([B,T,1024] f32, optional) and
  * the speaker code indices ([B,T*8] int32, -100 beyond the clip length, optional). */
 int dimx_legacy_speaker_features(dimx_handle h, const float* v_speaker, const uint8_t* mask, int B, int T,

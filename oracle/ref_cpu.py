@@ -28,6 +28,8 @@ Parity status
   ``VQSpeakerAutoEncoder`` imported by ``tests/golden/make_golden.py --legacy``; checked by
   ``tests/test_oracle_legacy.py``).  Its x-transformers encoder/decoder (dim 512, absolute positional embedding)
   shares the PARITY UNPINNED status and the self-consistency pins of the stage above.
+* ``SLM`` pre-training forward (``code/seq2seq_pretrain.py:58-323``): VQ-VAE halves pinned as above,
+  the x-transformers stage PARITY UNPINNED (``tests/test_oracle_slm.py``: structural properties only).
 """
 import math
 
@@ -499,3 +501,89 @@ def listener_generator_generate(sd, v_speaker, v_listener, mask, noise=None):
     enc = xt_encoder(sd, "generator.encoder.", x_speaker, mask, causal=False, depth=6, heads=8)
     z_pred = legacy_generate(sd, z_l[:, 0], z_l.shape[1], enc, mask, noise)
     return z_pred, z_l
+
+
+# ----------------------------------------------------------------------------
+# SLM pre-training forward (code/seq2seq_pretrain.py:58-323) -- SURVEY.md section 8(f2); x-transformers half
+# PARITY UNPINNED like the stages above, pinned by the same self-consistency properties
+# ----------------------------------------------------------------------------
+
+def slm_random_masks(mask, mask_ratio=0.15, generator=None):
+    """SLM.random_masking_unstructured (code/seq2seq_pretrain.py:170-183): per clip, int(len*ratio) distinct frames
+    among the valid ones.  True = masked (input zeroed, token predicted)."""
+    B, T = mask.shape
+    out = torch.zeros(B, T, dtype=torch.bool)
+    for i in range(B):
+        n = int(mask[i].sum())
+        idx = torch.randperm(n, generator=generator)[:int(n * mask_ratio)]
+        out[i, :n][idx] = True
+    return out
+
+
+def slm_forward_encoder(sd, v_speaker, v_listener, mask, mask_speaker, mask_listener):
+    """SLM.forward_encoder (code/seq2seq_pretrain.py:200-221) with the two random masks injected.  The encoders
+    get ``mask=mask`` only (no attn_mask): bidirectional attention with key padding."""
+    vs = v_speaker + sd["patch_embed_s"]
+    vl = v_listener + sd["patch_embed_l"]
+    vs = torch.where(mask_speaker[..., None], torch.zeros_like(vs), vs)
+    vl = torch.where(mask_listener[..., None], torch.zeros_like(vl), vl)
+    x_s = xt_encoder(sd, "encoder_s.", vs, mask, causal=False)
+    x_l = xt_encoder(sd, "encoder_l.", vl, mask, causal=False)
+    x_joint = xt_encoder(sd, "encoder_joint.", torch.cat([x_s, x_l], dim=1), torch.cat([mask, mask], dim=-1),
+                         causal=False)
+    x_l = xt_encoder(sd, "encoder_joint.", x_l, mask, causal=False)
+    x_s = xt_encoder(sd, "encoder_joint.", x_s, mask, causal=False)
+    ln = lambda x, n: F.layer_norm(x, (x.shape[-1],), sd[n + ".weight"], sd[n + ".bias"], LN_EPS)
+    return ln(x_s, "norm_s"), ln(x_l, "norm_l"), ln(x_joint, "norm")
+
+
+def slm_contrastive(s_rep, l_rep, mask):
+    """SLM.forward_contrastive, single direction (code/seq2seq_pretrain.py:270-289)."""
+    lens = mask.sum(1)
+    s = torch.stack([s_rep[i, :lens[i]].mean(0) for i in range(len(lens))])
+    l = torch.stack([l_rep[i, :lens[i]].mean(0) for i in range(len(lens))])
+    s, l = F.normalize(s, dim=-1), F.normalize(l, dim=-1)
+    total = s @ l.t() / 0.05
+    nce = -torch.mean(torch.diag(F.log_softmax(total, dim=0)))
+    c_acc = (F.softmax(total, dim=0).argmax(0) == torch.arange(total.shape[0])).sum() / total.shape[0]
+    return nce, c_acc
+
+
+def slm_decoder_tf(sd, z, context, context_mask, prefix="decoder_joint.net.", depth=4, heads=12):
+    """decoder_joint(z, context, context_mask, return_outputs=True) of SLM: AutoregressiveWrapper (mask_prob 0)
+    around a TransformerWrapper WITH absolute positional embedding (code/seq2seq_pretrain.py:131,160-165)."""
+    inp, target = z[:, :-1], z[:, 1:]
+    inp = torch.where(inp == -100, torch.zeros_like(inp), inp)
+    n = inp.shape[1]
+    h = sd[prefix + "token_emb.emb.weight"][inp]
+    h = h + sd[prefix + "pos_emb.emb.weight"][:n] * (h.shape[-1] ** -0.5)
+    causal = ~torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1)
+    h = xt_decoder_layers(sd, prefix, h, context, context_mask, causal, None, depth, heads)
+    logits = F.linear(h, sd[prefix + "to_logits.weight"])
+    loss = F.cross_entropy(logits.permute(0, 2, 1), target, ignore_index=-100)
+    return loss, logits
+
+
+def slm_forward(sd, v_speaker, v_listener, v_audio, mask, mask_speaker, mask_listener, return_aux=False):
+    """SLM.forward (code/seq2seq_pretrain.py:300-323) -> (total_loss, dict, None)."""
+    z_s, z_l = forward_vq(sd, v_speaker, v_listener, mask)
+    x_s, x_l, x_joint = slm_forward_encoder(sd, v_speaker, v_listener, mask, mask_speaker, mask_listener)
+    nce, c_acc = slm_contrastive(x_s, x_l, mask)
+    T = x_s.shape[1]
+    xj_s, xj_l = x_joint[:, :T], x_joint[:, T:]
+    z_s = torch.where(mask_speaker, z_s, torch.full_like(z_s, -100))
+    z_l = torch.where(mask_listener, z_l, torch.full_like(z_l, -100))
+    ctx_s = torch.cat([xj_s + sd["patch_embed_dec_s"], v_audio], dim=-1)
+    ctx_l = torch.cat([xj_l + sd["patch_embed_dec_l"], v_audio], dim=-1)
+    l_ce_s, px_s = slm_decoder_tf(sd, z_s, ctx_l, mask)
+    l_ce_l, px_l = slm_decoder_tf(sd, z_l, ctx_s, mask)
+    pred_s = vq_decode(sd, px_s.argmax(-1), "speaker_vq.")
+    pred_l = vq_decode(sd, px_l.argmax(-1), "listener_vq.")
+    l_cont_s = continuous_loss(pred_s, v_speaker, mask_speaker)
+    l_cont_l = continuous_loss(pred_l, v_listener, mask_listener)
+    total = l_ce_s + l_ce_l + l_cont_s + l_cont_l + nce
+    d = {"l_ce_s": l_ce_s, "l_ce_l": l_ce_l, "l_cont_s": l_cont_s, "l_cont_l": l_cont_l, "nce": nce, "c_acc": c_acc}
+    if return_aux:
+        return total, d, None, {"x_s": x_s, "x_l": x_l, "x_joint": x_joint, "px_s": px_s, "px_l": px_l,
+                                "z_s": z_s, "z_l": z_l, "pred_s": pred_s, "pred_l": pred_l}
+    return total, d, None
