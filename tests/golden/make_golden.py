@@ -184,7 +184,7 @@ def main():
     print(json.dumps(report, indent=1, sort_keys=True))
 
 
-if __name__ == "__main__" and "--legacy" not in sys.argv and "--mymetrics" not in sys.argv:
+if __name__ == "__main__" and "--legacy" not in sys.argv and "--mymetrics" not in sys.argv and "--postprocess" not in sys.argv:
     main()
 
 
@@ -272,3 +272,23 @@ def mymetrics_fixture():
 
 if __name__ == "__main__" and "--mymetrics" in sys.argv:
     mymetrics_fixture()
+
+
+def postprocess_fixture():
+    """smooth_logits_matrix of reference code/postprocess2emoca.py:7-31.  The script runs its export loop at import
+    time, so only that function definition is taken out of the parsed module and executed on a seeded input."""
+    import ast
+    src = open(os.path.join(REF, "postprocess2emoca.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "smooth_logits_matrix"]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "postprocess2emoca.py", "exec"), ns)
+    x = prng.normal(SEED, "golden.post.x", (37, 56)).astype(np.float64)
+    y = ns["smooth_logits_matrix"](x.copy())
+    np.savez_compressed(os.path.join(HERE, "postprocess_smooth.npz"), y=y)
+    print("postprocess_smooth: zero head rows", int((np.abs(y[:5]).sum(1) == 0).sum()), "zero tail rows",
+          int((np.abs(y[-4:]).sum(1) == 0).sum()))
+
+
+if __name__ == "__main__" and "--postprocess" in sys.argv:
+    postprocess_fixture()

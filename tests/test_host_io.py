@@ -72,3 +72,18 @@ def test_vico_dataset_reads_reference_pickles(tmp_path):
     x, y, path, spk, lst, sent = ds[0]
     assert tuple(x.shape) == (9, 824) and torch.all(x[:, :56] == 1.0) and torch.all(x[:, 56:] == 0.0)
     assert y[1, 0].item() == 56.0 and spk == 20 and lst == 10 and sent == 1 and path.endswith("a01.pkl")
+
+
+def test_postprocess_matches_reference(golden_dir, tmp_path):
+    from dimx import postprocess2emoca as pp
+    x = prng.normal(SEED, "golden.post.x", (37, 56)).astype(np.float64)
+    y = pp.smooth_logits_matrix(x)
+    ref = np.load(os.path.join(golden_dir, "postprocess_smooth.npz"))["y"]
+    assert np.allclose(y, ref, rtol=0, atol=1e-12)
+    assert (y[:5] == 0).all() and (y[-4:] == 0).all() and (y[5] != 0).any()
+    data = {"y_pred": [x.astype(np.float32)], "y_true": [x.astype(np.float32)], "data_ids": ["/a/b/clip7.pkl"]}
+    n = pp.export_predictions(data, str(tmp_path / "p"), str(tmp_path / "g"))
+    assert n == 37
+    pose = np.load(tmp_path / "p" / "clip7" / "10" / "pose.npy")
+    exp = np.load(tmp_path / "g" / "clip7" / "10" / "exp.npy")
+    assert pose.shape == (6,) and exp.shape == (50,) and np.allclose(pose, y[10, :6], atol=1e-6)
