@@ -994,12 +994,12 @@ static Arena scratch_arena(const dimx_ctx* c, void* ws, size_t ws_bytes, int B, 
 extern "C" {
 
 size_t dimx_workspace_bytes(dimx_handle h, int B, int T) {
-    if (!h || B < 1 || T < 1) return 0;
+    if (!h || B < 1 || T < 1 || T > h->d.max_seq_len) return 0;  // 0 = shape not supported
     return workspace_bytes(h, B, T);
 }
 
 size_t dimx_workspace_bytes_samples(dimx_handle h, int B, int T, int n_samples) {
-    if (!h || B < 1 || T < 1 || n_samples < 1) return 0;
+    if (!h || B < 1 || T < 1 || n_samples < 1 || T > h->d.max_seq_len) return 0;
     return workspace_bytes(h, B, T, n_samples);
 }
 

@@ -90,7 +90,8 @@ int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n);
 /* number of hot-path tensors still missing (0 = ready) */
 int dimx_missing_weights(dimx_handle h);
 
-/* Bytes of caller-provided device workspace needed by any stage call at (B, T). */
+/* Bytes of caller-provided device workspace needed by any stage call at (B, T); 0 = shape not supported
+ * (B < 1, T < 1 or T > max_seq_len). */
 size_t dimx_workspace_bytes(dimx_handle h, int B, int T);
 /* same, when dimx_generate will draw n_samples sequences per clip */
 size_t dimx_workspace_bytes_samples(dimx_handle h, int B, int T, int n_samples);
