@@ -182,7 +182,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                 int cnt = 0;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) cnt += __popcll(__ballot(key[c] >= cand));
-                if (cnt >= top_k) thr = cand;
+                if (cnt >= top_k) {
+                    thr = cand;
+                    // exactly k keys at or above the candidate: that IS the top-k set (every key >= its minimum is
+                    // already counted), the remaining bits could only tighten the threshold onto that minimum
+                    if (cnt == top_k) break;
+                }
             }
         }
         const float inv_t = 1.0f / temperature;

@@ -82,8 +82,14 @@ def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=Tru
             def consider(yp):           # yp [B, T-1, 56] numpy: one sample per clip
                 for j in range(B):
                     n = src_len[j] - 1
-                    cfid = clip_fd(y_true[j][:n], yp[j][:n])
-                    if cfid < cur_best[j]:
+                    try:
+                        cfid = clip_fd(y_true[j][:n], yp[j][:n])
+                    except ValueError:
+                        # scipy's sqrtm left an imaginary component (rank-deficient covariance of a very short
+                        # clip): the reference's calculate_frechet_distance raises here and aborts the epoch;
+                        # this candidate is skipped instead (kept only if nothing else was scored)
+                        cfid = float("inf")
+                    if cfid < cur_best[j] or best[j] is None:
                         best[j] = yp[j][:n].copy()
                         cur_best[j] = cfid
             if batched:

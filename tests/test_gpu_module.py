@@ -81,6 +81,7 @@ def test_vq_autoencoder_module_roundtrip(golden_dir):
 
 def test_evaluation_engine_protocol(model):
     from dimx import x_engine_pt
+    torch.manual_seed(1234)     # the sampling seeds are drawn from torch's generator
     B, T = 3, 32
     lens = [32, 20, 11]
     v_s, v_l, v_a, mask = _clips(B, T, lens)
