@@ -71,15 +71,6 @@ __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + (((
 //   * a plain row-major destination gets a dedicated path (one 64-bit base per column, 32-bit row offsets);
 //     the generic path handles head-major K/V caches, transposed V^T and per-row positional adds.
 // ------------------------------------------------------------------------------------------------
-// a.seg[s] with a run-time s would force the whole by-value kernel argument into scratch (336 bytes copied by
-// every lane in the prologue, every later field read a scratch load): select among constant indices instead
-__device__ __forceinline__ OutSeg pick_seg(const GemmArgs& a, int s) {
-    OutSeg g = a.seg[0];
-    if (s == 1) g = a.seg[1];
-    if (s == 2) g = a.seg[2];
-    return g;
-}
-
 template <int ACT, bool FAST> __device__ __forceinline__ float act_fn(float x) {
     if (ACT == ACT_LEAKY) return x > 0.f ? x : 0.2f * x;
     if (ACT == ACT_GELU_TANH) {
@@ -145,7 +136,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
             s = n / a.seg_width;
             nn = n - s * a.seg_width;
         }
-        const OutSeg sg = pick_seg(a, s);
+        const OutSeg sg = a.seg[s];
         const int hh = nn / sg.D, dd = nn - hh * sg.D;
         OutT* obase = (OutT*)sg.ptr + (long)hh * sg.sh + (long)dd * sg.sd;
 #pragma unroll
@@ -186,214 +177,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Staged epilogue (large M: the prefill GEMMs).  The MFMA accumulator layout gives a lane one column and 16
-// scattered rows, so direct stores are 2- or 4-byte pieces (rocprof: 170-290 us of a 470-520 us K/V projection
-// were the epilogue, 1.4 TB/s of output).  Here each wave stages a 32-row slice of its tile in a private LDS
-// region (the main loop's ring, free after a block barrier) and writes it out as 16-byte pieces that are
-// contiguous along the output row.  The accumulators are dumped raw (f32) so that the main loop's register
-// allocation is untouched; bias / activation / positional row / residual run on the row-contiguous data with the
-// same arithmetic as epilogue_tile (bit-identical results).
-// ------------------------------------------------------------------------------------------------
-// One 32-row slice: raw f32 accumulators of the wave sit in its private LDS region as [32][NI*32]; this writes
-// them out.  Row-major segments: a lane owns 4 consecutive columns of a row (bias / activation / positional row /
-// residual are applied here on row-contiguous data, then one 8-byte (bf16) or 16-byte (f32) store; 16 or 32 lanes
-// cover a full row of the wave tile).  Transposed segments (V^T: contiguous along time): a lane owns 4
-// consecutive rows of one column and stores them packed when the launcher proved that legal (vt_pack4).
-template <typename OutT, int NI, int ACT, bool FAST>
-__device__ __forceinline__ void stage_copy_out(const GemmArgs& a, const unsigned char* stage, int mb, int n0w, int lane) {
-    constexpr int ES = sizeof(OutT);
-    constexpr int ROWF = NI * 32;      // floats per staged row
-    constexpr int PPR = NI * 8;        // 4-column pieces per row
-    constexpr int RPI = 64 / PPR;      // rows per wave-wide step
-    constexpr int NIT = 32 / RPI;
-    const int rowT = a.rowT;
-    int b0, t0;
-    if (rowT == 1) {
-        b0 = mb;
-        t0 = 0;
-    } else {
-        b0 = mb / rowT;
-        t0 = mb - b0 * rowT;
-    }
-    // ---- row-major segments
-    {
-        const int cc = lane % PPR, crow = lane / PPR;
-        const int n = n0w + cc * 4;
-        const int nc = n < a.N ? n : 0;
-        int s = 0, nn = nc;
-        if (a.nseg > 1) {
-            s = nc / a.seg_width;
-            nn = nc - s * a.seg_width;
-        }
-        const OutSeg sg = pick_seg(a, s);
-        if (n < a.N && sg.sd == 1) {
-            const int hh = nn / sg.D, dd = nn - hh * sg.D;
-            OutT* const cbase = (OutT*)sg.ptr + (long)hh * sg.sh + dd;
-            const float4 bias4 = a.bias ? *(const float4*)(a.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
-            int b = b0, t = rowT == 1 ? 0 : t0 + crow;
-            if (rowT != 1 && t >= rowT) {
-                t -= rowT;
-                ++b;
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int row = it * RPI + crow;
-                const int m = mb + row;
-                if (m < a.M) {
-                    float4 v = *(const float4*)(stage + (row * ROWF + cc * 4) * 4);
-                    v.x = act_fn<ACT, FAST>(v.x + bias4.x);
-                    v.y = act_fn<ACT, FAST>(v.y + bias4.y);
-                    v.z = act_fn<ACT, FAST>(v.z + bias4.z);
-                    v.w = act_fn<ACT, FAST>(v.w + bias4.w);
-                    const int bb = rowT == 1 ? m : b;
-                    if (a.rowadd_mode) {
-                        const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? bb / a.rowadd_div + a.rowadd_off : a.rowadd_off);
-                        const float4 q = *(const float4*)(a.rowadd + (size_t)ri * a.ld_rowadd + nc);
-                        v.x += q.x * a.rowadd_scale;
-                        v.y += q.y * a.rowadd_scale;
-                        v.z += q.z * a.rowadd_scale;
-                        v.w += q.w * a.rowadd_scale;
-                    }
-                    if (a.residual) {
-                        const float4 q = *(const float4*)(a.residual + (size_t)m * a.ldr + nc);
-                        v.x += q.x;
-                        v.y += q.y;
-                        v.z += q.z;
-                        v.w += q.w;
-                    }
-                    OutT* p = cbase + (long)bb * sg.sb + (long)t * sg.st;
-                    if (ES == 2) {
-                        *(uint2*)p = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-                    } else {
-                        *(float4*)p = v;
-                    }
-                }
-                if (rowT != 1) {
-                    t += RPI;
-                    if (t >= rowT) {
-                        t -= rowT;
-                        ++b;
-                    }
-                }
-            }
-        }
-    }
-    // ---- transposed segments (whole 32-column blocks belong to one segment: seg_width % 32 == 0)
-    if (a.nseg > 1) {
-        const int col = lane & 31, qh = lane >> 5;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int nb = n0w + j * 32;
-            if (nb >= a.N) continue;
-            const int s = nb / a.seg_width;
-            const OutSeg sg = pick_seg(a, s);
-            if (sg.sd == 1) continue;  // wave-uniform
-            const int n = nb + col;
-            const int nc = n < a.N ? n : a.N - 1;
-            const int nn = nc - s * a.seg_width;
-            const int hh = nn / sg.D, dd = nn - hh * sg.D;
-            OutT* const obase = (OutT*)sg.ptr + (long)hh * sg.sh + (long)dd * sg.sd;
-            const float bias_v = a.bias ? a.bias[nc] : 0.f;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r0 = (it * 2 + qh) * 4;  // first of 4 consecutive rows
-                const int m0r = mb + r0;
-                int b = b0, t = t0 + r0;
-                if (rowT == 1) {
-                    b = m0r;
-                    t = 0;
-                } else if (t >= rowT) {
-                    t -= rowT;
-                    ++b;
-                }
-                float v4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = act_fn<ACT, FAST>(*(const float*)(stage + ((r0 + q) * ROWF + j * 32 + col) * 4) + bias_v);
-                    const int m = m0r + q;
-                    const int mc = m < a.M ? m : a.M - 1;
-                    if (a.rowadd_mode) {
-                        int bq = b, tq = t + q;
-                        if (rowT != 1 && tq >= rowT) {
-                            tq -= rowT;
-                            ++bq;
-                        }
-                        const int ri = a.rowadd_mode == 1 ? tq : (a.rowadd_mode == 2 ? (rowT == 1 ? mc : bq) / a.rowadd_div + a.rowadd_off : a.rowadd_off);
-                        v += a.rowadd[(size_t)ri * a.ld_rowadd + nc] * a.rowadd_scale;
-                    }
-                    if (a.residual) v += a.residual[(size_t)mc * a.ldr + nc];
-                    v4[q] = v;
-                }
-                if (n >= a.N || m0r >= a.M) continue;
-                if (a.vt_pack4) {  // 4 consecutive time steps of one clip (rowT % 4 == 0, M % 4 == 0, st == 1)
-                    OutT* p = obase + (long)b * sg.sb + (long)t * sg.st;
-                    if (ES == 2) {
-                        *(uint2*)p = make_uint2(pack_bf16x2(v4[0], v4[1]), pack_bf16x2(v4[2], v4[3]));
-                    } else {
-                        *(float4*)p = make_float4(v4[0], v4[1], v4[2], v4[3]);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (m0r + q >= a.M) continue;
-                        int bq = b, tq = t + q;
-                        if (rowT == 1) {
-                            bq = m0r + q;
-                            tq = 0;
-                        } else if (tq >= rowT) {
-                            tq -= rowT;
-                            ++bq;
-                        }
-                        store_from_f32<OutT>(obase + (long)bq * sg.sb + (long)tq * sg.st, v4[q]);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// slices I .. MI-1 of the wave tile: raw dump (compile-time accumulator indices, immediate LDS offsets), copy-out
-template <typename OutT, int I, int MI, int NI, int ACT, bool FAST>
-__device__ __forceinline__ void stage_slices(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w,
-                                             int half, int l31, unsigned char* stage) {
-    if constexpr (I < MI) {
-        const int mb = m0w + I * 32;
-        if (mb < a.M) {
-            float* base = (float*)stage + (4 * half) * (NI * 32) + l31;
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * (NI * 32) + j * 32] = acc[I][j][r];
-            // the slice is re-read with a different lane<->element mapping (and vector type): keep the compiler from
-            // moving those loads above the stores; the LDS itself executes one wave's operations in order
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stage_copy_out<OutT, NI, ACT, FAST>(a, stage, mb, n0w, half * 32 + l31);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next slice overwrites
-        }
-        stage_slices<OutT, I + 1, MI, NI, ACT, FAST>(a, acc, m0w, n0w, half, l31, stage);
-    }
-}
-
-template <typename OutT, int MI, int NI, int ACT, bool FAST>
-__device__ __forceinline__ void epilogue_staged(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w,
-                                                int half, int l31, unsigned char* stage) {
-    stage_slices<OutT, 0, MI, NI, ACT, FAST>(a, acc, m0w, n0w, half, l31, stage);
-}
-
 template <typename T, typename OutT, int MI, int NI>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w, int half,
-                                         int l31, int split, unsigned char* stage = nullptr) {
+                                         int l31, int split) {
     constexpr bool FAST = sizeof(T) == 2;
-    if (stage) {
-        switch (a.act) {
-            case ACT_LEAKY: epilogue_staged<OutT, MI, NI, ACT_LEAKY, FAST>(a, acc, m0w, n0w, half, l31, stage); break;
-            case ACT_GELU_TANH: epilogue_staged<OutT, MI, NI, ACT_GELU_TANH, FAST>(a, acc, m0w, n0w, half, l31, stage); break;
-            case ACT_GELU_ERF: epilogue_staged<OutT, MI, NI, ACT_GELU_ERF, FAST>(a, acc, m0w, n0w, half, l31, stage); break;
-            default: epilogue_staged<OutT, MI, NI, ACT_NONE, FAST>(a, acc, m0w, n0w, half, l31, stage); break;
-        }
-        return;
-    }
     switch (a.act) {
         case ACT_LEAKY: epilogue_tile<OutT, MI, NI, ACT_LEAKY, FAST>(a, acc, m0w, n0w, half, l31, split); break;
         case ACT_GELU_TANH: epilogue_tile<OutT, MI, NI, ACT_GELU_TANH, FAST>(a, acc, m0w, n0w, half, l31, split); break;
@@ -579,17 +366,8 @@ template <int MI, int NI> struct FragMma<float, MI, NI> {
 };
 
 // ABL (ablation, tuning only): 0 normal, 1 = no MFMA/ds_read in the loop (DMA only), 2 = no DMA in the loop
-// waves per SIMD the LDS footprint allows (blocks/CU x waves/block / 4 SIMDs): tells the register allocator its
-// budget, so that epilogue code can never cost the main loop a resident block
-constexpr int glds_waves_per_simd(int bm, int bn, int nw, int stages) {
-    int blocks = (160 * 1024) / (stages * (bm + bn) * 128);
-    blocks = blocks < 1 ? 1 : blocks;
-    int w = blocks * nw / 4;
-    return w < 1 ? 1 : (w > 4 ? 4 : w);
-}
-
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
-__global__ __launch_bounds__(WM* WN * 64, glds_waves_per_simd(BM, BN, WM* WN, STAGES)) void gemm_glds_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a) {
     constexpr int NW = WM * WN;
     constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
     constexpr int EPC = Elem<T>::kPerChunk;
@@ -624,7 +402,6 @@ __global__ __launch_bounds__(WM* WN * 64, glds_waves_per_simd(BM, BN, WM* WN, ST
     int nk = nk_all - kt0;
     nk = nk > per ? per : nk;
     if (nk <= 0) return;
-    if (a.dbg & 2) nk = 1;
 
     // DMA piece j of this wave covers tile rows (wave*L + j)*8 .. +7; lane l -> row + (l>>3), slot l&7
     const T* gA[LA];
@@ -731,17 +508,8 @@ __global__ __launch_bounds__(WM* WN * 64, glds_waves_per_simd(BM, BN, WM* WN, ST
         }
     }
 
-    if (a.dbg & 1) return;
     // ---- epilogue (split-K: this split's partial sums go to its own f32 slab)
-    unsigned char* stage = nullptr;
-    constexpr int SLICE = 32 * NI * 32 * 4;  // raw f32 slice per wave
-    if constexpr (SLICE * NW <= STAGES * TILE_BYTES) {  // (the single-buffer tuning configs are too small)
-        if (a.stage_out) {
-            __syncthreads();  // every wave is done reading the ring (all DMA landed before the last k-tile)
-            stage = smem + wave * SLICE;
-        }
-    }
-    epilogue<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, split, stage);
+    epilogue<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, split);
 }
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
@@ -771,10 +539,33 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
         case 1: return launch_glds<T, OutT, 128, 128, 2, 2, 2>(a, s);
+        case 2: return launch_glds<T, OutT, 128, 128, 2, 2, 3>(a, s);
+        case 3: return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
         case 4: return launch_glds<T, OutT, 64, 64, 2, 2, 3>(a, s);
+        case 5: return launch_glds<T, OutT, 64, 64, 2, 2, 2>(a, s);
+        case 6: return launch_glds<T, OutT, 128, 64, 2, 2, 3>(a, s);
+        case 7: return launch_glds<T, OutT, 128, 64, 2, 2, 2>(a, s);
+        case 8: return launch_glds<T, OutT, 64, 128, 2, 2, 3>(a, s);
+        case 9: return launch_glds<T, OutT, 64, 64, 2, 2, 8>(a, s);
+        case 10: return launch_glds<T, OutT, 64, 64, 2, 2, 6>(a, s);
+        case 11: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
+        case 12: return launch_glds<T, OutT, 128, 64, 2, 2, 4>(a, s);
+        case 13: return launch_glds<T, OutT, 128, 64, 4, 2, 3>(a, s);   // 8 waves
         case 14: return launch_glds<T, OutT, 128, 128, 4, 2, 2>(a, s);  // 8 waves
+        case 15: return launch_glds<T, OutT, 128, 128, 4, 2, 3>(a, s);  // 8 waves
+        case 16: return launch_glds<T, OutT, 256, 64, 8, 1, 2>(a, s);   // 8 waves, whole-M column tile
+        case 17: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 144 KB ring
         case 18: return launch_glds<T, OutT, 256, 128, 4, 2, 2>(a, s);  // 8 waves, 96 KB ring
         case 19: return launch_glds<T, OutT, 256, 256, 4, 2, 2>(a, s);  // 8 waves, 128 KB ring
+        case 22: return launch_glds<T, OutT, 128, 128, 2, 2, 1>(a, s);  // single buffer, 32 KB: up to 5 blocks/CU
+        case 23: return launch_glds<T, OutT, 128, 128, 4, 2, 1>(a, s);  // 8 waves, single buffer
+        case 24: return launch_glds<T, OutT, 128, 64, 2, 2, 1>(a, s);   // single buffer, 24 KB
+        case 27: return launch_glds<T, OutT, 256, 128, 4, 2, 1>(a, s);  // 8 waves, single 48 KB buffer: 3 blocks/CU
+        case 28: return launch_glds<T, OutT, 256, 256, 4, 2, 1>(a, s);  // 8 waves, single 64 KB buffer: 2 blocks/CU
+        case 25: return launch_glds<T, OutT, 128, 128, 4, 2, 2, 1>(a, s);  // ablation of cfg 14: DMA only
+        case 26: return launch_glds<T, OutT, 128, 128, 4, 2, 2, 2>(a, s);  // ablation of cfg 14: compute only
+        case 20: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 1>(a, s);  // ablation: DMA only
+        case 21: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 2>(a, s);  // ablation: compute only
         default: break;
     }
     set_error("gemm: unknown cfg %d", cfg);
@@ -805,39 +596,10 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
         return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
     }
     int cfg = a.cfg;
-    static const int cfg_large = getenv("DIMX_GEMM_CFG_LARGE") ? atoi(getenv("DIMX_GEMM_CFG_LARGE")) : 14;
-    if (cfg == 0) cfg = tiles128 >= 512 ? cfg_large : 4;  // measured on MI355X (tools/bench_gemm.py): 128x128 for large M, 64x64x3 for decode
+    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : 4;  // measured on MI355X (tools/bench_gemm.py): 128x128 8-wave for large M, 64x64x3 for decode
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;
-    }
-    // large-M outputs leave through LDS as 16-byte row pieces (epilogue_staged) when the output map allows it
-    a.stage_out = 0;
-    a.vt_pack4 = 0;
-    static const int dbg = getenv("DIMX_GEMM_DBG") ? atoi(getenv("DIMX_GEMM_DBG")) : 0;
-    a.dbg = dbg;
-    static const bool no_stage = getenv("DIMX_NO_STAGE") != nullptr;
-    if (!no_stage && !a.out_slabs && a.M >= 2048 && (a.rowT == 1 || a.rowT >= 32)) {
-        const int epo = 16 / (int)sizeof(OutT);
-        (void)epo;
-        bool ok = a.N % 4 == 0 && (a.nseg == 1 || a.seg_width % 32 == 0), any_row = false, pack = true;
-        ok = ok && (!a.bias || ((uintptr_t)a.bias % 16) == 0);
-        ok = ok && (!a.residual || (a.ldr % 4 == 0 && ((uintptr_t)a.residual % 16) == 0));
-        ok = ok && (!a.rowadd_mode || (a.ld_rowadd % 4 == 0 && ((uintptr_t)a.rowadd % 16) == 0));
-        for (int i = 0; i < a.nseg; ++i) {
-            const OutSeg& g = a.seg[i];
-            if (g.sd == 1) {
-                any_row = true;
-                ok = ok && ((uintptr_t)g.ptr % 16) == 0 && g.sb % 4 == 0 && g.st % 4 == 0 && g.sh % 4 == 0 && g.D % 4 == 0;
-            } else {
-                pack = pack && g.st == 1 && a.rowT % 4 == 0 && a.M % 4 == 0 && g.sb % 4 == 0 && g.sd % 4 == 0 &&
-                       g.sh % 4 == 0 && ((uintptr_t)g.ptr % (4 * sizeof(OutT))) == 0;
-            }
-        }
-        if (ok && any_row) {
-            a.stage_out = 1;
-            a.vt_pack4 = pack ? 1 : 0;
-        }
     }
     return launch_by_cfg<T, OutT>(a, cfg, s);
 }

@@ -12,7 +12,7 @@ from ctypes import (POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdimx_hip.so")
+LIB_PATH = os.environ.get("DIMX_LIB", os.path.join(HERE, "libdimx_hip.so"))   # DIMX_LIB: A/B a saved build
 
 MODE_PARITY_F32 = 0
 MODE_PERF_BF16 = 1
@@ -94,6 +94,8 @@ def load(build_if_missing=True):
         _build.build()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if "DIMX_LIB" in os.environ and not hasattr(lib, name):
+            continue                  # A/B run against an older saved build: newer entry points are absent
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
