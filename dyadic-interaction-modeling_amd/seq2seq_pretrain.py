@@ -293,3 +293,14 @@ class SLM(_EngineOwner):
             return total_loss, d, None, {"x_s": x_s, "x_l": x_l, "x_joint": x_joint, "px_s": px_s, "px_l": px_l,
                                          "pred_s": pred_s, "pred_l": pred_l}
         return total_loss, d, None
+
+
+class SpeakerSLMFT(nn.Module):
+    """Import-compatibility placeholder for reference ``code/seq2seq_pretrain.py:516-757`` (``test_s2s_pretrain.py:7``
+    imports it next to SLMFT).  The speaker-generation model depends on the EMOCA->FLAME converter and BIWI templates
+    and is outside the DIM-Listener path (out of scope): constructing it fails loudly."""
+
+    def __init__(self, *a, **kw):
+        super().__init__()
+        raise NotImplementedError("SpeakerSLMFT is not built: only the DIM-Listener path (SLMFT, SLM, the legacy "
+                                  "ListenerGenerator and the VQ-VAEs) runs on the HIP library")
