@@ -539,33 +539,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
         case 1: return launch_glds<T, OutT, 128, 128, 2, 2, 2>(a, s);
-        case 2: return launch_glds<T, OutT, 128, 128, 2, 2, 3>(a, s);
-        case 3: return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
         case 4: return launch_glds<T, OutT, 64, 64, 2, 2, 3>(a, s);
-        case 5: return launch_glds<T, OutT, 64, 64, 2, 2, 2>(a, s);
-        case 6: return launch_glds<T, OutT, 128, 64, 2, 2, 3>(a, s);
-        case 7: return launch_glds<T, OutT, 128, 64, 2, 2, 2>(a, s);
-        case 8: return launch_glds<T, OutT, 64, 128, 2, 2, 3>(a, s);
-        case 9: return launch_glds<T, OutT, 64, 64, 2, 2, 8>(a, s);
-        case 10: return launch_glds<T, OutT, 64, 64, 2, 2, 6>(a, s);
-        case 11: return launch_glds<T, OutT, 128, 128, 2, 2, 4>(a, s);
-        case 12: return launch_glds<T, OutT, 128, 64, 2, 2, 4>(a, s);
-        case 13: return launch_glds<T, OutT, 128, 64, 4, 2, 3>(a, s);   // 8 waves
         case 14: return launch_glds<T, OutT, 128, 128, 4, 2, 2>(a, s);  // 8 waves
-        case 15: return launch_glds<T, OutT, 128, 128, 4, 2, 3>(a, s);  // 8 waves
-        case 16: return launch_glds<T, OutT, 256, 64, 8, 1, 2>(a, s);   // 8 waves, whole-M column tile
-        case 17: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 144 KB ring
         case 18: return launch_glds<T, OutT, 256, 128, 4, 2, 2>(a, s);  // 8 waves, 96 KB ring
         case 19: return launch_glds<T, OutT, 256, 256, 4, 2, 2>(a, s);  // 8 waves, 128 KB ring
-        case 22: return launch_glds<T, OutT, 128, 128, 2, 2, 1>(a, s);  // single buffer, 32 KB: up to 5 blocks/CU
-        case 23: return launch_glds<T, OutT, 128, 128, 4, 2, 1>(a, s);  // 8 waves, single buffer
-        case 24: return launch_glds<T, OutT, 128, 64, 2, 2, 1>(a, s);   // single buffer, 24 KB
-        case 27: return launch_glds<T, OutT, 256, 128, 4, 2, 1>(a, s);  // 8 waves, single 48 KB buffer: 3 blocks/CU
-        case 28: return launch_glds<T, OutT, 256, 256, 4, 2, 1>(a, s);  // 8 waves, single 64 KB buffer: 2 blocks/CU
-        case 25: return launch_glds<T, OutT, 128, 128, 4, 2, 2, 1>(a, s);  // ablation of cfg 14: DMA only
-        case 26: return launch_glds<T, OutT, 128, 128, 4, 2, 2, 2>(a, s);  // ablation of cfg 14: compute only
-        case 20: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 1>(a, s);  // ablation: DMA only
-        case 21: return launch_glds<T, OutT, 64, 64, 2, 2, 3, 2>(a, s);  // ablation: compute only
         default: break;
     }
     set_error("gemm: unknown cfg %d", cfg);

@@ -84,7 +84,7 @@ if which in ("prefill", "all"):
               ("xe_qkv N2304 K384", 2304, 384, True, False, 0), ("xe_out N384 K768", 384, 768, False, True, 0),
               ("ckv N1536 K1152", 1536, 1152, True, False, 0)]
     for name, N, K, obf, inpl, act in shapes:
-        for cfg in (14, 27, 28):
+        for cfg in (14, 18, 19):
             run(name, 76800, N, K, obf, inpl, cfg, 0, act, iters=6, ncopies=2)
 if which == "kscan":
     # main-loop rate vs fixed (prologue + epilogue) cost: same M, N at two K; plus a square reference shape
