@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      unsigned* __restrict__ done_ctr,
                                                      const float* __restrict__ pos_table, float pos_scale,
                                                      int pos_rows) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint64_t step = step_dev ? (uint64_t)*step_dev : step_host;
     if (row < R) {
     const float* lr = logits + (size_t)row * ld;
@@ -422,7 +422,8 @@ int launch_sample(const float* logits, int ld_logits, int R, int top_k, float te
                   int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
                   hipStream_t s, const float* pos_table, float pos_scale, int pos_rows) {
     DIMX_REQUIRE(logits && tokens && R > 0, DIMX_ERR_ARG, "sample: bad arguments");
-    hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, logits, ld_logits, R, top_k,
+    const int wpb = R <= 1024 ? 1 : 4;  // one row per block for decode-sized batches: all CUs busy
+    hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, wpb)), dim3(64 * wpb), 0, s, logits, ld_logits, R, top_k,
                        temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, nslab < 1 ? 1 : nslab,
                        slab_stride, logits_out, logits_out_ld, row0, rows_total, emb_table, emb_C, x_next, step_rw, done_ctr,
                        pos_table, pos_scale, pos_rows);

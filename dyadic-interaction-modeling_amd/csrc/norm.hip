@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restr
                                                                   long slab_stride, OutT* __restrict__ y,
                                                                   const float* __restrict__ gamma, int M) {
     constexpr int NV = C / 128;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     float2* xr = (float2*)(x + (size_t)row * C);
@@ -118,7 +118,9 @@ int launch_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int 
                                const float* gamma, int M, int C, hipStream_t s) {
     DIMX_REQUIRE(x && y && gamma && M > 0 && (nslab == 0 || slabs), DIMX_ERR_ARG, "add_slabs_layernorm: null operand");
     DIMX_REQUIRE(C == 1152 || C == 384 || C == 512 || C == 768, DIMX_ERR_ARG, "add_slabs_layernorm: C=%d", C);
-    dim3 grid(ceil_div(M, 4)), block(256);
+    // decode batches are a few hundred rows: one row (one wave) per block spreads them over all CUs instead of M/4
+    const int wpb = M <= 1024 ? 1 : 4;
+    dim3 grid(ceil_div(M, wpb)), block(64 * wpb);
 #define ASL(OT, CC) hipLaunchKernelGGL((add_slabs_layernorm_kernel<OT, CC>), grid, block, 0, s, x, slabs, nslab, slab_stride, (OT*)y, gamma, M)
 #define ASL_C(OT)                      \
     do {                               \
