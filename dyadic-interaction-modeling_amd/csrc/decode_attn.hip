@@ -13,6 +13,14 @@
 namespace dimx {
 namespace {
 
+// K/V rows are read exactly once per launch and the per-layer cache (236 MB at C3) exceeds every cache level:
+// stream them with the non-temporal policy so they do not evict the weights / slabs the neighbouring kernels re-use
+typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+template <typename P> __device__ __forceinline__ uint4 ld_stream(const P* p) {
+    const u32x4_nt v = __builtin_nontemporal_load((const u32x4_nt*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 constexpr int kMaxKeys = 2048;  // x-transformers max_seq_len of the decoder (code/seq2seq_pretrain.py:381)
 constexpr float kNegD = -3.0e38f;
 
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * KPI + sub;
-            r[u] = *(const uint4*)(base + (size_t)(j < n ? j : (n > 0 ? n - 1 : 0)) * 64);
+            r[u] = ld_stream(base + (size_t)(j < n ? j : (n > 0 ? n - 1 : 0)) * 64);
         }
     };
     const int jfirst = part * KB, jstep = NSPLIT * KB;  // this wave's key batches: jfirst, jfirst + jstep, ...
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void decode_attn_multi_kernel(const DecodeAttn
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u * KPI + sub;
-            r[u] = *(const uint4*)(base + (size_t)(j < n ? j : n - 1) * 64);
+            r[u] = ld_stream(base + (size_t)(j < n ? j : n - 1) * 64);
         }
     };
     uint4 cur[U], nxt[U];
