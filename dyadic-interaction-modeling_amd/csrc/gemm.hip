@@ -390,7 +390,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     const int split = bid / ntiles, tile = bid - split * ntiles;
-    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    // few row tiles (decode: M = batch): n-major order, so that the blocks sharing a W column tile are neighbours
+    // and land on the same XCD -- its L2 then fetches every weight byte once instead of once per row tile (the A
+    // panel is tiny and stays resident everywhere).  Many row tiles (prefill): m-major, A panels are the big operand.
+    int tile_m, tile_n;
+    if (tiles_m <= 8) {
+        tile_n = tile / tiles_m;
+        tile_m = tile - tile_n * tiles_m;
+    } else {
+        tile_m = tile / tiles_n;
+        tile_n = tile - tile_m * tiles_n;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const T* __restrict__ A = (const T*)a.A;
     const T* __restrict__ W = (const T*)a.W;
