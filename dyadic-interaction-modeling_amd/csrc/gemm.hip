@@ -604,8 +604,10 @@ int gemm_plan_splits(const GemmArgs& a) {
     if (tiles >= 256) return 1;
     const int nk = a.ldw / bk;
     // measured (tools/bench_gemm.py under rocprofv3): ~288 blocks (one per CU + a few) is the sweet spot
-    int sp = (288 + tiles / 2) / tiles;
-    const int max_sp = nk / 4 > 0 ? nk / 4 : 1;
+    static const int target = getenv("DIMX_SPLIT_TARGET") ? atoi(getenv("DIMX_SPLIT_TARGET")) : 288;
+    static const int min_nk = getenv("DIMX_SPLIT_MINNK") ? atoi(getenv("DIMX_SPLIT_MINNK")) : 6;  // k-tiles per split at least (swept 3..9)
+    int sp = (target + tiles / 2) / tiles;
+    const int max_sp = nk / min_nk > 0 ? nk / min_nk : 1;
     sp = sp > max_sp ? max_sp : sp;
     sp = sp > 8 ? 8 : sp;
     return sp < 1 ? 1 : sp;
