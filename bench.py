@@ -162,7 +162,7 @@ def main():
                    "code indices)" % world},
         "achieved_tflops_necessary_work": clips_s * GFLOP_PER_CLIP_T300 * (T / 300.0) / 1e3,
     }
-    if world == 1 and not args.no_roofline:   # single-GPU runs only (the other ranks have left by now)
+    if not args.no_roofline:   # per-GPU kernel measurement on rank 0's device (for N > 1 the other ranks have left by now)
         from dimx import roofline
         out["roofline"] = roofline.dominant_kernel(eng, B, T, args.mode)
         out["cross_attn_mfma"] = roofline.cross_kv_gemm(B, T, args.mode, device)
