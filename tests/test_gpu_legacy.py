@@ -172,3 +172,49 @@ def test_evaluate_epoch_protocol(legacy_sd):
         cnt += int(sel.sum())
     ppl = x_engine.evaluate_epoch(model, batches, torch.device("cuda:0"), generate_kw={"greedy": True}, verbose=False)
     assert abs(ppl - np.exp(nll / cnt)) < 1e-3 * np.exp(nll / cnt)
+
+
+def test_fullsize_properties_B64_T300(legacy_sd):
+    """size-independent properties at the C3 sequence length: batch / shard invariance of the generated tokens,
+    determinism of the seeded sampler, KV-cached generation == teacher-forced logits (f32 parity mode)."""
+    from dimx import engine, lib, prng
+    e = engine.Engine("cuda:0", lib.MODE_PARITY_F32, "legacy")
+    e.load_state_dict(legacy_sd)
+    B, T = 16, 300
+    lens = [300] * 10 + [287, 211, 150, 97, 33, 8]
+    v_s, v_l, mask = _case(B, T, lens, seed=31)
+    v_s, v_l = v_s.cuda(), v_l.cuda()
+    m8 = mask.to(torch.uint8).cuda()
+    lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
+    z_l = e.vq_encode(1, v_l, lens_t, pe_mode=0, pad_value=-100)
+    noise = torch.from_numpy(prng.exponential(6, "legacy.full.noise", (T, B, 512))).cuda()
+
+    def gen(sl, nz):
+        e.encode_ctx(v_s[sl].contiguous(), None, m8[sl].contiguous(), True)
+        return e.generate(z_l[sl, 0].contiguous(), m8[sl].contiguous(), T, 1.0, 52, nz, return_logits=True)
+    tok, lg = gen(slice(0, B), noise)
+    t0, _ = gen(slice(0, 8), noise[:, :8].contiguous())
+    t1, _ = gen(slice(8, 16), noise[:, 8:].contiguous())
+    assert torch.equal(tok[:8], t0) and torch.equal(tok[8:], t1)          # shard invariance
+    tok2, _ = gen(slice(0, B), noise)
+    assert torch.equal(tok, tok2)                                           # determinism
+    assert int(tok.min()) >= 0 and int(tok.max()) < 512
+    seq = torch.cat([z_l[:, :1], tok[:, :T - 1]], 1).contiguous()
+    e.encode_ctx(v_s, None, m8, False)
+    tf_logits, _, _ = e.decode_tf(seq, m8, None)
+    assert (tf_logits - lg[:, :T - 1]).abs().max() < 3e-3                   # cache consistency over 299 steps
+
+
+def test_maximum_context_T1024(legacy_sd):
+    """max_seq_len = 1024 of the legacy generator (decoder positional table bound): bf16, finite, in range."""
+    from dimx import engine, lib
+    e = engine.Engine("cuda:0", lib.MODE_PERF_BF16, "legacy")
+    e.load_state_dict(legacy_sd)
+    v_s, v_l, mask = _case(2, 1024, [1024, 700], seed=9)
+    m8 = mask.to(torch.uint8).cuda()
+    z_l = e.vq_encode(1, v_l.cuda(), mask.sum(1).to(torch.int32).cuda(), pe_mode=0, pad_value=-100)
+    e.encode_ctx(v_s.cuda(), None, m8, True)
+    tok = e.generate(z_l[:, 0].contiguous(), m8, 1024, 1.0, 52, None, seed=5)
+    assert tuple(tok.shape) == (2, 1024) and int(tok.min()) >= 0 and int(tok.max()) < 512
+    with pytest.raises(lib.DimxError):
+        e.workspace(1, 1025)
