@@ -158,6 +158,8 @@ struct GemmArgs {
     int out_slabs;     // split-K partial sums go to f32 slabs C + split*slab_stride (plain stores, fixed order
                        // reduction by the consumer kernel); requires act none, no residual/rowadd, plain output
     long slab_stride;  // elements between slabs
+    int stage_out;     // set by the launcher: large-M outputs leave through LDS as 8/16-byte row-contiguous pieces
+    int vt_pack4;      // set by the launcher: transposed (time-contiguous) segments take 4 packed rows per store
 };
 
 void gemm_args_init(GemmArgs& a);

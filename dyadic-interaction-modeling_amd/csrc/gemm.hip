@@ -189,6 +189,225 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16_t (&acc
     }
 }
 
+// (staged epilogue only) a.seg[s] with a run-time s, field by field so that nothing forces the by-value kernel
+// argument into scratch
+__device__ __forceinline__ OutSeg pick_seg_stg(const GemmArgs& a, int s) {
+    OutSeg g;
+#define DIMX_PICK(f) g.f = s == 0 ? a.seg[0].f : (s == 1 ? a.seg[1].f : a.seg[2].f)
+    DIMX_PICK(ptr);
+    DIMX_PICK(sb);
+    DIMX_PICK(sh);
+    DIMX_PICK(st);
+    DIMX_PICK(sd);
+    DIMX_PICK(D);
+#undef DIMX_PICK
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Staged epilogue (STG instantiations only: large-M prefill GEMMs; the decode kernels do not contain this code).
+// Each wave dumps a 32-row slice of its accumulators raw (f32) into a private LDS region (the main loop's ring,
+// free after a block barrier) and writes it out as 8/16-byte pieces contiguous along the output row; bias /
+// activation / positional row / residual run on the row-contiguous data with epilogue_tile's arithmetic.
+// ------------------------------------------------------------------------------------------------
+// One 32-row slice: raw f32 accumulators of the wave sit in its private LDS region as [32][NI*32]; this writes
+// them out.  Row-major segments: a lane owns 4 consecutive columns of a row (bias / activation / positional row /
+// residual are applied here on row-contiguous data, then one 8-byte (bf16) or 16-byte (f32) store; 16 or 32 lanes
+// cover a full row of the wave tile).  Transposed segments (V^T: contiguous along time): a lane owns 4
+// consecutive rows of one column and stores them packed when the launcher proved that legal (vt_pack4).
+template <typename OutT, int NI, int ACT, bool FAST>
+__device__ __forceinline__ void stage_copy_out(const GemmArgs& a, const unsigned char* stage, int mb, int n0w, int lane) {
+    constexpr int ES = sizeof(OutT);
+    constexpr int ROWF = NI * 32;      // floats per staged row
+    constexpr int PPR = NI * 8;        // 4-column pieces per row
+    constexpr int RPI = 64 / PPR;      // rows per wave-wide step
+    constexpr int NIT = 32 / RPI;
+    const int rowT = a.rowT;
+    int b0, t0;
+    if (rowT == 1) {
+        b0 = mb;
+        t0 = 0;
+    } else {
+        b0 = mb / rowT;
+        t0 = mb - b0 * rowT;
+    }
+    // ---- row-major segments
+    {
+        const int cc = lane % PPR, crow = lane / PPR;
+        const int n = n0w + cc * 4;
+        const int nc = n < a.N ? n : 0;
+        int s = 0, nn = nc;
+        if (a.nseg > 1) {
+            s = nc / a.seg_width;
+            nn = nc - s * a.seg_width;
+        }
+        const OutSeg sg = pick_seg_stg(a, s);
+        if (n < a.N && sg.sd == 1) {
+            const int hh = nn / sg.D, dd = nn - hh * sg.D;
+            OutT* const cbase = (OutT*)sg.ptr + (long)hh * sg.sh + dd;
+            const float4 bias4 = a.bias ? *(const float4*)(a.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            int b = b0, t = rowT == 1 ? 0 : t0 + crow;
+            if (rowT != 1 && t >= rowT) {
+                t -= rowT;
+                ++b;
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = it * RPI + crow;
+                const int m = mb + row;
+                if (m < a.M) {
+                    float4 v = *(const float4*)(stage + (row * ROWF + cc * 4) * 4);
+                    v.x = act_fn<ACT, FAST>(v.x + bias4.x);
+                    v.y = act_fn<ACT, FAST>(v.y + bias4.y);
+                    v.z = act_fn<ACT, FAST>(v.z + bias4.z);
+                    v.w = act_fn<ACT, FAST>(v.w + bias4.w);
+                    const int bb = rowT == 1 ? m : b;
+                    if (a.rowadd_mode) {
+                        const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? bb / a.rowadd_div + a.rowadd_off : a.rowadd_off);
+                        const float4 q = *(const float4*)(a.rowadd + (size_t)ri * a.ld_rowadd + nc);
+                        v.x += q.x * a.rowadd_scale;
+                        v.y += q.y * a.rowadd_scale;
+                        v.z += q.z * a.rowadd_scale;
+                        v.w += q.w * a.rowadd_scale;
+                    }
+                    if (a.residual) {
+                        const float4 q = *(const float4*)(a.residual + (size_t)m * a.ldr + nc);
+                        v.x += q.x;
+                        v.y += q.y;
+                        v.z += q.z;
+                        v.w += q.w;
+                    }
+                    OutT* p = cbase + (long)bb * sg.sb + (long)t * sg.st;
+                    if (ES == 2) {
+                        *(uint2*)p = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                    } else {
+                        *(float4*)p = v;
+                    }
+                }
+                if (rowT != 1) {
+                    t += RPI;
+                    if (t >= rowT) {
+                        t -= rowT;
+                        ++b;
+                    }
+                }
+            }
+        }
+    }
+    // ---- transposed segments (whole 32-column blocks belong to one segment: seg_width % 32 == 0)
+    if (a.nseg > 1) {
+        const int col = lane & 31, qh = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nb = n0w + j * 32;
+            if (nb >= a.N) continue;
+            const int s = nb / a.seg_width;
+            const OutSeg sg = pick_seg_stg(a, s);
+            if (sg.sd == 1) continue;  // wave-uniform
+            const int n = nb + col;
+            const int nc = n < a.N ? n : a.N - 1;
+            const int nn = nc - s * a.seg_width;
+            const int hh = nn / sg.D, dd = nn - hh * sg.D;
+            OutT* const obase = (OutT*)sg.ptr + (long)hh * sg.sh + (long)dd * sg.sd;
+            const float bias_v = a.bias ? a.bias[nc] : 0.f;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r0 = (it * 2 + qh) * 4;  // first of 4 consecutive rows
+                const int m0r = mb + r0;
+                int b = b0, t = t0 + r0;
+                if (rowT == 1) {
+                    b = m0r;
+                    t = 0;
+                } else if (t >= rowT) {
+                    t -= rowT;
+                    ++b;
+                }
+                float v4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = act_fn<ACT, FAST>(*(const float*)(stage + ((r0 + q) * ROWF + j * 32 + col) * 4) + bias_v);
+                    const int m = m0r + q;
+                    const int mc = m < a.M ? m : a.M - 1;
+                    if (a.rowadd_mode) {
+                        int bq = b, tq = t + q;
+                        if (rowT != 1 && tq >= rowT) {
+                            tq -= rowT;
+                            ++bq;
+                        }
+                        const int ri = a.rowadd_mode == 1 ? tq : (a.rowadd_mode == 2 ? (rowT == 1 ? mc : bq) / a.rowadd_div + a.rowadd_off : a.rowadd_off);
+                        v += a.rowadd[(size_t)ri * a.ld_rowadd + nc] * a.rowadd_scale;
+                    }
+                    if (a.residual) v += a.residual[(size_t)mc * a.ldr + nc];
+                    v4[q] = v;
+                }
+                if (n >= a.N || m0r >= a.M) continue;
+                if (a.vt_pack4) {  // 4 consecutive time steps of one clip (rowT % 4 == 0, M % 4 == 0, st == 1)
+                    OutT* p = obase + (long)b * sg.sb + (long)t * sg.st;
+                    if (ES == 2) {
+                        *(uint2*)p = make_uint2(pack_bf16x2(v4[0], v4[1]), pack_bf16x2(v4[2], v4[3]));
+                    } else {
+                        *(float4*)p = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (m0r + q >= a.M) continue;
+                        int bq = b, tq = t + q;
+                        if (rowT == 1) {
+                            bq = m0r + q;
+                            tq = 0;
+                        } else if (tq >= rowT) {
+                            tq -= rowT;
+                            ++bq;
+                        }
+                        store_from_f32<OutT>(obase + (long)bq * sg.sb + (long)tq * sg.st, v4[q]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// slices I .. MI-1 of the wave tile: raw dump (compile-time accumulator indices, immediate LDS offsets), copy-out
+template <typename OutT, int I, int MI, int NI, int ACT, bool FAST>
+__device__ __forceinline__ void stage_slices(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w,
+                                             int half, int l31, unsigned char* stage) {
+    if constexpr (I < MI) {
+        const int mb = m0w + I * 32;
+        if (mb < a.M) {
+            float* base = (float*)stage + (4 * half) * (NI * 32) + l31;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * (NI * 32) + j * 32] = acc[I][j][r];
+            // the slice is re-read with a different lane<->element mapping (and vector type): keep the compiler from
+            // moving those loads above the stores; the LDS itself executes one wave's operations in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage_copy_out<OutT, NI, ACT, FAST>(a, stage, mb, n0w, half * 32 + l31);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next slice overwrites
+        }
+        stage_slices<OutT, I + 1, MI, NI, ACT, FAST>(a, acc, m0w, n0w, half, l31, stage);
+    }
+}
+
+template <typename OutT, int MI, int NI, int ACT, bool FAST>
+__device__ __forceinline__ void epilogue_staged(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w,
+                                                int half, int l31, unsigned char* stage) {
+    stage_slices<OutT, 0, MI, NI, ACT, FAST>(a, acc, m0w, n0w, half, l31, stage);
+}
+
+template <typename T, typename OutT, int MI, int NI>
+__device__ __forceinline__ void epilogue_stg(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w, int half,
+                                             int l31, unsigned char* stage) {
+    constexpr bool FAST = sizeof(T) == 2;
+    switch (a.act) {
+        case ACT_LEAKY: epilogue_staged<OutT, MI, NI, ACT_LEAKY, FAST>(a, acc, m0w, n0w, half, l31, stage); break;
+        case ACT_GELU_TANH: epilogue_staged<OutT, MI, NI, ACT_GELU_TANH, FAST>(a, acc, m0w, n0w, half, l31, stage); break;
+        case ACT_GELU_ERF: epilogue_staged<OutT, MI, NI, ACT_GELU_ERF, FAST>(a, acc, m0w, n0w, half, l31, stage); break;
+        default: epilogue_staged<OutT, MI, NI, ACT_NONE, FAST>(a, acc, m0w, n0w, half, l31, stage); break;
+    }
+}
+
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs a) {
     constexpr int NT = WM * WN * 64;
@@ -366,7 +585,7 @@ template <int MI, int NI> struct FragMma<float, MI, NI> {
 };
 
 // ABL (ablation, tuning only): 0 normal, 1 = no MFMA/ds_read in the loop (DMA only), 2 = no DMA in the loop
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0, bool STG = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a) {
     constexpr int NW = WM * WN;
     constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
@@ -519,13 +738,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     }
 
     // ---- epilogue (split-K: this split's partial sums go to its own f32 slab)
-    epilogue<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, split);
+    if constexpr (STG) {
+        constexpr int SLICE = 32 * NI * 32 * 4;  // raw f32 slice per wave
+        static_assert(SLICE * NW <= STAGES * TILE_BYTES, "staging slices must fit in the ring");
+        __syncthreads();  // every wave is done reading the ring (all DMA landed before the last k-tile)
+        epilogue_stg<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, smem + wave * SLICE);
+    } else {
+        epilogue<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, split);
+    }
 }
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
 static int launch_glds(const GemmArgs& a, hipStream_t s) {
     const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
     dim3 grid(tiles * a.splitk), block(WM * WN * 64);
+    if constexpr (BM * BN >= 128 * 128 && ABL == 0) {
+        if (a.stage_out) {
+            hipLaunchKernelGGL((gemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES, ABL, true>), grid, block, 0, s, a);
+            DIMX_HIP(hipGetLastError());
+            return DIMX_OK;
+        }
+    }
     hipLaunchKernelGGL((gemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES, ABL>), grid, block, 0, s, a);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
@@ -587,6 +820,32 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;
+    }
+    // large-M outputs leave through LDS as 16-byte row pieces (epilogue_staged) when the output map allows it
+    a.stage_out = 0;
+    a.vt_pack4 = 0;
+    static const bool no_stage = getenv("DIMX_NO_STAGE") != nullptr;
+    if (!no_stage && !a.out_slabs && a.M >= 2048 && (a.rowT == 1 || a.rowT >= 32)) {
+        const int epo = 16 / (int)sizeof(OutT);
+        (void)epo;
+        bool ok = a.N % 4 == 0 && (a.nseg == 1 || a.seg_width % 32 == 0), any_row = false, pack = true;
+        ok = ok && (!a.bias || ((uintptr_t)a.bias % 16) == 0);
+        ok = ok && (!a.residual || (a.ldr % 4 == 0 && ((uintptr_t)a.residual % 16) == 0));
+        ok = ok && (!a.rowadd_mode || (a.ld_rowadd % 4 == 0 && ((uintptr_t)a.rowadd % 16) == 0));
+        for (int i = 0; i < a.nseg; ++i) {
+            const OutSeg& g = a.seg[i];
+            if (g.sd == 1) {
+                any_row = true;
+                ok = ok && ((uintptr_t)g.ptr % 16) == 0 && g.sb % 4 == 0 && g.st % 4 == 0 && g.sh % 4 == 0 && g.D % 4 == 0;
+            } else {
+                pack = pack && g.st == 1 && a.rowT % 4 == 0 && a.M % 4 == 0 && g.sb % 4 == 0 && g.sd % 4 == 0 &&
+                       g.sh % 4 == 0 && ((uintptr_t)g.ptr % (4 * sizeof(OutT))) == 0;
+            }
+        }
+        if (ok && any_row) {
+            a.stage_out = 1;
+            a.vt_pack4 = pack ? 1 : 0;
+        }
     }
     return launch_by_cfg<T, OutT>(a, cfg, s);
 }
