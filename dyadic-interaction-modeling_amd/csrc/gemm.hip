@@ -752,7 +752,9 @@ template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES,
 static int launch_glds(const GemmArgs& a, hipStream_t s) {
     const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
     dim3 grid(tiles * a.splitk), block(WM * WN * 64);
-    if constexpr (BM * BN >= 128 * 128 && ABL == 0) {
+    // one 32-row slice per wave (MI == 1) is where staging pays (128x128 on 8 waves: -12..-39 %); with two slices per
+    // wave (the 4-wave 128x128 and the 256-wide tiles) it measured 30-40 % slower than direct stores
+    if constexpr (BM * BN >= 128 * 128 && ABL == 0 && BM / (WM * 32) == 1) {
         if (a.stage_out) {
             hipLaunchKernelGGL((gemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES, ABL, true>), grid, block, 0, s, a);
             DIMX_HIP(hipGetLastError());
