@@ -41,6 +41,13 @@ template <> struct MmaT<float> {
 
 constexpr float kNeg = -3.0e38f;
 
+// bf16 perf mode: the bare v_exp_f32 (arguments are <= 0, results that underflow flush to 0, which is what a
+// softmax wants); f32 parity mode keeps exp2f
+template <typename T> __device__ __forceinline__ float fast_exp2(float x) {
+    if (sizeof(T) == 2) return __builtin_amdgcn_exp2f(x);
+    return exp2f(x);
+}
+
 // DK = head-dim extent the kernel reduces over (64 for D in {48,64}; 96 for the 8 x 96 heads of the legacy
 // speaker VQ-VAE, hidden 768).  K rows are padded to DKP = 64 / 128 elements so the XOR swizzle stays a power
 // of two; the V^T tile has DK rows (NB = DK/32 output blocks) of 64 keys.
@@ -170,28 +177,46 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
                 MmaT<T>::run(st[kt], kf, qf[ks]);
             }
         }
-        // ---- mask, online softmax (lane-local: this lane's query, 32 of the tile's 64 keys)
+        // ---- mask, online softmax (lane-local: this lane's query, 32 of the tile's 64 keys).  This part, not the
+        // MFMAs, bounds the kernel (VALU: ~3 k cycles per tile and wave against 512 MFMA cycles), so interior
+        // tiles -- every key valid and, if causal, wholly below the diagonal of this wave's queries -- skip the
+        // masking, and the masked path tests compile-time bit positions of a pre-shifted 32-bit validity word.
+        const int qlo = qblk0 + wave * 32;  // smallest query index of this wave
+        const bool interior = kbits == ~0ull && (!a.causal || j0 + 63 <= qlo);
         float mx = kNeg;
+        if (interior) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-                bool ok = (kbits >> kl) & 1ull;
-                if (a.causal) ok = ok && (j0 + kl) <= qi;
-                const float s = ok ? st[kt][r] * scale2 : kNeg;
-                st[kt][r] = s;
-                mx = fmaxf(mx, s);
+                for (int r = 0; r < 16; ++r) {
+                    const float sv = st[kt][r] * scale2;
+                    st[kt][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+        } else {
+            const int dq = a.causal ? j0 + 4 * half - qi : -(1 << 30);  // key (32kt + c) is visible iff 32kt + c + dq <= 0
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const uint32_t w = (uint32_t)(kbits >> (32 * kt)) >> (4 * half);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = (r & 3) + 8 * (r >> 2);
+                    const bool ok = (w & (1u << c)) != 0u && (32 * kt + c + dq <= 0);
+                    const float sv = ok ? st[kt][r] * scale2 : kNeg;
+                    st[kt][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
             }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = fast_exp2<T>(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(st[kt][r] - m_new);
+                const float p = fast_exp2<T>(st[kt][r] - m_new);
                 st[kt][r] = p;
                 psum += p;
             }
