@@ -46,11 +46,11 @@ def decode_attention(B, T, mode, device, iters=40):
     sec = _time_launches(lambda i: E.op_decode_attn(q, kc[i % layers], vc[i % layers], T, 0.125, km), 8, iters)
     alg_bytes = B * H * T * 64 * 2 * es + 2 * B * H * 64 * es
     gbs = alg_bytes / sec / 1e9
-    # HBM bytes per launch from the committed PMC pass (profiles/r01b_pmc_*): FETCH_SIZE (KB) is doubled for
+    # HBM bytes per launch from the committed PMC pass (profiles/r01c_pmc_*): FETCH_SIZE (KB) is doubled for
     # 16-B/lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM section) + WRITE_SIZE (KB)
     traffic = None
     if (B, T, mode) == (256, 300, "bf16"):
-        traffic = (2 * 115793.0 + 384.0) * 1024   # profiles/r01b_pmc_{FETCH,WRITE}_SIZE_roofline_kernels.txt
+        traffic = (2 * 115793.0 + 384.0) * 1024   # profiles/r01c_pmc_{FETCH,WRITE}_SIZE_roofline_kernels.txt
     return {"kernel": "decode_attn_kernel<%s, false, true, 1> (cross-attention form, %d keys)" % ("dimx::bf16" if mode == "bf16" else "float", T), "bound": "hbm",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sec * 1e6}
