@@ -784,6 +784,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
         case 1: return launch_glds<T, OutT, 128, 128, 2, 2, 2>(a, s);
+        case 3: return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
         case 4: return launch_glds<T, OutT, 64, 64, 2, 2, 3>(a, s);
         case 14: return launch_glds<T, OutT, 128, 128, 4, 2, 2>(a, s);  // 8 waves
         case 18: return launch_glds<T, OutT, 256, 128, 4, 2, 2>(a, s);  // 8 waves, 96 KB ring
@@ -818,7 +819,8 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
         return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
     }
     int cfg = a.cfg;
-    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : 4;  // measured on MI355X (tools/bench_gemm.py): 128x128 8-wave for large M, 64x64x3 for decode
+    static const int cfg_small = getenv("DIMX_GEMM_CFG_SMALL") ? atoi(getenv("DIMX_GEMM_CFG_SMALL")) : 3;
+    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : cfg_small;  // measured on MI355X: 128x128 8-wave for large M; 64x64 with a 4-deep ring for decode (3: -0.4 %, 5: -1 %)
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;
