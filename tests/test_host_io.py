@@ -87,3 +87,15 @@ def test_postprocess_matches_reference(golden_dir, tmp_path):
     pose = np.load(tmp_path / "p" / "clip7" / "10" / "pose.npy")
     exp = np.load(tmp_path / "g" / "clip7" / "10" / "exp.npy")
     assert pose.shape == (6,) and exp.shape == (50,) and np.allclose(pose, y[10, :6], atol=1e-6)
+
+
+def test_example_driver_compiles():
+    """examples/test_s2s_pretrain.py (the reference driver on the drop-ins) is valid Python and names only
+    modules that exist in the package."""
+    import importlib
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    py_compile.compile(os.path.join(root, "examples", "test_s2s_pretrain.py"), doraise=True)
+    for mod in ("dimx.dataset.data_loader", "dimx.mymetrics", "dimx.seq2seq_pretrain", "dimx.x_engine_pt",
+                "dimx.x_engine", "dimx.seq2seq", "dimx.postprocess2emoca"):
+        importlib.import_module(mod)
