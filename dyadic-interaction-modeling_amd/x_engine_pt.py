@@ -119,3 +119,9 @@ def generate_sharded(model, v_speaker, v_listener, v_audio, mask, **forward_kw):
     tokens = ddist.all_gather_rows(tokens.to(torch.int32))
     pred = ddist.all_gather_rows(pred)
     return tokens, pred
+
+
+def train_epoch(*args, **kwargs):
+    """Import-compatibility placeholder for reference code/x_engine_pt.py:9-60 (``test_s2s_pretrain.py:6`` imports it
+    next to the evaluation functions).  Backward / optimiser steps are SURVEY 8(f3) and not built: calling it fails."""
+    raise NotImplementedError("dimx is forward/inference only: train_epoch (backward + AdamW) is not built")
