@@ -47,6 +47,33 @@ def _compile(src):
     return obj, True
 
 
+def have_hipcc():
+    import shutil
+    c = _hipcc()
+    return (os.path.isabs(c) and os.path.exists(c)) or shutil.which(c) is not None
+
+
+STAMP = LIB + ".srchash"   # sha256 of the sources / headers / flags the shipped library was built from
+
+
+def _src_hash():
+    import hashlib
+    hsh = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            hsh.update(f.encode() + b"\0" + fh.read())
+    return hsh.hexdigest()
+
+
+def stale():
+    """True when libdimx_hip.so is missing or was built from other sources than the ones in the tree (content hash,
+    not mtime: the copy that travels to a GPU box does not keep timestamps)."""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return True
+    with open(STAMP) as fh:
+        return fh.read().strip() != _src_hash()
+
+
 def build(force=False):
     os.makedirs(OBJ, exist_ok=True)
     if force:
@@ -60,6 +87,8 @@ def build(force=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(STAMP, "w") as fh:
+        fh.write(_src_hash() + "\n")
     return LIB
 
 

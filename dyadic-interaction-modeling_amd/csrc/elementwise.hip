@@ -138,9 +138,18 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      float* __restrict__ x_next, int32_t* __restrict__ step_rw,
                                                      unsigned* __restrict__ done_ctr,
                                                      const float* __restrict__ pos_table, float pos_scale,
-                                                     int pos_rows) {
+                                                     int pos_rows, const int32_t* __restrict__ dev_params) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint64_t step = step_dev ? (uint64_t)*step_dev : step_host;
+    if (dev_params) {  // generate(): temperature / seed live in device memory so that the captured step graph
+                       // does not depend on them (a new seed per batch must not force a re-capture)
+        temperature = __builtin_bit_cast(float, dev_params[0]);
+        seed = *(const uint64_t*)(dev_params + 2);
+    }
+    // counter of the on-device generator: (step, GLOBAL sequence row, code) -- a rank that generates rows
+    // [off, off + R) of a sharded batch of `tot` sequences draws what the single-process batch would draw
+    const int rng_off = dev_params ? dev_params[4] : 0;
+    const int rng_tot = dev_params && dev_params[5] > 0 ? dev_params[5] : rows_total;
     if (row < R) {
     const float* lr = logits + (size_t)row * ld;
     float v[8];
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             if (noise) {
                 q = noise[((size_t)step * rows_total + row0 + row) * 512 + i];
             } else {
-                const uint64_t r = splitmix(seed, ((uint64_t)step * rows_total + row0 + row) * 512 + i);
+                const uint64_t r = splitmix(seed, ((uint64_t)step * rng_tot + rng_off + row0 + row) * 512 + i);
                 const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
                 q = fmaxf(-log1pf(-u), 9.313225746154785e-10f);
             }
@@ -330,6 +339,21 @@ __global__ void legacy_scramble_kernel(const float* __restrict__ E, const int32_
 
 __global__ void step_inc_kernel(int32_t* step) { *step += 1; }
 
+// per clip group: [0] step counter = 0, [8] done counter = 0, [2] temperature bits, [4..5] seed, [6] global row
+// offset and [7] global row count of the sampler's counter-based generator (generate())
+__global__ void gen_params_kernel(int32_t* base, int groups, float temperature, uint64_t seed, int row_off,
+                                  int rows_total) {
+    const int g = threadIdx.x;
+    if (g >= groups) return;
+    int32_t* p = base + 16 * g;
+    p[0] = 0;
+    p[8] = 0;
+    p[2] = __builtin_bit_cast(int32_t, temperature);
+    *(uint64_t*)(p + 4) = seed;
+    p[6] = row_off;
+    p[7] = rows_total;
+}
+
 // dst[b, step, :] = src[b, :]  (optional per-step logits dump of generate)
 __global__ void copy_rows_step_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int V, int n,
                                       const int32_t* __restrict__ step_dev) {
@@ -420,13 +444,20 @@ int launch_sample(const float* logits, int ld_logits, int R, int top_k, float te
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
                   int tok_col_from_step, int nslab, long slab_stride, float* logits_out, int logits_out_ld, int row0,
                   int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
-                  hipStream_t s, const float* pos_table, float pos_scale, int pos_rows) {
+                  hipStream_t s, const float* pos_table, float pos_scale, int pos_rows, const int32_t* dev_params) {
     DIMX_REQUIRE(logits && tokens && R > 0, DIMX_ERR_ARG, "sample: bad arguments");
     const int wpb = R <= 1024 ? 1 : 4;  // one row per block for decode-sized batches: all CUs busy
     hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, wpb)), dim3(64 * wpb), 0, s, logits, ld_logits, R, top_k,
                        temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, nslab < 1 ? 1 : nslab,
                        slab_stride, logits_out, logits_out_ld, row0, rows_total, emb_table, emb_C, x_next, step_rw, done_ctr,
-                       pos_table, pos_scale, pos_rows);
+                       pos_table, pos_scale, pos_rows, dev_params);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int launch_gen_params(int32_t* base, int groups, float temperature, uint64_t seed, int row_off, int rows_total,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(gen_params_kernel, dim3(1), dim3(64), 0, s, base, groups, temperature, seed, row_off, rows_total);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

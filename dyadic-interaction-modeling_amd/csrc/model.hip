@@ -716,6 +716,15 @@ int dimx_destroy(dimx_handle h) {
 
 int dimx_numeric_mode(dimx_handle h) { return h ? h->mode : DIMX_ERR_ARG; }
 
+int dimx_set_shard(dimx_handle h, int row_offset, int rows_total) {
+    DIMX_REQUIRE(h, DIMX_ERR_ARG, "set_shard: null handle");
+    DIMX_REQUIRE(row_offset >= 0 && (rows_total == 0 || rows_total > row_offset), DIMX_ERR_ARG,
+                 "set_shard: row_offset %d, rows_total %d", row_offset, rows_total);
+    h->shard_row_off = row_offset;
+    h->shard_rows_total = rows_total;
+    return DIMX_OK;
+}
+
 int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n) {
     DIMX_REQUIRE(h && descs && n >= 0, DIMX_ERR_ARG, "dimx_load_weights: null argument");
     static thread_local std::map<std::string, std::vector<int64_t>> spec;
@@ -1029,11 +1038,12 @@ int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens
     return DIMX_OK;
 }
 
-int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset, int rows_per_clip,
-                   float* out, void* ws, size_t ws_bytes, void* stream) {
+// shared body of dimx_vq_decode (codebook rows gathered from idx) and dimx_vq_decode_latent (z given)
+static int vq_decode_impl(dimx_handle h, int which, const int32_t* idx, const float* z, int B, int L,
+                          int batch_row_offset, int rows_per_clip, float* out, void* ws, size_t ws_bytes, void* stream) {
     DIMX_REQUIRE(which == 0 || which == 1, DIMX_ERR_ARG, "vq_decode: which must be 0 or 1");
     DIMX_TRY(check_common(h, B, L, ws, ws_bytes, which == 0 ? COMP_VQ0 : COMP_VQ1));
-    DIMX_REQUIRE(idx && out, DIMX_ERR_ARG, "vq_decode: null argument");
+    DIMX_REQUIRE((idx || z) && out, DIMX_ERR_ARG, "vq_decode: null argument");
     DIMX_REQUIRE(B + batch_row_offset <= 5000 && batch_row_offset >= 0, DIMX_ERR_ARG,
                  "vq_decode: positional row %d out of range", B + batch_row_offset);
     hipStream_t st = (hipStream_t)stream;
@@ -1045,7 +1055,10 @@ int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, i
     plan_vq(h, vg, ar, B, L, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_decode: workspace overflow");
     const int M = B * L, Hd = vg.hidden, zd = vg.zdim;
-    DIMX_TRY(launch_gather_rows(h->at, v.E, zd, vg.n_embed, idx, s.xa, zd, M, zd, st));
+    if (idx)
+        DIMX_TRY(launch_gather_rows(h->at, v.E, zd, vg.n_embed, idx, s.xa, zd, M, zd, st));
+    else
+        DIMX_TRY(launch_cast_pad(h->at, z, zd, nullptr, s.xa, zd, M, zd, st));
     GemmArgs g;
     gemm_lin(h, s.xa, zd, v.pre, M, g);
     g.out_dtype = h->at;
@@ -1060,6 +1073,38 @@ int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, i
     g.out_dtype = DIMX_F32;
     gemm_set_plain_out(g, out, vg.in_dim);
     DIMX_TRY(launch_gemm(g, st));
+    return DIMX_OK;
+}
+
+int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset, int rows_per_clip,
+                   float* out, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(idx, DIMX_ERR_ARG, "vq_decode: null argument");
+    return vq_decode_impl(h, which, idx, nullptr, B, L, batch_row_offset, rows_per_clip, out, ws, ws_bytes, stream);
+}
+
+int dimx_vq_decode_latent(dimx_handle h, int which, const float* z, int B, int L, int batch_row_offset, float* out,
+                          void* ws, size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(z, DIMX_ERR_ARG, "vq_decode_latent: null argument");
+    return vq_decode_impl(h, which, nullptr, z, B, L, batch_row_offset, 1, out, ws, ws_bytes, stream);
+}
+
+// SLMFT.forward_encoder alone (code/seq2seq_pretrain.py:431-442): x_s = norm_s(encoder_joint(encoder_s(v + patch)))
+int dimx_encode_speaker(dimx_handle h, const float* v_speaker, const uint8_t* mask, int B, int T, float* x_s_out, void* ws,
+                        size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(h && h->variant == 0, DIMX_ERR_ARG, "encode_speaker: SLMFT variant only");
+    DIMX_TRY(check_common(h, B, T, ws, ws_bytes, COMP_ENC));
+    DIMX_REQUIRE(v_speaker && mask && x_s_out, DIMX_ERR_ARG, "encode_speaker: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, T, nullptr);
+    EncScratch s;
+    plan_enc(h, ar, B, T, s);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "encode_speaker: workspace overflow");
+    const int M = B * T, dim = h->d.dim;
+    DIMX_TRY(launch_cast_pad(h->at, v_speaker, h->d.dim_in, h->patch_s, s.xa, 64, M, h->d.dim_in, st));
+    DIMX_TRY(run_xenc(h, h->encg[0], h->enc_s, s.xa, 64, s, B, T, mask, h->at, s.xa, st));
+    DIMX_TRY(run_xenc(h, h->encg[1], h->enc_joint, s.xa, dim, s, B, T, mask, DIMX_F32, s.tmp, st));
+    DIMX_TRY(launch_layernorm(DIMX_F32, s.tmp, x_s_out, h->norm_s_g, h->norm_s_b, M, dim, st));
+    h->ctx_ready = false;  // the encoder scratch overlaps a previously built context
     return DIMX_OK;
 }
 
@@ -1467,7 +1512,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     DIMX_TRY(slab_gemm(s.y, DD, h->dec.logits, s.logits, s0.st_lg, &nlg));
     DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, nlg, s0.st_lg,
                            logits_out, n, row0, Btot, h->dec.tok_emb, DD, s.x, s.step, (unsigned*)(s.step + 8), st, pos,
-                           pos_scale, n));
+                           pos_scale, n, s.step + 2));
     return DIMX_OK;
 }
 
@@ -1493,7 +1538,10 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     plan_gen(h, ar, R, T, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "generate: workspace overflow");
     const int n = gen_steps(h, T);
-    DIMX_HIP(hipMemsetAsync(s.step, 0, 64 * dimx_ctx::kMaxGroups, st));
+    // step / done counters = 0; temperature, seed and the sampler's global row window go to device memory so that
+    // the captured step graph is independent of them
+    DIMX_TRY(launch_gen_params(s.step, dimx_ctx::kMaxGroups, temperature, seed, h->shard_row_off * S,
+                               h->shard_rows_total * S, st));
     // Independent clip groups run as separate step graphs on separate streams: every decode kernel is
     // latency-bound at these sizes, so two groups in flight let one group's GEMM/LayerNorm chain overlap the
     // other group's HBM-bound attention.  Results do not depend on the grouping (per-clip state only; the
@@ -1525,7 +1573,8 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
                 DIMX_TRY(gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], R, g, T, temperature, top_k,
                                   exp_noise, seed, tokens, logits_out, gs[g], false, S));
     } else {
-        GraphKey key{ws, B, T, top_k, temperature, exp_noise, seed, start, ctx_mask, tokens, logits_out, G * 100 + S};
+        // greedy vs sampling is decided from the device-side parameters; only shapes and pointers key the graph
+        GraphKey key{ws, B, T, top_k, 0.f, exp_noise, 0, start, ctx_mask, tokens, logits_out, G * 100 + S};
         if (!(h->graph_valid && h->graph_key == key)) {
             h->graph_valid = false;
             if (!h->cap_stream) DIMX_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -1649,6 +1698,36 @@ int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void
     a.q_f32 = q_is_f32 ? 1 : 0;
     a.nslab = 1;
     return launch_decode_attn(a, (hipStream_t)stream);
+}
+
+int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, void* vcache, void* out, int B, int H,
+                             int Tmax, const int32_t* step_dev, float scale, int q_is_f32, void* stream) {
+    DecodeAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = dtype;
+    const size_t es = q_is_f32 ? 4 : dtype_size(dtype);
+    a.q = qkv;
+    a.q_ld = ld;
+    a.knew = (const unsigned char*)qkv + (size_t)H * 64 * es;
+    a.vnew = (const unsigned char*)qkv + (size_t)2 * H * 64 * es;
+    a.kv_ld = ld;
+    a.kcache = kcache;
+    a.vcache = vcache;
+    a.Tmax = Tmax;
+    a.out = out;
+    a.o_ld = H * 64;
+    a.B = B;
+    a.H = H;
+    a.step = step_dev;
+    a.scale = scale;
+    a.q_f32 = q_is_f32 ? 1 : 0;
+    a.nslab = 1;
+    return launch_decode_attn(a, (hipStream_t)stream);
+}
+
+int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
+                                const float* gamma, int M, int C, void* stream) {
+    return launch_add_slabs_layernorm(out_dtype, x, slabs, nslab, slab_stride, y, gamma, M, C, (hipStream_t)stream);
 }
 
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise, uint64_t seed,

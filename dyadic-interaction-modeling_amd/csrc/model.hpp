@@ -142,4 +142,7 @@ struct dimx_ctx {
     dimx::GraphKey graph_key{};
     bool graph_valid = false;
     int use_graph = 1;
+    // sampler generator window of a sharded batch (dimx_set_shard): this handle generates clips
+    // [shard_row_off, shard_row_off + B) of shard_rows_total (0 = the call's own B)
+    int shard_row_off = 0, shard_rows_total = 0;
 };

@@ -102,9 +102,13 @@ def _loader(ds, batch_size, shuffle):
 
 def get_vico_dataloaders(batch_size, data_path="../data/vico_processed_30fps", meta_data_path="../data/RLD_data.csv",
                          synthetic=None):
-    """reference :461-478 -> {'train', 'valid', 'all'} loaders.  When the ViCo files are absent (or ``synthetic``
-    is given: a dict of SyntheticDyadDataset kwargs) the loaders serve synthetic clips of the same format."""
-    if synthetic is None and os.path.isdir(data_path) and os.path.isfile(meta_data_path):
+    """reference :461-478 -> {'train', 'valid', 'all'} loaders.  ``synthetic`` (a dict of SyntheticDyadDataset
+    kwargs) asks for synthetic clips of the same format; without it the ViCo files must exist -- like the reference,
+    which fails on a missing data directory -- so metrics on random clips can never pass for ViCo results."""
+    if synthetic is None:
+        if not (os.path.isdir(data_path) and os.path.isfile(meta_data_path)):
+            raise FileNotFoundError("ViCo data not found (%s, %s); pass synthetic={...} to get synthetic clips"
+                                    % (data_path, meta_data_path))
         train, val = ViCoDataset(data_path, meta_data_path, "train"), ViCoDataset(data_path, meta_data_path, "test")
     else:
         kw = dict(synthetic or {})

@@ -49,16 +49,23 @@ def shard_bounds(n, r, w):
     return lo, lo + base + (1 if r < extra else 0)
 
 
+def all_gather_counts(n_rows, device):
+    """[rows held by rank 0, rank 1, ...]."""
+    if world_size() == 1:
+        return [int(n_rows)]
+    n = torch.tensor([int(n_rows)], device=device, dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(world_size())]
+    dist.all_gather(counts, n)
+    return [int(c.item()) for c in counts]
+
+
 def all_gather_rows(t):
-    """Concatenate every rank's rows along dim 0 (shards may differ in length by one row)."""
+    """Concatenate every rank's rows along dim 0 (shards may differ in length, empty shards included)."""
     if world_size() == 1:
         return t
     t = t.contiguous()
     w = world_size()
-    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
-    counts = [torch.zeros_like(n) for _ in range(w)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    counts = all_gather_counts(t.shape[0], t.device)
     if len(set(counts)) == 1:
         out = torch.empty((w * counts[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t)

@@ -120,6 +120,33 @@ class Engine:
                                         self._s()), "dimx_vq_decode")
         return out
 
+    def vq_decode_latent(self, which, z, row_offset=0):
+        """z [B,L,128] f32 (time-major latents, quantised or not) -> [B,L,56]: VQAutoEncoder.decode on what it is given."""
+        B, Lq, _ = z.shape
+        z = z.to(torch.float32).contiguous()
+        self._chk(z)
+        out = torch.empty(B, Lq, self.dims.vq_in_dim, dtype=torch.float32, device=self.device)
+        ws, wsb = self.workspace(B, Lq)
+        L.check(self.lib.dimx_vq_decode_latent(self.h, which, L.ptr(z), B, Lq, row_offset, L.ptr(out), ws, wsb,
+                                               self._s()), "dimx_vq_decode_latent")
+        return out
+
+    def encode_speaker(self, v_speaker, mask_u8):
+        """SLMFT.forward_encoder alone -> x_s [B,T,384] f32 (no audio, no context, no K/V projection)."""
+        B, T, _ = v_speaker.shape
+        v_speaker = v_speaker.to(torch.float32).contiguous()
+        self._chk(v_speaker, mask_u8)
+        x_s = torch.empty(B, T, self.dims.dim, dtype=torch.float32, device=self.device)
+        ws, wsb = self.workspace(B, T)
+        L.check(self.lib.dimx_encode_speaker(self.h, L.ptr(v_speaker), L.ptr(mask_u8), B, T, L.ptr(x_s), ws, wsb,
+                                             self._s()), "dimx_encode_speaker")
+        return x_s
+
+    def set_shard(self, row_offset=0, rows_total=0):
+        """This engine generates clips [row_offset, row_offset+B) of a sharded batch of rows_total clips (only the
+        sampler's counter-based generator depends on it); (0, 0) = unsharded."""
+        L.check(self.lib.dimx_set_shard(self.h, int(row_offset), int(rows_total)), "dimx_set_shard")
+
     def encode_ctx(self, v_speaker, v_audio, mask_u8, for_generate, return_x_s=False, n_samples=1):
         B, T, _ = v_speaker.shape
         v_speaker = v_speaker.to(torch.float32).contiguous()

@@ -54,6 +54,11 @@ SIGNATURES = {
     "dimx_vq_argmin": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dimx_vq_decode": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
+    "dimx_vq_decode_latent": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
+    "dimx_encode_speaker": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
+    "dimx_set_shard": (c_int, [c_void_p, c_int, c_int]),
     "dimx_encode_ctx": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
     "dimx_legacy_speaker_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
@@ -75,6 +80,10 @@ SIGNATURES = {
                                   c_void_p]),
     "dimx_op_decode_attn": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p, c_int, c_int, c_void_p]),
+    "dimx_op_decode_attn_self": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_void_p, c_float, c_int, c_void_p]),
+    "dimx_op_add_slabs_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_int, ctypes.c_long, c_void_p, c_void_p, c_int,
+                                            c_int, c_void_p]),
     "dimx_op_sample": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p,
                                c_void_p]),
 }
@@ -87,20 +96,35 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    in_tree = "DIMX_LIB" not in os.environ
     if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
+        if not build_if_missing or not in_tree:
             raise DimxError("libdimx_hip.so not found at %s (run python __graft_entry__.py build)" % LIB_PATH)
         from . import build as _build
         _build.build()
+    elif in_tree and build_if_missing:
+        # the in-tree library is rebuilt when a source or header is newer than it (mtime check, no-op otherwise), so
+        # the ctypes signatures below can never describe a stale binary; a box without hipcc keeps the shipped .so
+        from . import build as _build
+        if _build.stale() and _build.have_hipcc():
+            _build.build()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        if "DIMX_LIB" in os.environ and not hasattr(lib, name):
-            continue                  # A/B run against an older saved build: newer entry points are absent
+        if not in_tree and not hasattr(lib, name):
+            # A/B run against an older saved build (DIMX_LIB): a newer entry point fails at its first use, loudly
+            setattr(lib, name, _missing_symbol(name))
+            continue
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _missing_symbol(name):
+    def _raise(*a, **k):
+        raise DimxError("%s is not exported by %s (DIMX_LIB points to an older build)" % (name, LIB_PATH))
+    return _raise
 
 
 def check(status, what=""):

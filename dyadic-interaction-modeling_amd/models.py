@@ -127,13 +127,11 @@ class VQAutoEncoder(_EngineOwner):
         return self.engine(idx.device).vq_decode(self.which, idx, batch_row_offset)
 
     @torch.no_grad()
-    def decode(self, quant):
-        """quant [B,128,L] (codebook rows, as encode returns them) -> [B,L,56].  The rows are mapped back
-        to their indices with the HIP argmin (exact for codebook rows) and decoded on the GPU."""
-        B, C, Lq = quant.shape
-        z = quant.permute(0, 2, 1).reshape(B * Lq, C).contiguous()
-        idx = self.engine(quant.device).vq_argmin(self.which, z)
-        return self.decode_indices(idx.view(B, Lq))
+    def decode(self, quant, batch_row_offset=0):
+        """quant [B,128,L] -> [B,L,56] (reference :29-37): the decoder runs on the latents it is GIVEN -- codebook
+        rows as ``encode`` returns them, or any other [B,128,L] tensor -- with no re-quantisation."""
+        return self.engine(quant.device).vq_decode_latent(self.which, quant.permute(0, 2, 1).contiguous(),
+                                                          batch_row_offset)
 
     def forward(self, x):
         quant, emb_loss, info = self.encode(x)

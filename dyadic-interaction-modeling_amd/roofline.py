@@ -10,12 +10,39 @@ exactly as dimx_generate launches them, on the current stream, bracketed by HIP 
   * decode GEMM (the 1152 <- 4608 feed-forward down projection, M = B rows, f32 residual epilogue).
     Algorithmic flops per launch = 2*B*1152*4608; bound = MFMA (2.5 PFLOP/s dense bf16, 157.3 TFLOP/s f32).
 
-`traffic` (HBM bytes per launch from the TCC PMC counters) is filled in from profiles/ when a PMC pass was
-collected for the same commit, else null.
+`traffic` (HBM bytes per launch from the TCC PMC counters) comes from profiles/pmc_decode_attn_<hash>.json, where
+<hash> is the first 12 hex digits of the sha256 of csrc/decode_attn.hip: a PMC pass only counts for the kernel source
+it was collected on (tools/pmc_record.py writes the file; .git does not travel to the GPU box, so the kernel source
+hash -- not the commit id -- is what ties the two together; the commit is recorded inside the file).  No matching
+file -> null.
 """
+import hashlib
+import json
+import os
+
 import torch
 
 from . import engine as E
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PROFILES = os.path.join(os.path.dirname(HERE), "profiles")
+
+
+def kernel_source_hash(name="decode_attn.hip"):
+    with open(os.path.join(HERE, "csrc", name), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:12]
+
+
+def pmc_traffic(B, T, mode):
+    """HBM bytes per launch of the cross-attention decode kernel from the PMC pass recorded for THIS kernel source."""
+    path = os.path.join(PROFILES, "pmc_decode_attn_%s.json" % kernel_source_hash())
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    if (rec.get("B"), rec.get("T"), rec.get("mode")) != (B, T, mode):
+        return None
+    return float(rec["traffic_bytes"])
 
 HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
@@ -46,13 +73,61 @@ def decode_attention(B, T, mode, device, iters=40):
     sec = _time_launches(lambda i: E.op_decode_attn(q, kc[i % layers], vc[i % layers], T, 0.125, km), 8, iters)
     alg_bytes = B * H * T * 64 * 2 * es + 2 * B * H * 64 * es
     gbs = alg_bytes / sec / 1e9
-    # HBM bytes per launch from the committed PMC pass (profiles/r01c_pmc_*): FETCH_SIZE (KB) is doubled for
-    # 16-B/lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM section) + WRITE_SIZE (KB)
-    traffic = None
-    if (B, T, mode) == (256, 300, "bf16"):
-        traffic = (2 * 115793.0 + 384.0) * 1024   # profiles/r01c_pmc_{FETCH,WRITE}_SIZE_roofline_kernels.txt
+    # HBM bytes per launch from the PMC pass recorded for this kernel source (FETCH_SIZE doubled for 16-B/lane
+    # streaming reads on gfx950 per MI355X_MICROARCH.md + WRITE_SIZE), else null
+    traffic = pmc_traffic(B, T, mode)
     return {"kernel": "decode_attn_kernel<%s, false, true, 1> (cross-attention form, %d keys)" % ("dimx::bf16" if mode == "bf16" else "float", T), "bound": "hbm",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sec * 1e6}
+
+
+def decode_self_attention(B, T, mode, device, iters=40):
+    """Self-attention form of the step kernel at the AVERAGE cache fill of the loop (T/2 keys): appends the step's
+    k/v and streams the [B,12,n,64] K and V caches.  Algorithmic bytes = B*12*n*64*2*es + q/k/v in (f32) + out."""
+    from . import lib as L
+    lib = L.load()
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    es = 2 if mode == "bf16" else 4
+    H, n = 12, T // 2
+    layers = 4
+    kc = [torch.randn(B, H, T, 64, device=device).to(dt) for _ in range(layers)]
+    vc = [torch.randn(B, H, T, 64, device=device).to(dt) for _ in range(layers)]
+    qkv = torch.randn(B, 3 * H * 64, device=device)
+    out = torch.empty(B, H * 64, device=device, dtype=dt)
+    step = torch.tensor([n], dtype=torch.int32, device=device)
+
+    def run(i):
+        L.check(lib.dimx_op_decode_attn_self(L.BF16 if mode == "bf16" else L.F32, L.ptr(qkv), 3 * H * 64,
+                                             L.ptr(kc[i % layers]), L.ptr(vc[i % layers]), L.ptr(out), B, H, T,
+                                             L.ptr(step), 0.125, 1, L.stream_ptr(device)), "decode_attn_self")
+    sec = _time_launches(run, 8, iters)
+    alg_bytes = B * H * n * 64 * 2 * es + B * 3 * H * 64 * 4 + B * H * 64 * es + 2 * B * H * 64 * es
+    gbs = alg_bytes / sec / 1e9
+    return {"kernel": "decode_attn_kernel<%s, true, true, 1> (self-attention form, %d cached keys = mean fill)" % (
+                "dimx::bf16" if mode == "bf16" else "float", n), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_us": sec * 1e6}
+
+
+def decode_layernorm(B, mode, device, iters=60, C=1152, nslab=4):
+    """Residual + pre-norm of the decode step (x += 4 split-K slabs; y = LN(x)): B rows of 1152.  Algorithmic bytes =
+    B*C*(4 read x + 4*nslab read slabs + 4 write x + es write y); latency-bound at B = 256."""
+    from . import lib as L
+    lib = L.load()
+    es = 2 if mode == "bf16" else 4
+    x = torch.randn(B, C, device=device)
+    slabs = torch.randn(nslab, B, C, device=device) * 0.01
+    y = torch.empty(B, C, device=device, dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
+    g = torch.ones(C, device=device)
+
+    def run(i):
+        L.check(lib.dimx_op_add_slabs_layernorm(L.BF16 if mode == "bf16" else L.F32, L.ptr(x), L.ptr(slabs), nslab, B * C,
+                                                L.ptr(y), L.ptr(g), B, C, L.stream_ptr(device)), "add_slabs_layernorm")
+    sec = _time_launches(run, 8, iters)
+    alg_bytes = B * C * (4 + 4 * nslab + 4 + es)
+    gbs = alg_bytes / sec / 1e9
+    return {"kernel": "add_slabs_layernorm_kernel<%s, %d> (%d slabs)" % (mode, C, nslab), "bound": "hbm", "achieved": gbs,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sec * 1e6}
 
 
@@ -118,4 +193,5 @@ def dominant_kernel(eng, B, T, mode):
     first, second = (att, gem) if att_share >= gem_share else (gem, att)
     first = dict(first)
     first["secondary"] = second
+    first["others"] = [decode_self_attention(B, T, mode, dev), decode_layernorm(B, mode, dev)]
     return first

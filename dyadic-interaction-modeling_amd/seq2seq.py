@@ -125,8 +125,9 @@ class ListenerGenerator(_EngineOwner):
         if greedy:
             temperature, seed_v = 0.0, 0
         else:
-            seed_v = 0 if noise is not None else (seed if seed is not None else
-                                                  int(torch.randint(1, 2 ** 62, (1,)).item()))
+            # seed 0 is reserved by the C-ABI for "greedy when no noise is given": remap it
+            from .seq2seq_pretrain import SLMFT as _S
+            seed_v = 0 if noise is not None else _S._user_seed(seed)
         T = z_l.shape[1]
         tok = eng.generate(z_l[:, 0], m8, T, temperature, 52, noise, seed_v, n_samples=n_samples).long()
         if n_samples > 1:

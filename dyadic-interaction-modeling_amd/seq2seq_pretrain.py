@@ -83,34 +83,49 @@ class SLMFT(_EngineOwner):
     @torch.no_grad()
     def forward_encoder(self, v_speaker, mask):
         """reference :431-442 -> x_s [B,T,384] (rows of padded frames are unspecified)."""
-        eng = self.engine(v_speaker.device)
-        zeros = torch.zeros(v_speaker.shape[0], v_speaker.shape[1], self.s2s.dim_a, device=v_speaker.device)
-        return eng.encode_ctx(v_speaker, zeros, self._mask8(mask), False, return_x_s=True)
+        return self.engine(v_speaker.device).encode_speaker(v_speaker, self._mask8(mask.bool()))
+
+    def _build_context(self, eng, x_s, v_speaker, x_a, m8, for_generate, n_samples=1):
+        # x_s given (the reference's call shape): context straight from it; x_s None + v_speaker: the fused stage that
+        # keeps the encoder output inside the workspace (what forward() uses)
+        if x_s is not None:
+            eng.set_context(x_s, x_a, which_patch=0, for_generate=for_generate, n_samples=n_samples)
+        else:
+            assert v_speaker is not None, "forward_decoder needs x_s (reference call) or v_speaker= (fused path)"
+            eng.encode_ctx(v_speaker, x_a, m8, for_generate, n_samples=n_samples)
+
+    @staticmethod
+    def _user_seed(seed):
+        """seed -> non-zero generator key (the C-ABI reserves 0 for 'greedy when no noise is given')."""
+        if seed is None:
+            return int(torch.randint(1, 2 ** 62, (1,)).item())
+        seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        return seed if seed != 0 else 0x9E3779B97F4A7C15
 
     @torch.no_grad()
     def forward_decoder(self, x_s, z_l, x_a, mask, mode, v_speaker=None, noise=None, kv_mask=None, greedy=False,
                         seed=None, temperature=1.0, n_samples=1):
-        """reference :444-452.  The encoder output lives inside the engine workspace, so this needs the
-        speaker motion (``v_speaker``) rather than ``x_s`` to (re)build the context."""
-        assert v_speaker is not None, "dimx keeps x_s on the device: pass v_speaker= to forward_decoder"
-        eng = self.engine(v_speaker.device)
-        m8 = self._mask8(mask)
+        """reference :444-452, same positional call: ``forward_decoder(x_s, z_l, x_a, mask, mode)`` with the ``x_s``
+        that ``forward_encoder`` returned.  ``forward()`` passes ``x_s=None, v_speaker=...`` instead, which keeps the
+        encoder output inside the engine workspace (no round trip through a tensor)."""
+        dev = (x_s if x_s is not None else v_speaker).device
+        eng = self.engine(dev)
+        m8 = self._mask8(mask.bool())
         B, T = z_l.shape
         if mode == "train":
-            eng.encode_ctx(v_speaker, x_a, m8, False)
+            self._build_context(eng, x_s, v_speaker, x_a, m8, False)
             if kv_mask is None:
-                kv_mask = self.draw_kv_mask(B, T, v_speaker.device)
+                kv_mask = self.draw_kv_mask(B, T, dev)
             elif kv_mask is False:
                 kv_mask = None
             logits, row_loss, _ = eng.decode_tf(z_l, m8, self._mask8(kv_mask) if kv_mask is not None else None)
             n_valid = (z_l[:, 1:] != -100).sum().clamp(min=1)
             return row_loss.sum() / n_valid, logits
-        eng.encode_ctx(v_speaker, x_a, m8, True, n_samples=n_samples)
+        self._build_context(eng, x_s, v_speaker, x_a, m8, True, n_samples=n_samples)
         if greedy:
             temperature, seed_v = 0.0, 0
         else:
-            seed_v = 0 if noise is not None else (seed if seed is not None else
-                                                  int(torch.randint(1, 2 ** 62, (1,)).item()))
+            seed_v = 0 if noise is not None else self._user_seed(seed)
         tokens = eng.generate(z_l[:, 0], m8, T, temperature, 52, noise, seed_v, n_samples=n_samples)
         return 0.0, tokens.long()
 
@@ -141,7 +156,7 @@ class SLMFT(_EngineOwner):
     @torch.no_grad()
     def forward(self, v_speaker, v_listener, v_audio, mask, mode="train", speaker_ids=None, listener_ids=None,
                 noise=None, kv_mask=None, greedy=False, seed=None, temperature=1.0, batch_row_offset=0,
-                return_tokens=False, n_samples=1):
+                return_tokens=False, n_samples=1, shard=None):
         """reference :496-514 -> (total_loss, dict, pred_cont_seq_l [B,T-1,56]).
 
         ``n_samples`` S > 1 (mode 'val' only): S independent generations per clip in ONE pass -- what the
@@ -151,9 +166,16 @@ class SLMFT(_EngineOwner):
         S = int(n_samples)
         assert S == 1 or mode != "train", "n_samples applies to mode='val'"
         _, z_l = self.forward_vq(v_speaker, v_listener, mask, with_speaker=False)
-        l_ce_l, px_l = self.forward_decoder(None, z_l, v_audio, mask, mode, v_speaker=v_speaker, noise=noise,
-                                            kv_mask=kv_mask, greedy=greedy, seed=seed, temperature=temperature,
-                                            n_samples=S)
+        # shard = (first clip row, clips in the whole batch) when this call is one rank's slice of a batch: together
+        # with batch_row_offset it makes the slice reproduce the same rows of a single-process call
+        eng = self.engine(v_speaker.device)
+        eng.set_shard(*(shard if shard is not None else (0, 0)))
+        try:
+            l_ce_l, px_l = self.forward_decoder(None, z_l, v_audio, mask, mode, v_speaker=v_speaker, noise=noise,
+                                                kv_mask=kv_mask, greedy=greedy, seed=seed, temperature=temperature,
+                                                n_samples=S)
+        finally:
+            eng.set_shard(0, 0)
         pred = self.forward_vq_decoder(px_l, mode=mode, batch_row_offset=batch_row_offset, rows_per_clip=S)
         if S > 1:
             B, T = mask.shape

@@ -55,16 +55,38 @@ def evaluate_finetune_epoch(model, loader, device):
 BATCHED_SAMPLE_COUNTS = (2, 4, 5, 8, 10)
 
 
-def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=True, **forward_kw):
-    """reference code/x_engine_pt.py:232-277 (autoregressive generation, best of ``beam_size`` by FD).
+def _gather_ragged(best, n_local, width, feat, device):
+    """all-gather a rank's list of [n_j, feat] arrays (None = no candidate was ever better than inf, as in the
+    reference) in shard order; returns the list for the whole batch."""
+    lens = torch.tensor([-1 if b is None else b.shape[0] for b in best], dtype=torch.int64, device=device)
+    pad = torch.zeros(n_local, width, feat, dtype=torch.float32, device=device)
+    for j, b in enumerate(best):
+        if b is not None and b.shape[0]:
+            pad[j, :b.shape[0]] = torch.from_numpy(np.ascontiguousarray(b)).to(device)
+    lens = ddist.all_gather_rows(lens).cpu().tolist()
+    pad = ddist.all_gather_rows(pad).cpu().numpy()
+    return [None if n < 0 else pad[j, :n].copy() for j, n in enumerate(lens)]
+
+
+def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=True, skip_degenerate=False,
+                        **forward_kw):
+    """reference code/x_engine_pt.py:232-277 (autoregressive generation, best of ``beam_size`` by FD; a candidate
+    replaces the current best only when its FD is strictly smaller, and scipy's "Imaginary component" ValueError on a
+    degenerate clip propagates, both as in the reference; ``skip_degenerate=True`` scores such a candidate as inf).
 
     ``batched_samples``: draw the ``beam_size`` generations of a clip in ONE forward pass (n_samples) instead of
     ``beam_size`` passes -- same distribution (independent multinomial draws given the same inputs), but the VQ
     encode, the encoder stack and the context K/V stream are shared.  Falls back to the reference's loop for
-    sample counts the kernels are not instantiated for."""
+    sample counts the kernels are not instantiated for.
+
+    Multi-GPU (default process group initialised): every rank receives the full batch from its loader, generates and
+    scores rows [lo, hi) of it (``batch_row_offset=lo`` and ``shard=(lo, B)`` keep positional rows and sampler
+    streams those of the unsharded batch) and the selected predictions are all-gathered, so every rank returns the
+    complete lists."""
     y_trues_all, y_preds_all, x_all, data_ids_all = [], [], [], []
     model.eval()
     batched = batched_samples and beam_size in BATCHED_SAMPLE_COUNTS
+    rank, world = ddist.rank(), ddist.world_size()
     with torch.no_grad():
         for batch in loader:
             src_s_v, src_s_a, tgt, mask, src_len, data_ids = _prepare(batch, device)
@@ -76,46 +98,71 @@ def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=Tru
                 y_trues_all.append(y_true[j][:n])
                 data_ids_all.append(data_ids[j])
                 x_all.append(xs[j][:n])
-            cur_best = [float("inf")] * B
-            best = [None] * B
+            lo, hi = ddist.shard_bounds(B, rank, world)
+            nl = hi - lo
+            cur_best = [float("inf")] * nl
+            best = [None] * nl
 
-            def consider(yp):           # yp [B, T-1, 56] numpy: one sample per clip
-                for j in range(B):
-                    n = src_len[j] - 1
+            def consider(yp):           # yp [nl, T-1, 56] numpy: one sample per local clip
+                for j in range(nl):
+                    n = src_len[lo + j] - 1
                     try:
-                        cfid = clip_fd(y_true[j][:n], yp[j][:n])
+                        cfid = clip_fd(y_true[lo + j][:n], yp[j][:n])
                     except ValueError:
-                        # scipy's sqrtm left an imaginary component (rank-deficient covariance of a very short
-                        # clip): the reference's calculate_frechet_distance raises here and aborts the epoch;
-                        # this candidate is skipped instead (kept only if nothing else was scored)
+                        if not skip_degenerate:
+                            raise
                         cfid = float("inf")
-                    if cfid < cur_best[j] or best[j] is None:
+                    if cfid < cur_best[j]:
                         best[j] = yp[j][:n].copy()
                         cur_best[j] = cfid
-            if batched:
-                _, _, y_preds = model(src_s_v, tgt, src_s_a, mask, mode="val", n_samples=beam_size, **forward_kw)
-                yp_all = y_preds.cpu().numpy()          # [B, S, T-1, 56]
-                for s_i in range(beam_size):
-                    consider(yp_all[:, s_i])
-            else:
-                for _ in range(beam_size):
-                    _, _, y_preds = model(src_s_v, tgt, src_s_a, mask, mode="val", **forward_kw)
-                    consider(y_preds.cpu().numpy())
+            if nl > 0:
+                kw = dict(forward_kw)
+                if world > 1:
+                    kw.update(batch_row_offset=lo, shard=(lo, B))
+                sl = [t[lo:hi].contiguous() for t in (src_s_v, tgt, src_s_a, mask)]
+                if batched:
+                    _, _, y_preds = model(sl[0], sl[1], sl[2], sl[3], mode="val", n_samples=beam_size, **kw)
+                    yp_all = y_preds.cpu().numpy()          # [nl, S, T-1, 56]
+                    for s_i in range(beam_size):
+                        consider(yp_all[:, s_i])
+                else:
+                    for _ in range(beam_size):
+                        _, _, y_preds = model(sl[0], sl[1], sl[2], sl[3], mode="val", **kw)
+                        consider(y_preds.cpu().numpy())
+            if world > 1:
+                best = _gather_ragged(best, nl, tgt.shape[1] - 1, tgt.shape[2], device)
             y_preds_all.extend(best)
     return y_trues_all, y_preds_all, x_all, data_ids_all
 
 
 def generate_sharded(model, v_speaker, v_listener, v_audio, mask, **forward_kw):
     """One evaluation batch across the ranks of the default process group: every rank receives the FULL
-    batch (or just its shard with ``pre_sharded=True``), evaluates rows [rank*B/W, (rank+1)*B/W) and the
-    generated code indices + decoded coefficients are all-gathered (RCCL over xGMI on GPUs).
-    Returns (tokens [B,T-1] int32, pred [B,T-1,56]) on every rank."""
+    batch (or just its shard with ``pre_sharded=True``), evaluates rows [lo, hi) and the generated code indices +
+    decoded coefficients are all-gathered (RCCL over xGMI on GPUs).  The shard is run with
+    ``batch_row_offset=lo`` (the VQ decoder's batch-row positional quirk) and ``shard=(lo, B)`` (the sampler's
+    counter-based generator is indexed by the global row), so the gathered result equals the single-process
+    result for the same seed / injected noise.  Returns (tokens [B,T-1] int32, pred [B,T-1,56]) on every rank."""
     pre_sharded = forward_kw.pop("pre_sharded", False)
     rank, world = ddist.rank(), ddist.world_size()
-    if not pre_sharded:
-        lo, hi = ddist.shard_bounds(v_speaker.shape[0], rank, world)
+    if pre_sharded:
+        counts = ddist.all_gather_counts(v_speaker.shape[0], v_speaker.device)
+        lo, total = sum(counts[:rank]), sum(counts)
+    else:
+        total = v_speaker.shape[0]
+        lo, hi = ddist.shard_bounds(total, rank, world)
+        noise = forward_kw.get("noise")
+        if noise is not None:                       # injected sampling noise [T-1, B, 512]: this shard's columns
+            forward_kw["noise"] = noise[:, lo:hi].contiguous()
         v_speaker, v_listener, v_audio, mask = (t[lo:hi].contiguous() for t in (v_speaker, v_listener, v_audio, mask))
-    _, _, pred, tokens = model(v_speaker, v_listener, v_audio, mask, mode="val", return_tokens=True, **forward_kw)
+    if world > 1:
+        forward_kw.setdefault("batch_row_offset", lo)
+        forward_kw.setdefault("shard", (lo, total))
+    if v_speaker.shape[0] > 0:
+        _, _, pred, tokens = model(v_speaker, v_listener, v_audio, mask, mode="val", return_tokens=True, **forward_kw)
+    else:
+        T = v_speaker.shape[1]
+        pred = torch.zeros(0, T - 1, v_listener.shape[2], device=v_speaker.device)
+        tokens = torch.zeros(0, T - 1, dtype=torch.int32, device=v_speaker.device)
     tokens = ddist.all_gather_rows(tokens.to(torch.int32))
     pred = ddist.all_gather_rows(pred)
     return tokens, pred

@@ -116,6 +116,24 @@ int dimx_vq_argmin(dimx_handle h, int which, const float* z, int N, int32_t* idx
 int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset,
                    int rows_per_clip, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* VQAutoEncoder.decode on latents the caller supplies (reference code/models/stage1_BIWI.py:29-37: decode(quant)
+ * applies the decoder to WHATEVER [B,128,L] tensor it is given, quantised or not): z [B,L,128] f32 (time-major,
+ * i.e. quant.permute(0,2,1)), clip b decoded with positional row b + batch_row_offset.  out: [B,L,56] f32. */
+int dimx_vq_decode_latent(dimx_handle h, int which, const float* z, int B, int L, int batch_row_offset,
+                          float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* SLMFT.forward_encoder on its own (reference code/seq2seq_pretrain.py:431-442): x_s_out [B,T,384] f32 =
+ * norm_s(encoder_joint(encoder_s(v_speaker + patch_embed_s))) with the causal attn_mask and the padding mask.
+ * No audio, no context, no K/V projection; invalidates a context built earlier in the same workspace. */
+int dimx_encode_speaker(dimx_handle h, const float* v_speaker, const uint8_t* mask, int B, int T,
+                        float* x_s_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Multi-GPU sharding of one evaluation batch: this handle generates clips
+ * [row_offset, row_offset + B) of a batch of rows_total clips.  Only the sampler's counter-based generator
+ * depends on it (its counter is indexed by the GLOBAL sequence row, so the shards of a batch draw exactly what a
+ * single process would draw for the same seed).  rows_total = 0 restores the default (the call's own B). */
+int dimx_set_shard(dimx_handle h, int row_offset, int rows_total);
+
 /* Speaker encoder stack + context assembly + cross-attention K/V projection for all decoder
  * layers.  v_speaker [B,T,56] f32, v_audio [B,T,768] f32, mask [B,T] uint8 (1 = valid frame).
  * The result lives in the workspace (same ws must be passed to the decode call that follows).
@@ -207,6 +225,14 @@ int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, v
 int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void* vcache, void* out, int B, int H,
                         int Tmax, int n_keys, float scale, const uint8_t* kmask, int nsplit, int q_is_f32,
                         void* stream);
+/* Self-attention form of the step kernel, exactly as dimx_generate launches it: qkv [B, ld] holds this step's
+ * q | k | v (H*64 each; f32 when q_is_f32, else the cache type), *step_dev keys are already cached; the kernel
+ * appends k/v at position *step_dev and attends over *step_dev + 1 keys.  out [B, H*64] in the cache type. */
+int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, void* vcache, void* out, int B, int H,
+                             int Tmax, const int32_t* step_dev, float scale, int q_is_f32, void* stream);
+/* Decode-step residual + pre-norm: x[M,C] += sum_s slabs[s] (fixed order), y = LayerNorm(x) * gamma (no bias). */
+int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
+                                const float* gamma, int M, int C, void* stream);
 /* tokens = sampler(logits[R,512]) -- see dimx_generate. */
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise,
                    uint64_t seed, uint64_t step, int32_t* tokens, void* stream);

@@ -292,3 +292,50 @@ def postprocess_fixture():
 
 if __name__ == "__main__" and "--postprocess" in sys.argv:
     postprocess_fixture()
+
+
+def host_protocol_fixture():
+    """the reference's OWN evaluation loops and collate function, lifted out of their modules
+    by AST (code/x_engine_pt.py imports torcheval and code/dataset/data_loader.py reads files at import; neither
+    import works here), executed around tests/stub_model.StubSLMFT on seeded batches."""
+    import ast
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, REF)
+    import stub_model
+    from metrics.eval_utils import calculate_activation_statistics, calculate_frechet_distance
+
+    def lift(path, names, ns):
+        tree = ast.parse(open(os.path.join(REF, path)).read())
+        fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        assert len(fns) == len(names), (path, names)
+        exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+        return ns
+
+    ns = lift("x_engine_pt.py", ("evaluate_test_epoch", "evaluate_finetune_epoch"),
+              {"torch": torch, "np": np, "tqdm": (lambda it, *a, **k: it),
+               "calculate_activation_statistics": calculate_activation_statistics,
+               "calculate_frechet_distance": calculate_frechet_distance})
+    dev = torch.device("cpu")
+    out = {}
+    yt, yp, xs, ids = ns["evaluate_test_epoch"](stub_model.StubSLMFT(), stub_model.protocol_batches(), dev)
+    out["test_ids"] = np.array(ids)
+    for name, lst in (("test_true", yt), ("test_pred", yp), ("test_x", xs)):
+        out[name + "_lens"] = np.array([a.shape[0] for a in lst])
+        out[name + ("" if name == "test_pred" else "_sum")] = (np.concatenate(lst, 0) if name == "test_pred" else
+                                                                np.array([float(a.astype(np.float64).sum()) for a in lst]))
+    yt, yp, xs, ids = ns["evaluate_finetune_epoch"](stub_model.StubSLMFT(), stub_model.protocol_batches(), dev)
+    for name, lst in (("ft_true", yt), ("ft_pred", yp), ("ft_x", xs)):
+        out[name + "_lens"] = np.array([a.shape[0] for a in lst])
+        out[name + ("" if name == "ft_pred" else "_sum")] = (np.concatenate(lst, 0) if name == "ft_pred" else
+                                                              np.array([float(a.astype(np.float64).sum()) for a in lst]))
+    cns = lift(os.path.join("dataset", "data_loader.py"), ("pad_collate",), {"torch": torch})
+    xx, yy, lens, (sp, li), names = cns["pad_collate"](stub_model.collate_items())
+    out.update(coll_x=xx.numpy(), coll_y=yy.numpy(), coll_lens=np.array(lens), coll_speaker=sp.numpy(),
+               coll_listener=li.numpy(), coll_names=np.array(names))
+    np.savez_compressed(os.path.join(HERE, "host_protocol.npz"), **out)
+    print("host_protocol: %d + %d clips, best-of-10 preds %s, collate %s" % (
+        len(out["test_pred_lens"]), len(out["ft_pred_lens"]), out["test_pred"].shape, out["coll_x"].shape))
+
+
+if __name__ == "__main__" and "--host-protocol" in sys.argv:
+    host_protocol_fixture()

@@ -64,3 +64,104 @@ def test_shard_bounds_partition():
         for w in (1, 2, 3, 8):
             b = [dd.shard_bounds(n, r, w) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The sharded evaluation paths (x_engine_pt.generate_sharded / evaluate_test_epoch) with a CPU stub standing in for
+# SLMFT: its outputs depend on the clip CONTENT, on the global batch row (batch_row_offset -- the VQ decoder's
+# positional quirk) and on a counter-based noise stream indexed by the global row (shard=(lo, total)), so the
+# world-size-2 result can only equal the single-process result if both offsets are plumbed through.
+# ---------------------------------------------------------------------------------------------------------------
+class _StubListener(torch.nn.Module):
+    def forward(self, v_speaker, v_listener, v_audio, mask, mode="val", n_samples=1, batch_row_offset=0, shard=None,
+                return_tokens=False, noise=None, seed=7, **kw):
+        B, T, _ = v_speaker.shape
+        off, total = shard if shard is not None else (0, B)
+        S = int(n_samples)
+        rows = torch.arange(B, dtype=torch.float32) + batch_row_offset                   # "positional row"
+        base = v_speaker[:, 1:, :] * 0.5 + v_audio[:, 1:, :56] * 0.25 + rows[:, None, None] * 1e-3
+        g_rows = (torch.arange(B) + off)[:, None] * S + torch.arange(S)[None, :]        # global sequence row
+        if noise is not None:                                                           # injected [T-1, B*S, 56]
+            nz = noise.permute(1, 0, 2).reshape(B, S, T - 1, -1)
+        else:
+            t = torch.arange(T - 1, dtype=torch.float32)[None, None, :, None]
+            c = torch.arange(56, dtype=torch.float32)[None, None, None, :]
+            nz = torch.sin(g_rows[:, :, None, None].float() * 12.9898 + t * 78.233 + c * 37.719 + seed) * 0.3
+        pred = base[:, None] + nz
+        tokens = (pred.abs().sum(-1) * 1000).long() % 512
+        if S == 1:
+            pred, tokens = pred[:, 0], tokens[:, 0]
+        out = (torch.zeros(()), {}, pred)
+        return out + (tokens,) if return_tokens else out
+
+
+def _eval_inputs(B=7, T=12):
+    g = torch.Generator().manual_seed(3)
+    v_s, v_l, v_a = torch.randn(B, T, 56, generator=g), torch.randn(B, T, 56, generator=g), torch.randn(B, T, 768, generator=g)
+    lens = [12, 9, 12, 5, 7, 12, 4][:B]
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    for j, n in enumerate(lens):
+        mask[j, :n] = True
+    src = torch.cat([v_s, v_a], -1) * mask[..., None]
+    loader = [(src, v_l * mask[..., None], lens, None, ["id%d" % j for j in range(B)])]
+    return v_s, v_l, v_a, mask, loader
+
+
+def _eval_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import dimx  # noqa: F401
+    from dimx import dist as dd
+    from dimx import x_engine_pt
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank))
+        dd.init_from_env("gloo")
+    model = _StubListener()
+    v_s, v_l, v_a, mask, loader = _eval_inputs()
+    tok, pred = x_engine_pt.generate_sharded(model, v_s, v_l, v_a, mask)
+    # pre-sharded inputs (every rank holds only its rows) must give the same gathered result
+    lo, hi = dd.shard_bounds(v_s.shape[0], dd.rank(), dd.world_size())
+    tok2, pred2 = x_engine_pt.generate_sharded(model, v_s[lo:hi], v_l[lo:hi], v_a[lo:hi], mask[lo:hi], pre_sharded=True)
+    yt, yp, xs, ids = x_engine_pt.evaluate_test_epoch(model, loader, torch.device("cpu"), beam_size=4)
+    yt3, yp3, _, _ = x_engine_pt.evaluate_test_epoch(model, loader, torch.device("cpu"), beam_size=3)   # looped samples
+    q.put((rank, tok.numpy(), pred.numpy(), tok2.numpy(), pred2.numpy(), [np.asarray(a) for a in yp],
+           [np.asarray(a) for a in yt], ids, [np.asarray(a) for a in yp3]))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _run_eval(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_sharded_generation_and_evaluation_equal_single_process_world2():
+    import numpy as np
+    single = _run_eval(1)[0]
+    for r in _run_eval(2):
+        assert np.array_equal(r[1], single[1]) and np.allclose(r[2], single[2], atol=0, rtol=0)      # generate_sharded
+        assert np.array_equal(r[3], single[1]) and np.array_equal(r[4], single[2])                    # pre-sharded
+        assert r[7] == single[7] and len(r[5]) == 7
+        for a, b in zip(r[5], single[5]):                       # best-of-4 (batched samples): same selected prediction
+            assert a.shape == b.shape and np.array_equal(a, b)
+        for a, b in zip(r[6], single[6]):
+            assert np.array_equal(a, b)
+        for a, b in zip(r[8], single[8]):                       # best-of-3 (sample loop)
+            assert np.array_equal(a, b)
+    # the stub really depends on both offsets: dropping them changes the second shard
+    m = _StubListener()
+    v_s, v_l, v_a, mask, _ = _eval_inputs()
+    full = m(v_s, v_l, v_a, mask)[2]
+    part = m(v_s[4:], v_l[4:], v_a[4:], mask[4:])[2]
+    good = m(v_s[4:], v_l[4:], v_a[4:], mask[4:], batch_row_offset=4, shard=(4, 7))[2]
+    assert not torch.equal(part, full[4:]) and torch.equal(good, full[4:])
