@@ -127,7 +127,9 @@ struct GemmArgs {
     const void* A;
     int lda;
     const void* W;
-    int ldw;  // = padded K
+    int ldw;  // row stride of W (elements), >= the k extent the loop runs over
+    int kloop;  // k extent of the main loop (multiple of the k-tile; 0 = ldw).  ldw > kloop lets the caller pad the
+                // row stride so that consecutive rows do not camp on the same L2 channels
     int M, N, K;
     // temporal k=5 convolution gather on A (conv_T > 0)
     int conv_T;

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.ldw / BK;  // W is padded to a multiple of BK
+    const int nk = (a.kloop ? a.kloop : a.ldw) / BK;  // W is padded to a multiple of BK
     gload(0);
     lstore(0);
     __syncthreads();
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     const T* __restrict__ W = (const T*)a.W;
 
     // k-tiles of this split
-    const int nk_all = a.ldw / BK;
+    const int nk_all = (a.kloop ? a.kloop : a.ldw) / BK;
     const int per = (nk_all + a.splitk - 1) / a.splitk;
     const int kt0 = split * per;
     int nk = nk_all - kt0;
@@ -812,7 +812,8 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     a.splitk = 1;
     const int bk = 8 * Elem<T>::kPerChunk;
     const long tiles128 = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
-    const bool pipelined = a.conv_T == 0 && a.K % bk == 0 && a.K == a.ldw && !a.force_simple;
+    const int kext = a.kloop ? a.kloop : a.ldw;
+    const bool pipelined = a.conv_T == 0 && a.K % bk == 0 && a.K == kext && !a.force_simple;
     if (!pipelined) {
         // gather / ragged-K path: register-staged kernel
         if (tiles128 >= 256) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
@@ -859,13 +860,14 @@ int gemm_plan_splits(const GemmArgs& a) {
     if (a.force_splitk > 0) return a.force_splitk;
     if (!a.allow_splitk) return 1;
     const int bk = a.in_dtype == DIMX_BF16 ? 64 : 32;
-    if (a.conv_T != 0 || a.K % bk != 0 || a.K != a.ldw || a.force_simple) return 1;  // register-staged kernel: no split
+    const int kext = a.kloop ? a.kloop : a.ldw;
+    if (a.conv_T != 0 || a.K % bk != 0 || a.K != kext || a.force_simple) return 1;  // register-staged kernel: no split
     int cfg = a.cfg, bm, bn;
     if (cfg == 0) cfg = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) >= 512 ? 14 : 4;
     cfg_tile(cfg, bm, bn);
     const int tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
     if (tiles >= 256) return 1;
-    const int nk = a.ldw / bk;
+    const int nk = kext / bk;
     // measured (tools/bench_gemm.py under rocprofv3): ~288 blocks (one per CU + a few) is the sweet spot
     static const int target = getenv("DIMX_SPLIT_TARGET") ? atoi(getenv("DIMX_SPLIT_TARGET")) : 288;
     static const int min_nk = getenv("DIMX_SPLIT_MINNK") ? atoi(getenv("DIMX_SPLIT_MINNK")) : 6;  // k-tiles per split at least (swept 3..9)
@@ -881,8 +883,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int bk = 8 * epc;
     const size_t es = dtype_size(a.in_dtype);
     DIMX_REQUIRE(a.A && a.W && a.M > 0 && a.N > 0 && a.K > 0, DIMX_ERR_ARG, "gemm: null operand or empty shape");
-    DIMX_REQUIRE(a.ldw % bk == 0 && a.ldw >= a.K, DIMX_ERR_ARG, "gemm: W must be K-padded to %d (ldw=%d K=%d)", bk,
-                 a.ldw, a.K);
+    DIMX_REQUIRE(a.ldw % epc == 0 && a.ldw >= a.K && (a.kloop ? a.kloop : a.ldw) % bk == 0 &&
+                     (a.kloop == 0 || (a.kloop >= a.K && a.kloop <= a.ldw)),
+                 DIMX_ERR_ARG, "gemm: W must be K-padded to %d (ldw=%d kloop=%d K=%d)", bk, a.ldw, a.kloop, a.K);
     DIMX_REQUIRE((a.lda * es) % 16 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, DIMX_ERR_ARG,
                  "gemm: A/W rows must be 16-byte aligned (lda=%d)", a.lda);
     DIMX_REQUIRE(a.K % epc == 0, DIMX_ERR_ARG, "gemm: K=%d must be a multiple of %d", a.K, epc);
@@ -895,7 +898,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         DIMX_REQUIRE(a.seg[i].ptr && a.seg[i].D > 0, DIMX_ERR_ARG, "gemm: output segment %d unset", i);
     if (a.out_slabs)
         DIMX_REQUIRE(a.out_dtype == DIMX_F32 && a.act == ACT_NONE && !a.residual && a.rowadd_mode == 0 && a.nseg == 1 &&
-                         a.conv_T == 0 && a.K == a.ldw,
+                         a.conv_T == 0 && a.K == (a.kloop ? a.kloop : a.ldw),
                      DIMX_ERR_ARG, "gemm: slab output needs a plain f32 GEMM without activation/residual");
     if (a.in_dtype == DIMX_BF16) {
         if (a.out_dtype == DIMX_BF16) return launch_typed<bf16, bf16>(a, s);

@@ -1637,6 +1637,7 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     g.slab_stride = (long)M * ldc;
     g.cfg = (flags >> 8) & 0xff;           /* tuning: tile/stage config id */
     g.force_splitk = (flags >> 16) & 0xff; /* tuning: split count */
+    if (ldw > K && K % (in_dtype == DIMX_BF16 ? 64 : 32) == 0) g.kloop = K; /* padded row stride, exact k extent */
     if (conv_T > 0) {
         g.conv_T = conv_T;
         g.conv_lens = conv_lens;

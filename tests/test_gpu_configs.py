@@ -132,7 +132,7 @@ def test_c4_rank7_shard_bf16_properties(model_bf16, model_f32, c4_clips):
     p_f = model_f32.engine(v_s.device).vq_decode(1, tok[:8].contiguous(), C4_OFF)
     err = (p_off - p_f).abs().max().item()
     print("C4 bf16 vs f32 VQ decode of the same codes (row offset 1792): max err %.4f" % err)
-    assert err < 5e-2
+    assert err <= 3e-2          # measured 0.0124
 
 
 # ------------------------------------------------------------------------------------------------ C5
@@ -172,7 +172,8 @@ def test_c5_shard_b64_t1500_bf16(model_bf16, model_f32):
     agree = (tf_arg == af)[valid].float().mean().item()
     print("C5 shard bf16: cache vs teacher-forced max logit err %.4f (argmax agreement on clear margins %.4f); "
           "bf16 vs f32 teacher-forced: max logit err %.4f, argmax agreement %.4f" % (cerr, cagree, lerr, agree))
-    assert cerr < 0.1 and cagree > 0.995
-    assert lerr < 0.1 and agree > 0.985
+    # measured on MI355X (round 2): 0.0078 / 1.0000 and 0.0117 / 0.9938 -- asserted with a small margin
+    assert cerr <= 2.5e-2 and cagree >= 0.999
+    assert lerr <= 3e-2 and agree >= 0.99
     pred = eng.vq_decode(1, g_tok)
     assert pred.shape == (Bc, Tc - 1, 56) and torch.isfinite(pred).all()

@@ -111,7 +111,8 @@ def test_c3_bf16_perf_mode(clips, full_f32):
     agree = (ab == af)[valid].float().mean().item()
     err = (lb - lf).abs()[valid].max().item()
     print("C3 bf16 vs f32: VQ index agreement %.4f, argmax agreement %.4f, max logit err %.4f" % (agree_idx, agree, err))
-    assert agree_idx > 0.95 and agree > 0.97
+    # measured on MI355X (round 2): 0.9915 / 0.9952 / 0.0093 -- asserted with a small margin
+    assert agree_idx >= 0.98 and agree >= 0.99 and err <= 2e-2
 
 
 def test_c5_long_context_t1500(model_f32):

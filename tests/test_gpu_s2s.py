@@ -164,4 +164,5 @@ def test_bf16_mode_agreement_report(eng_bf16, full_sd):
     agree = (amax.cpu().long() == ref.argmax(-1))[valid].float().mean().item()
     xerr = max((xs_g[b, :n] - x_s[b, :n]).abs().max().item() for b, n in enumerate(lens))
     print("bf16 perf mode: x_s max err %.4f, logit max err %.4f, argmax agreement %.3f" % (xerr, lerr, agree))
-    assert agree > 0.7 and lerr < 1.0
+    # measured on MI355X (round 2): x_s 0.028, logits 0.0085, argmax agreement 0.995 -- asserted with a small margin
+    assert agree >= 0.99 and lerr <= 2e-2 and xerr <= 6e-2

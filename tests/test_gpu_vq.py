@@ -97,11 +97,12 @@ def test_roundtrip_c1(eng, golden_dir):
 
 
 def test_bf16_mode_report(eng_bf16, golden_dir):
-    """perf mode is not asserted bit-exact: report index agreement and decode error."""
+    """perf mode is not bit-exact: index agreement and decode error are held at their measured levels."""
     g = _g(golden_dir, "vq_roundtrip_C1.npz")
     idx = eng_bf16.vq_encode(1, torch.from_numpy(g["x"]).cuda(), pe_mode=1)
     agree = (idx.cpu().numpy() == g["idx"]).mean()
     xhat = eng_bf16.vq_decode(1, torch.from_numpy(g["idx"].astype(np.int32)).cuda())
     err = np.abs(xhat.cpu().numpy() - g["xhat"]).max()
     print("bf16 mode: index agreement %.3f, decode max err %.4f" % (agree, err))
-    assert agree > 0.6 and err < 0.2
+    # measured on MI355X (round 2): agreement 0.987, decode error 0.0121 -- asserted with a small margin
+    assert agree >= 0.975 and err <= 0.03
