@@ -1,0 +1,405 @@
+// chain.hip -- XCD-local chain kernels of the autoregressive decoder step (bf16 perf mode, 8 <= B <= 256).
+//
+// Between two attention kernels a decoder layer runs  projection -> residual add -> LayerNorm -> projection
+// (x-transformers Decoder, pre-norm, constructed at reference code/seq2seq_pretrain.py:413-419; one step of
+// AutoregressiveWrapper.generate, :450).  As separate launches those are 3 dependent kernels of 5-8 us each whose
+// cost is fixed overhead, not work (profiles/r01c_*: 43 kernels per step).  Clips are independent, so the batch is
+// split into 8 groups of 32 clips and group g lives entirely on XCD g (block b runs on XCD b % 8: measured,
+// profiles/r02_xcd_probe.txt; verified in the kernel).  Inside a group:
+//   * GEMM phases: M = 32 rows (one 32x32x16 MFMA row block), the N columns are split over the XCD's 32 CUs; a CU
+//     pulls its whole weight slice (and the 32 activation rows) into LDS by LDS-DMA in one burst, the 8 waves split
+//     K and combine through LDS in a fixed order (deterministic).
+//   * row phase: CU i owns clip i of the group: residual add (+ split-K slabs of a preceding chip-wide GEMM), two
+//     exact LayerNorm passes, bf16 row for the next GEMM.
+//   * hand-offs stay inside the XCD's coherent L2: plain stores, s_waitcnt vmcnt(0), an arrival on a per-XCD
+//     counter (0.9 us per barrier measured vs 4-7 us for a chip-wide one), readers use sc1 loads (L1 bypass).
+// The weights of a phase are read once per XCD (8x the chip-wide GEMM's fabric traffic, measured 7 TB/s), which is why
+// only the small projections (attention out / cross-q / logits: 0.6-1.8 MB each) take this path and the feed-forward
+// and fused-qkv GEMMs (5-11 MB) stay chip-wide launches.
+#include "common.hpp"
+
+namespace dimx {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kGroupCUs = 32;   // CUs (= blocks) per XCD
+constexpr int kGroupRows = 32;  // clips per group = one MFMA row block
+constexpr int AUX_PLAIN = 0, AUX_SC1 = 16;
+constexpr size_t kMaxDynLds = 160 * 1024 - 64;  // the kernel also has a few bytes of static LDS
+
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+__device__ __forceinline__ unsigned ld_sc1_u32(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1_f32(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + (((kc ^ (row >> 1)) & 7) << 4); }
+
+// Barrier among the 32 blocks of one XCD.  Every thread drains its own stores (they are then in the XCD's L2), the
+// block meets, lane 0 arrives on the group's monotonic counter and polls it with L1-bypassing loads.  Bounded: a
+// placement that is not one-block-per-CU would otherwise hang the GPU.
+__device__ __forceinline__ void xcd_barrier(unsigned* ctr, unsigned target, unsigned* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((int)(ld_sc1_u32(ctr) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if (spins > (1u << 20) || ((spins & 1023u) == 0 && (ld_sc1_u32(err) & 2u))) {  // bounded; dead once one timed out
+                atomicOr(err, 2u);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// rows [r_begin, r_begin + rows_pad) (clamped to r_last) x K of a row-major bf16 matrix -> LDS as K/64 tiles of
+// rows_pad x 128 B; chunk c of a row sits at slot c ^ ((row >> 1) & 7).  Pieces of 8 rows x 128 B (1 KiB, one wave-wide
+// global_load_lds) are dealt round-robin to the 8 waves.
+template <int AUX, int NW>
+__device__ __forceinline__ void issue_panel_nw(const bf16* base, int ld, int r_begin, int r_last, int rows_pad, int nkt,
+                                               unsigned char* dst, int wave, int lane) {
+    const int groups = rows_pad >> 3;
+    const int pieces = nkt * groups;
+    for (int p = wave; p < pieces; p += NW) {
+        const int kt = p / groups, gr = p - kt * groups;
+        const int row = gr * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int r = r_begin + row;
+        r = r <= r_last ? r : r_last;
+        const bf16* src = base + (size_t)r * ld + kt * 64 + c * 8;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + (size_t)p * 1024), 16, 0, AUX);
+    }
+}
+template <int AUX>
+__device__ __forceinline__ void issue_panel(const bf16* base, int ld, int r_begin, int r_last, int rows_pad, int nkt,
+                                            unsigned char* dst, int wave, int lane) {
+    issue_panel_nw<AUX, kWaves>(base, ld, r_begin, r_last, rows_pad, nkt, dst, wave, lane);
+}
+template <int AUX>
+__device__ __forceinline__ void issue_panel4(const bf16* base, int ld, int r_begin, int r_last, int rows_pad, int nkt,
+                                             unsigned char* dst, int wave, int lane) {
+    issue_panel_nw<AUX, 4>(base, ld, r_begin, r_last, rows_pad, nkt, dst, wave, lane);
+}
+
+// acc[j] += A(32 x K) . W_j(32 x K)^T over the k-tiles kt == wave (mod 8)
+template <int NCB>
+__device__ __forceinline__ void mfma_panel(const unsigned char* Apan, const unsigned char* Wpan, int nkt, int wrows_pad,
+                                           f32x16_t (&acc)[NCB], int wave, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int kt = wave; kt < nkt; kt += kWaves) {
+        const unsigned char* At = Apan + (size_t)kt * (kGroupRows * 128);
+        const unsigned char* Wt = Wpan + (size_t)kt * wrows_pad * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kc = 2 * ks + half;
+            const uint4 fa = *(const uint4*)(At + lds_off(l31, kc));
+#pragma unroll
+            for (int j = 0; j < NCB; ++j) {
+                const uint4 fw = *(const uint4*)(Wt + lds_off(j * 32 + l31, kc));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                                 __builtin_bit_cast(bf16x8_t, fw), acc[j], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// the 8 waves' partial 32 x (NCB*32) tiles -> LDS -> summed in wave order -> out[row0 + m][n0 + col] (valid part)
+template <int NCB>
+__device__ __forceinline__ void reduce_store(const f32x16_t (&acc)[NCB], float* red, float* out, long ld_out, int row0,
+                                             int nrows, int n0, int ncols, int wave, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+    __syncthreads();  // every wave is done with the panels the scratch aliases
+#pragma unroll
+    for (int j = 0; j < NCB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[((wave * NCB + j) * 32 + m) * 32 + l31] = acc[j][r];
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NCB * 1024; e += kThreads) {
+        const int j = e >> 10, m = (e >> 5) & 31, n = e & 31;
+        float v = red[((0 * NCB + j) * 32 + m) * 32 + n];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[((w * NCB + j) * 32 + m) * 32 + n];
+        const int col = j * 32 + n;
+        if (col < ncols && m < nrows) out[(size_t)(row0 + m) * ld_out + n0 + col] = v;
+    }
+}
+
+// block barrier that orders LDS traffic only: it must NOT drain vmcnt (the loader waves have weight DMAs in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+}  // namespace
+
+// HAS_G1: projection of the attention output first; HAS_G2: projection of the normalised row last.
+// NCB1 / NCB2: 32-column blocks of a CU's slice of the two projections.
+// Wave roles after the first group barrier: waves 0-3 normalise the CU's row, waves 4-7 stream the second
+// projection's weight slice into LDS (vmcnt is per wave, so the row's loads do not queue behind that burst).
+template <bool HAS_G1, bool HAS_G2, int NCB1, int NCB2>
+__global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ float sm_s[4], sm_q[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // The group IS the XCD the block really runs on: consecutive block ids go to consecutive XCDs, but the first block of
+    // a launch does not always land on XCD 0 (the rotation continues from the previous dispatch: observed after kernels
+    // whose grid is not a multiple of 8).  Under any rotation the blocks of one XCD have distinct blockIdx >> 3, which
+    // makes (xcc, blockIdx >> 3) a bijection onto (group, CU slot); that is checked, not assumed (seen[] below).
+    const int g = (int)(xcc_id() & 7), li = blockIdx.x >> 3;
+    const unsigned stamp = (unsigned)(*a.step) + 1u;
+    unsigned seen_old = 0;
+    if (tid == 0) seen_old = atomicExch(a.seen + g * kGroupCUs + li, stamp);
+    const int row0 = g * kGroupRows;
+    const int nrows = a.B - row0 < kGroupRows ? a.B - row0 : kGroupRows;
+    if (nrows <= 0) {  // the whole group leaves (all of its blocks take this branch)
+        if (tid == 0 && seen_old == stamp) atomicOr(a.err, 1u);
+        return;
+    }
+    const int r_last = row0 + nrows - 1;
+    unsigned* ctr = a.counters + 16 * g;
+    unsigned target = (unsigned)(*a.step) * (unsigned)(a.nbar * kGroupCUs);
+
+    // ---- row waves: everything of the CU's own row that is already there goes into registers now (x, gamma, the
+    // split-K slabs of a preceding chip-wide GEMM, all loads in flight together); only xr has to wait for barrier 1
+    const bool own = li < nrows && wave < 4;
+    const int row = row0 + (li < nrows ? li : 0), C = a.C;
+    float* xrow = a.x + (size_t)row * C;
+    float v[6], gm[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] = 0.f;
+        gm[i] = 0.f;
+    }
+    if (own) {
+        float t[8][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = tid + i * 256;
+            if (c < C) {
+                v[i] = xrow[c];
+                gm[i] = a.gamma[c];
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int c = tid + i * 256;
+                t[sl][i] = (sl < a.nslab && c < C) ? a.slabs[(size_t)sl * a.slab_stride + (size_t)row * C + c] : 0.f;
+            }
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl)  // slab order = the order the one-kernel-per-op step adds them in
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] += t[sl][i];
+    }
+
+    // ---- burst 1 + first projection: partial[32 rows][this CU's columns] -> xr
+    if (HAS_G1) {
+        issue_panel<AUX_PLAIN>((const bf16*)a.A1, a.lda1, row0, r_last, kGroupRows, a.g1.nkt, lds + a.offA1, wave, lane);
+        const int n0 = li * a.g1.cols;
+        issue_panel<AUX_PLAIN>((const bf16*)a.g1.W, a.g1.ldw, n0, n0 + a.g1.cols - 1, a.g1.rows_pad, a.g1.nkt,
+                               lds + a.offW1, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16_t acc[NCB1];
+#pragma unroll
+        for (int j = 0; j < NCB1; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        mfma_panel<NCB1>(lds + a.offA1, lds + a.offW1, a.g1.nkt, a.g1.rows_pad, acc, wave, lane);
+        reduce_store<NCB1>(acc, (float*)(lds + a.offRed1), a.xr, a.C, row0, nrows, n0, a.g1.cols, wave, lane);
+        target += kGroupCUs;
+        xcd_barrier(ctr, target, a.err);
+    }
+
+    // ---- loader waves: the second projection's weight slice (independent of everything computed here)
+    if (HAS_G2 && wave >= 4) {
+        const int n0 = li * a.g2.cols;
+        issue_panel4<AUX_PLAIN>((const bf16*)a.g2.W, a.g2.ldw, n0, n0 + a.g2.cols - 1, a.g2.rows_pad, a.g2.nkt,
+                                lds + a.offW2, wave - 4, lane);
+    }
+    // ---- row waves: residual add, two exact LayerNorm passes
+    float s = 0.f;
+    if (own) {
+        if (HAS_G1) {
+            float xr[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int c = tid + i * 256;
+                xr[i] = c < C ? ld_sc1_f32(a.xr + (size_t)row * C + c) : 0.f;  // written by the other CUs of the XCD
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] += xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s += v[i];
+        s = wave_sum(s);
+        if (lane == 0) sm_s[wave] = s;
+    }
+    lds_barrier();
+    float mean = 0.f, q = 0.f;
+    if (own) {
+        mean = (sm_s[0] + sm_s[1] + sm_s[2] + sm_s[3]) * (1.0f / C);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = tid + i * 256;
+            const float d = c < C ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        q = wave_sum(q);
+        if (lane == 0) sm_q[wave] = q;
+    }
+    lds_barrier();
+    if (own) {
+        const float rstd = rsqrtf((sm_q[0] + sm_q[1] + sm_q[2] + sm_q[3]) * (1.0f / C) + 1e-5f);
+        bf16* yrow = (bf16*)a.y + (size_t)row * C;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = tid + i * 256;
+            if (c < C) {
+                if (HAS_G1 || a.nslab > 0) xrow[c] = v[i];
+                yrow[c].x = f32_to_bf16((v[i] - mean) * rstd * gm[i]);
+            }
+        }
+    }
+    if (tid == 0 && seen_old == stamp) atomicOr(a.err, 1u);  // two blocks claimed the same (XCD, slot): not a bijection
+    if (!HAS_G2) return;
+    // group barrier 2: only the row waves have stores to drain; the loader waves keep their DMAs in flight
+    target += kGroupCUs;
+    if (wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((int)(ld_sc1_u32(ctr) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if (spins > (1u << 20) || ((spins & 1023u) == 0 && (ld_sc1_u32(a.err) & 2u))) {
+                atomicOr(a.err, 2u);
+                break;
+            }
+        }
+    }
+    lds_barrier();
+
+    // ---- second projection on the normalised rows of the whole group (written by 32 CUs of this XCD: sc1)
+    {
+        issue_panel<AUX_SC1>((const bf16*)a.y, a.C, row0, r_last, kGroupRows, a.g2.nkt, lds + a.offA2, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows, and on waves 4-7 the weight slice
+        __syncthreads();
+        f32x16_t acc[NCB2];
+#pragma unroll
+        for (int j = 0; j < NCB2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        mfma_panel<NCB2>(lds + a.offA2, lds + a.offW2, a.g2.nkt, a.g2.rows_pad, acc, wave, lane);
+        const int n0 = li * a.g2.cols;
+        reduce_store<NCB2>(acc, (float*)(lds + a.offRed2), a.out2, a.ld_out2, row0, nrows, n0, a.g2.cols, wave, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static void desc_fill(ChainGemmDesc& d) {
+    d.cols = d.N / kGroupCUs;
+    d.rows_pad = (d.cols + 7) / 8 * 8;
+    d.ncb = (d.cols + 31) / 32;
+    d.nkt = d.K / 64;
+}
+
+bool chain_supported(const ChainArgs& a0, int cu_count) {
+    ChainArgs a = a0;
+    if (cu_count != 8 * kGroupCUs) return false;  // one block per CU, 32 CUs per XCD
+    if (a.B < 1 || a.B > 8 * kGroupRows || a.C > 3 * kThreads || a.C % 64 != 0) return false;
+    for (ChainGemmDesc* d : {&a.g1, &a.g2}) {
+        if (!d->W) continue;
+        if (d->N % kGroupCUs != 0 || d->K % 64 != 0 || d->ldw % 8 != 0) return false;
+        desc_fill(*d);
+        if (d->ncb < 1 || d->ncb > 2) return false;
+    }
+    if (a.g1.W && (a.g1.N != a.C || a.lda1 % 8 != 0)) return false;
+    if (a.g2.W && a.g2.K != a.C) return false;
+    return chain_plan(a) <= kMaxDynLds;
+}
+
+// LDS plan (bytes); returns the dynamic LDS size.  Burst 1 = {A1, W1}; its reduction scratch aliases them once the
+// MFMAs are done; A2 (the normalised rows) reuses the front, W2 sits behind A2.
+size_t chain_plan(ChainArgs& a) {
+    size_t front = 0, total = 0;
+    if (a.g1.W) {
+        desc_fill(a.g1);
+        a.offA1 = 0;
+        a.offW1 = a.g1.nkt * kGroupRows * 128;
+        const size_t w1 = (size_t)a.g1.nkt * a.g1.rows_pad * 128 + 4096;  // + read slack of the padded column block
+        a.offRed1 = 0;
+        const size_t red1 = (size_t)kWaves * a.g1.ncb * 4096;
+        front = a.offW1 + w1;
+        front = front > red1 ? front : red1;
+        total = front;
+    }
+    if (a.g2.W) {
+        desc_fill(a.g2);
+        const size_t a2 = (size_t)a.g2.nkt * kGroupRows * 128;
+        const size_t red2 = (size_t)kWaves * a.g2.ncb * 4096;
+        // W2 is issued after the first group barrier (burst 1 and its scratch are dead by then) and must only stay
+        // clear of A2, which is loaded in front of it later; scratch 2 aliases A2 / W2 once the MFMAs are done
+        const size_t w2_at = a2;
+        a.offA2 = 0;
+        a.offRed2 = 0;
+        a.offW2 = (int)w2_at;
+        size_t end2 = w2_at + (size_t)a.g2.nkt * a.g2.rows_pad * 128 + 4096;
+        end2 = end2 > red2 ? end2 : red2;
+        total = total > end2 ? total : end2;
+    }
+    return total;
+}
+
+int launch_chain(const ChainArgs& a0, hipStream_t s) {
+    ChainArgs a = a0;
+    DIMX_REQUIRE(a.x && a.y && a.gamma && a.counters && a.step && a.err, DIMX_ERR_ARG, "chain: null operand");
+    DIMX_REQUIRE(!a.g1.W || (a.A1 && a.xr), DIMX_ERR_ARG, "chain: first projection needs A1 and xr");
+    DIMX_REQUIRE(!a.g2.W || a.out2, DIMX_ERR_ARG, "chain: second projection needs out2");
+    DIMX_REQUIRE(a.nslab == 0 || a.slabs, DIMX_ERR_ARG, "chain: slabs missing");
+    const size_t lds = chain_plan(a);
+    DIMX_REQUIRE(lds <= kMaxDynLds, DIMX_ERR_ARG, "chain: LDS plan %zu bytes", lds);
+    a.nbar = (a.g1.W ? 1 : 0) + (a.g2.W ? 1 : 0);
+    dim3 grid(8 * kGroupCUs), block(kThreads);
+#define CH(G1, G2, N1, N2)                                                                                      \
+    do {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)xcd_chain_kernel<G1, G2, N1, N2>,                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);                      \
+        hipLaunchKernelGGL((xcd_chain_kernel<G1, G2, N1, N2>), grid, block, lds, s, a);                         \
+    } while (0)
+    const int n1 = a.g1.W ? a.g1.ncb : 1, n2 = a.g2.W ? a.g2.ncb : 1;
+    if (a.g1.W && a.g2.W) {
+        if (n1 == 1 && n2 == 1) CH(true, true, 1, 1);
+        else if (n1 == 2 && n2 == 1) CH(true, true, 2, 1);
+        else if (n1 == 1 && n2 == 2) CH(true, true, 1, 2);
+        else CH(true, true, 2, 2);
+    } else if (a.g1.W) {
+        if (n1 == 1) CH(true, false, 1, 1);
+        else CH(true, false, 2, 1);
+    } else if (a.g2.W) {
+        if (n2 == 1) CH(false, true, 1, 1);
+        else CH(false, true, 1, 2);
+    } else {
+        CH(false, false, 1, 1);
+    }
+#undef CH
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+}  // namespace dimx

@@ -227,6 +227,44 @@ int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s);
 int launch_vq_argmin(const float* z, int N, const float* Et /*[128][512]*/, const float* ee /*[512]*/,
                      int32_t* idx, float* best_d, float* margin, hipStream_t s);
 
+// ---------------------------------------------------------------- XCD-local chain kernels (chain.hip)
+struct ChainGemmDesc {
+    const void* W;  // [N][ldw] bf16, rows = output columns
+    int N, K, ldw;
+    int cols, rows_pad, ncb, nkt;  // filled by the planner: columns per CU, 8-row padded, 32-column blocks, k-tiles
+};
+struct ChainArgs {
+    int B;  // rows (clips), <= 256: group g = rows [32g, 32g + 32) lives on XCD g
+    // first projection (optional, g1.W != nullptr): A1 [B, lda1] bf16 . W1^T -> xr [B, C] f32 (C = g1.N)
+    ChainGemmDesc g1;
+    const void* A1;
+    int lda1;
+    float* xr;
+    // row phase: x [B, C] f32 += xr (+ slabs[0..nslab) of a preceding chip-wide split-K GEMM); y = LayerNorm(x) * gamma
+    float* x;
+    int C;
+    const float* slabs;
+    int nslab;
+    long slab_stride;
+    void* y;  // bf16 [B, C]
+    const float* gamma;
+    // second projection (optional): y . W2^T -> out2 [B, ld_out2] f32 (K = C)
+    ChainGemmDesc g2;
+    float* out2;
+    int ld_out2;
+    // synchronisation: this launch site's per-XCD arrival counters [8][16] (zeroed once per generate call), the
+    // device step counter (epoch of the monotonic counters), error flags (bit 0 placement, bit 1 barrier timeout)
+    unsigned* counters;
+    unsigned* seen;  // [8][32] this launch site's (XCD, CU slot) claim stamps (zeroed with the counters)
+    const int32_t* step;
+    unsigned* err;
+    int nbar;                                                // set by the launcher
+    int offA1, offW1, offRed1, offA2, offW2, offRed2;        // LDS plan, set by the launcher
+};
+size_t chain_plan(ChainArgs& a);
+bool chain_supported(const ChainArgs& a, int cu_count);
+int launch_chain(const ChainArgs& a, hipStream_t s);
+
 // elementwise helpers (elementwise.hip)
 int launch_cast_pad(int out_dtype, const float* x, int ldx, const float* coladd, void* y, int ldy, int M, int K,
                     hipStream_t s, const uint8_t* zero_rows = nullptr);

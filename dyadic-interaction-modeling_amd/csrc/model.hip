@@ -693,6 +693,12 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     for (const auto& k : all_keys(d)) c->required.push_back(k.name);
     const char* ng = getenv("DIMX_NO_GRAPH");
     c->use_graph = (ng && ng[0] == '1') ? 0 : 1;
+    const char* nc = getenv("DIMX_NO_CHAIN");
+    c->use_chain = (nc && nc[0] == '1') ? 0 : 1;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess) c->cu_count = cus;
+    }
     const char* gg = getenv("DIMX_GEN_GROUPS");
     if (gg && atoi(gg) >= 1 && atoi(gg) <= dimx_ctx::kMaxGroups) c->gen_groups = atoi(gg);
     *h = c;
@@ -709,6 +715,9 @@ int dimx_destroy(dimx_handle h) {
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->chain_err_ev) (void)hipEventDestroy(h->chain_err_ev);
+    if (h->chain_err_dev) (void)hipFree(h->chain_err_dev);
+    if (h->chain_err_host) (void)hipHostFree(h->chain_err_host);
     free_packed(h);
     delete h;
     return DIMX_OK;
@@ -797,7 +806,10 @@ struct GenScratch {
     float *qkv, *qc, *xr;  // f32 split-K slabs [kMaxSlabs][B, N] of the qkv / cross-q / residual projections
     long st_qkv, st_qc, st_xr, st_lg;  // slab strides (elements)
     int32_t* step;
+    unsigned* chain_ctr;  // [kChainSites][8][16] per-XCD arrival counters of the chain launch sites
 };
+constexpr int kChainSites = 32;
+constexpr int kChainSiteWords = 8 * 16 + 8 * 32;  // arrival counters [8][16] + claim stamps [8][32]
 
 static void plan_persist(const dimx_ctx* c, Arena& ar, int B, int T, CtxPersist& p) {
     const size_t es = es_of(c);
@@ -862,6 +874,7 @@ static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) 
     s.f = ar.take((size_t)B * D * c->decg.ff_mult * es);
     s.logits = (float*)ar.take((size_t)kMaxSlabs * B * c->decg.num_tokens * 4);
     s.step = (int32_t*)ar.take(64 * dimx_ctx::kMaxGroups);  // one counter per clip group, 64 B apart
+    s.chain_ctr = (unsigned*)ar.take((size_t)kChainSites * kChainSiteWords * 4);
 }
 
 // SLM.forward_encoder: the encoder scratch is sized for the joint 2T pass; xs / xl keep the two first-stage
@@ -980,6 +993,17 @@ static int check_common(dimx_handle h, int B, int T, void* ws, size_t ws_bytes, 
     const size_t need_bytes = workspace_bytes(h, B, T, S);
     DIMX_REQUIRE(ws_bytes >= need_bytes, DIMX_ERR_WORKSPACE, "workspace %zu < required %zu", ws_bytes, need_bytes);
     DIMX_HIP(hipSetDevice(h->device));
+    if (h->chain_err_host && h->chain_err_ev && hipEventQuery(h->chain_err_ev) == hipSuccess && *h->chain_err_host) {
+        const unsigned e = *h->chain_err_host;
+        *h->chain_err_host = 0;
+        (void)hipMemset(h->chain_err_dev, 0, 64);
+        h->use_chain = 0;  // fall back to the one-kernel-per-op step from now on
+        DIMX_REQUIRE(false, DIMX_ERR_STATE,
+                     "the previous generate call's XCD-local chain kernels reported %s%s: its tokens are not trustworthy "
+                     "(chain path disabled for this handle; set DIMX_NO_CHAIN=1 to avoid it from the start)"
+                     ,
+                     (e & 1) ? "two blocks on one (XCD, CU slot) " : "", (e & 2) ? "a group-barrier timeout" : "");
+    }
     DIMX_TRY(ensure_packed(h, need));
     return DIMX_OK;
 }
@@ -1398,6 +1422,26 @@ int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, c
 
 namespace dimx {
 
+// The chain kernels run when: bf16 operands, one sample per clip, a single clip group, <= 256 rows, a 256-CU device on
+// which the placement probe passed, and every launch site's LDS plan fits.
+static bool gen_use_chain(dimx_handle h, int B, int S, int grp) {
+    if (!h->use_chain || h->at != DIMX_BF16 || S != 1 || grp != 0 || h->gen_groups > 1 || !h->chain_err_dev) return false;
+    const DecGeom& dg = h->decg;
+    ChainArgs c;
+    memset(&c, 0, sizeof(c));
+    c.B = B;
+    c.C = dg.dim;
+    const XAttn& sa = h->dec.self_[0];
+    const XAttn& ca = h->dec.cross[0];
+    c.g1.W = sa.out.w; c.g1.N = sa.out.N; c.g1.K = sa.out.K; c.g1.ldw = sa.out.Kp;
+    c.lda1 = dg.heads * dg.dim_head;
+    c.g2.W = ca.qkv.w; c.g2.N = ca.qkv.N; c.g2.K = ca.qkv.K; c.g2.ldw = ca.qkv.Kp;
+    if (!chain_supported(c, h->cu_count)) return false;
+    c.g2.W = h->dec.logits.w; c.g2.N = h->dec.logits.N; c.g2.K = h->dec.logits.K; c.g2.ldw = h->dec.logits.Kp;
+    c.g1.W = nullptr;
+    return chain_supported(c, h->cu_count) && 3 * dg.depth + 1 <= kChainSites;
+}
+
 // one decoder step for the clip group [row0, row0 + B) of a batch of Btot clips:
 // x = emb(token) -> 4 x {self, cross, ff} -> logits -> sample -> step += 1
 static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, const int32_t* start,
@@ -1446,6 +1490,43 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         g.force_splitk = *nsl;
         return launch_gemm(g, st);
     };
+    // XCD-local chain kernels (chain.hip) replace {projection, residual + LayerNorm, projection} triples by one launch
+    const bool chain = gen_use_chain(h, B, S, grp);
+    auto chain_site = [&](int site, const void* A1, int lda1, const Linear* W1, int nslab, const float* gamma,
+                          const Linear* W2, float* out2, int ld_out2) -> int {
+        ChainArgs c;
+        memset(&c, 0, sizeof(c));
+        c.B = B;
+        if (W1) {
+            c.g1.W = W1->w;
+            c.g1.N = W1->N;
+            c.g1.K = W1->K;
+            c.g1.ldw = W1->Kp;
+            c.A1 = A1;
+            c.lda1 = lda1;
+            c.xr = s.xr;
+        }
+        c.x = s.x;
+        c.C = DD;
+        c.slabs = nslab ? s.xr : nullptr;
+        c.nslab = nslab;
+        c.slab_stride = s0.st_xr;
+        c.y = s.y;
+        c.gamma = gamma;
+        if (W2) {
+            c.g2.W = W2->w;
+            c.g2.N = W2->N;
+            c.g2.K = W2->K;
+            c.g2.ldw = W2->Kp;
+            c.out2 = out2;
+            c.ld_out2 = ld_out2;
+        }
+        c.counters = s0.chain_ctr + (size_t)site * kChainSiteWords;
+        c.seen = c.counters + 8 * 16;
+        c.step = s.step;
+        c.err = h->chain_err_dev;
+        return launch_chain(c, st);
+    };
     int pending = 0;  // slabs of the previous residual projection not yet folded into x
     for (int l = 0; l < dg.depth; ++l) {
         GemmArgs g;
@@ -1473,10 +1554,15 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         a.step = s.step;
         a.scale = scale;
         DIMX_TRY(launch_decode_attn(a, st));
-        DIMX_TRY(slab_gemm(s.o, inner, h->dec.self_[l].out, s.xr, s0.st_xr, &pending));
-
-        DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.cross[l].ln_g, B, DD, st));
-        DIMX_TRY(slab_gemm(s.y, DD, h->dec.cross[l].qkv, s.qc, s0.st_qc, &ns));
+        if (chain) {  // self out-projection -> x += . -> LayerNorm -> cross q-projection
+            DIMX_TRY(chain_site(3 * l, s.o, inner, &h->dec.self_[l].out, 0, h->dec.cross[l].ln_g, &h->dec.cross[l].qkv,
+                                s.qc, inner));
+            ns = 1;
+        } else {
+            DIMX_TRY(slab_gemm(s.o, inner, h->dec.self_[l].out, s.xr, s0.st_xr, &pending));
+            DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.cross[l].ln_g, B, DD, st));
+            DIMX_TRY(slab_gemm(s.y, DD, h->dec.cross[l].qkv, s.qc, s0.st_qc, &ns));
+        }
         memset(&a, 0, sizeof(a));
         a.dtype = h->at;
         a.q = s.qc;
@@ -1497,9 +1583,12 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         a.kmask_ld = T;
         a.scale = scale;
         DIMX_TRY(launch_decode_attn(a, st));
-        DIMX_TRY(slab_gemm(s.o, inner, h->dec.cross[l].out, s.xr, s0.st_xr, &pending));
-
-        DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.ff[l].ln_g, B, DD, st));
+        if (chain) {  // cross out-projection -> x += . -> LayerNorm (feed-forward input)
+            DIMX_TRY(chain_site(3 * l + 1, s.o, inner, &h->dec.cross[l].out, 0, h->dec.ff[l].ln_g, nullptr, nullptr, 0));
+        } else {
+            DIMX_TRY(slab_gemm(s.o, inner, h->dec.cross[l].out, s.xr, s0.st_xr, &pending));
+            DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.ff[l].ln_g, B, DD, st));
+        }
         gemm_lin(h, s.y, DD, h->dec.ff[l].f1, B, g);
         g.out_dtype = h->at;
         g.act = ACT_GELU_ERF;
@@ -1507,9 +1596,14 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         DIMX_TRY(launch_gemm(g, st));
         DIMX_TRY(slab_gemm(s.f, DD * dg.ff_mult, h->dec.ff[l].f2, s.xr, s0.st_xr, &pending));
     }
-    DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.final_g, B, DD, st));
     int nlg = 0;
-    DIMX_TRY(slab_gemm(s.y, DD, h->dec.logits, s.logits, s0.st_lg, &nlg));
+    if (chain) {  // x += feed-forward slabs -> final LayerNorm -> logits
+        DIMX_TRY(chain_site(3 * dg.depth, nullptr, 0, nullptr, pending, h->dec.final_g, &h->dec.logits, s.logits, V));
+        nlg = 1;
+    } else {
+        DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.final_g, B, DD, st));
+        DIMX_TRY(slab_gemm(s.y, DD, h->dec.logits, s.logits, s0.st_lg, &nlg));
+    }
     DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, nlg, s0.st_lg,
                            logits_out, n, row0, Btot, h->dec.tok_emb, DD, s.x, s.step, (unsigned*)(s.step + 8), st, pos,
                            pos_scale, n, s.step + 2));
@@ -1538,6 +1632,14 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     plan_gen(h, ar, R, T, s);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "generate: workspace overflow");
     const int n = gen_steps(h, T);
+    if (h->use_chain && h->at == DIMX_BF16 && !h->chain_err_dev) {
+        DIMX_HIP(hipMalloc((void**)&h->chain_err_dev, 64));
+        DIMX_HIP(hipMemset(h->chain_err_dev, 0, 64));
+        DIMX_HIP(hipHostMalloc((void**)&h->chain_err_host, 64, hipHostMallocDefault));
+        *h->chain_err_host = 0;
+        DIMX_HIP(hipEventCreateWithFlags(&h->chain_err_ev, hipEventDisableTiming));
+    }
+    DIMX_HIP(hipMemsetAsync(s.chain_ctr, 0, (size_t)kChainSites * kChainSiteWords * 4, st));
     // step / done counters = 0; temperature, seed and the sampler's global row window go to device memory so that
     // the captured step graph is independent of them
     DIMX_TRY(launch_gen_params(s.step, dimx_ctx::kMaxGroups, temperature, seed, h->shard_row_off * S,
@@ -1574,7 +1676,7 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
                                   exp_noise, seed, tokens, logits_out, gs[g], false, S));
     } else {
         // greedy vs sampling is decided from the device-side parameters; only shapes and pointers key the graph
-        GraphKey key{ws, B, T, top_k, 0.f, exp_noise, 0, start, ctx_mask, tokens, logits_out, G * 100 + S};
+        GraphKey key{ws, B, T, top_k, 0.f, exp_noise, 0, start, ctx_mask, tokens, logits_out, G * 100 + S + (h->use_chain ? 1000 : 0)};
         if (!(h->graph_valid && h->graph_key == key)) {
             h->graph_valid = false;
             if (!h->cap_stream) DIMX_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -1608,6 +1710,10 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
             DIMX_HIP(hipEventRecord(h->ev_join[g], gs[g]));
             DIMX_HIP(hipStreamWaitEvent(st, h->ev_join[g], 0));
         }
+    }
+    if (h->chain_err_dev) {  // looked at by the next call on this handle (check_common), never waited for here
+        DIMX_HIP(hipMemcpyAsync(h->chain_err_host, h->chain_err_dev, 4, hipMemcpyDeviceToHost, st));
+        DIMX_HIP(hipEventRecord(h->chain_err_ev, st));
     }
     return DIMX_OK;
 }
@@ -1729,6 +1835,41 @@ int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, v
 int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
                                 const float* gamma, int M, int C, void* stream) {
     return launch_add_slabs_layernorm(out_dtype, x, slabs, nslab, slab_stride, y, gamma, M, C, (hipStream_t)stream);
+}
+
+int dimx_op_chain(const void* A1, int K1, const void* W1, float* x, const float* slabs, int nslab, const float* gamma,
+                  void* y, const void* W2, int N2, float* out2, int B, int C, void* scratch, void* stream) {
+    DIMX_REQUIRE(scratch && x && y && gamma, DIMX_ERR_ARG, "op_chain: null argument");
+    int dev = 0, cus = 0;
+    DIMX_HIP(hipGetDevice(&dev));
+    DIMX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    ChainArgs c;
+    memset(&c, 0, sizeof(c));
+    unsigned* u = (unsigned*)scratch;  // [0..127] counters, [128] step, [129] error flags, [256..511] claim stamps, then xr
+    c.B = B;
+    c.C = C;
+    if (W1) {
+        c.g1.W = W1; c.g1.N = C; c.g1.K = K1; c.g1.ldw = K1;
+        c.A1 = A1; c.lda1 = K1;
+        c.xr = (float*)(u + 512);
+    }
+    c.x = x;
+    c.slabs = slabs;
+    c.nslab = nslab;
+    c.slab_stride = (long)B * C;
+    c.y = y;
+    c.gamma = gamma;
+    if (W2) {
+        c.g2.W = W2; c.g2.N = N2; c.g2.K = C; c.g2.ldw = C;
+        c.out2 = out2; c.ld_out2 = N2;
+    }
+    c.counters = u;
+    c.seen = u + 256;
+    c.step = (const int32_t*)(u + 128);
+    c.err = u + 129;
+    DIMX_REQUIRE(chain_supported(c, cus), DIMX_ERR_ARG, "op_chain: shape not supported on this device (%d CUs)", cus);
+    DIMX_HIP(hipMemsetAsync(u, 0, 512 * 4, (hipStream_t)stream));
+    return launch_chain(c, (hipStream_t)stream);
 }
 
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise, uint64_t seed,

@@ -142,6 +142,12 @@ struct dimx_ctx {
     dimx::GraphKey graph_key{};
     bool graph_valid = false;
     int use_graph = 1;
+    // XCD-local chain kernels of the decode step (chain.hip): bf16 mode, one sample per clip, 256-CU device
+    int use_chain = 1;                  // DIMX_NO_CHAIN=1 keeps the one-kernel-per-op step
+    int cu_count = 0;
+    unsigned* chain_err_dev = nullptr;  // bit 0: two blocks claimed one (XCD, CU slot), bit 1: a group barrier timed out
+    unsigned* chain_err_host = nullptr; // pinned copy, refreshed at the end of every generate call
+    hipEvent_t chain_err_ev = nullptr;
     // sampler generator window of a sharded batch (dimx_set_shard): this handle generates clips
     // [shard_row_off, shard_row_off + B) of shard_rows_total (0 = the call's own B)
     int shard_row_off = 0, shard_rows_total = 0;

@@ -327,6 +327,29 @@ def op_sample(logits, top_k=52, temperature=1.0, noise=None, seed=0, step=0):
     return tok
 
 
+def op_chain(x, gamma, a1=None, w1=None, slabs=None, w2=None):
+    """One XCD-local chain launch (csrc/chain.hip): x [B,C] f32 is updated in place; returns (y bf16 [B,C],
+    out2 f32 [B,N2] or None).  a1 [B,K1] / w1 [C,K1] / w2 [N2,C] are converted to bf16."""
+    lib = L.load()
+    dev = x.device
+    B, C = x.shape
+    bf = lambda t: None if t is None else t.to(torch.bfloat16).contiguous()
+    a1, w1, w2 = bf(a1), bf(w1), bf(w2)
+    y = torch.empty(B, C, dtype=torch.bfloat16, device=dev)
+    out2 = torch.empty(B, w2.shape[0], dtype=torch.float32, device=dev) if w2 is not None else None
+    scratch = torch.zeros(512 + B * C, dtype=torch.int32, device=dev)
+    nslab = 0 if slabs is None else slabs.shape[0]
+    L.check(lib.dimx_op_chain(L.ptr(a1), a1.shape[1] if a1 is not None else 0, L.ptr(w1), L.ptr(x),
+                              L.ptr(slabs.contiguous()) if slabs is not None else None, nslab, L.ptr(gamma), L.ptr(y),
+                              L.ptr(w2), w2.shape[0] if w2 is not None else 0, L.ptr(out2), B, C, L.ptr(scratch),
+                              L.stream_ptr(dev)), "dimx_op_chain")
+    torch.cuda.synchronize(dev)
+    flags = int(scratch[129].item())
+    if flags:
+        raise L.DimxError("chain kernel error flags 0x%x (1 = (XCD, slot) claimed twice, 2 = group barrier timeout)" % flags)
+    return y, out2
+
+
 def op_decode_attn(q, kcache, vcache, n_keys, scale, kmask=None, nsplit=0):
     """q [B,H*64]; kcache/vcache [B,H,Tmax,64] (f32 or bf16) -> [B,H*64]."""
     lib = L.load()

@@ -233,6 +233,14 @@ int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, v
 /* Decode-step residual + pre-norm: x[M,C] += sum_s slabs[s] (fixed order), y = LayerNorm(x) * gamma (no bias). */
 int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
                                 const float* gamma, int M, int C, void* stream);
+/* One XCD-local chain launch of the decode step (csrc/chain.hip; bf16 only, B <= 256, 256-CU device):
+ *   [W1 != NULL]  xr = A1[B,K1] . W1[C,K1]^T ;   x[B,C] += xr + sum_s slabs[s][B,C] ;   y = bf16(LayerNorm(x) * gamma) ;
+ *   [W2 != NULL]  out2[B,N2] = y . W2[N2,C]^T   (f32).
+ * A1 / W1 / W2 / y are bf16, x / slabs / gamma / out2 f32.  scratch: >= 2048 + B*C*4 bytes of device memory; on return
+ * (after the stream has drained) ((uint32_t*)scratch)[129] holds the kernel's error flags (0 = ok, bit 0 = two blocks
+ * claimed the same (XCD, CU slot), bit 1 = a group barrier timed out). */
+int dimx_op_chain(const void* A1, int K1, const void* W1, float* x, const float* slabs, int nslab, const float* gamma,
+                  void* y, const void* W2, int N2, float* out2, int B, int C, void* scratch, void* stream);
 /* tokens = sampler(logits[R,512]) -- see dimx_generate. */
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise,
                    uint64_t seed, uint64_t step, int32_t* tokens, void* stream);
