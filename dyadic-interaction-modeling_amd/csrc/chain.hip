@@ -140,6 +140,11 @@ __device__ __forceinline__ void reduce_store(const f32x16_t (&acc)[NCB], float* 
     }
 }
 
+#define CHAIN_STAMP(i)                                                            \
+    do {                                                                          \
+        if (a.prof && threadIdx.x == 0) a.prof[blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+
 // block barrier that orders LDS traffic only: it must NOT drain vmcnt (the loader waves have weight DMAs in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
     unsigned* ctr = a.counters + 16 * g;
     unsigned target = (unsigned)(*a.step) * (unsigned)(a.nbar * kGroupCUs);
 
+    CHAIN_STAMP(0);
     // ---- row waves: everything of the CU's own row that is already there goes into registers now (x, gamma, the
     // split-K slabs of a preceding chip-wide GEMM, all loads in flight together); only xr has to wait for barrier 1
     const bool own = li < nrows && wave < 4;
@@ -214,15 +220,19 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
                                lds + a.offW1, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        CHAIN_STAMP(1);
         f32x16_t acc[NCB1];
 #pragma unroll
         for (int j = 0; j < NCB1; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         mfma_panel<NCB1>(lds + a.offA1, lds + a.offW1, a.g1.nkt, a.g1.rows_pad, acc, wave, lane);
+        CHAIN_STAMP(2);
         reduce_store<NCB1>(acc, (float*)(lds + a.offRed1), a.xr, a.C, row0, nrows, n0, a.g1.cols, wave, lane);
+        CHAIN_STAMP(3);
         target += kGroupCUs;
         xcd_barrier(ctr, target, a.err);
+        CHAIN_STAMP(4);
     }
 
     // ---- loader waves: the second projection's weight slice (independent of everything computed here)
@@ -275,6 +285,7 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
             }
         }
     }
+    CHAIN_STAMP(5);
     if (tid == 0 && seen_old == stamp) atomicOr(a.err, 1u);  // two blocks claimed the same (XCD, slot): not a bijection
     if (!HAS_G2) return;
     // group barrier 2: only the row waves have stores to drain; the loader waves keep their DMAs in flight
@@ -294,12 +305,14 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
         }
     }
     lds_barrier();
+    CHAIN_STAMP(6);
 
     // ---- second projection on the normalised rows of the whole group (written by 32 CUs of this XCD: sc1)
     {
         issue_panel<AUX_SC1>((const bf16*)a.y, a.C, row0, r_last, kGroupRows, a.g2.nkt, lds + a.offA2, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows, and on waves 4-7 the weight slice
         __syncthreads();
+        CHAIN_STAMP(7);
         f32x16_t acc[NCB2];
 #pragma unroll
         for (int j = 0; j < NCB2; ++j)
@@ -307,7 +320,9 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         mfma_panel<NCB2>(lds + a.offA2, lds + a.offW2, a.g2.nkt, a.g2.rows_pad, acc, wave, lane);
         const int n0 = li * a.g2.cols;
+        CHAIN_STAMP(8);
         reduce_store<NCB2>(acc, (float*)(lds + a.offRed2), a.out2, a.ld_out2, row0, nrows, n0, a.g2.cols, wave, lane);
+        CHAIN_STAMP(9);
     }
 }
 

@@ -161,6 +161,8 @@ struct GemmArgs {
                        // reduction by the consumer kernel); requires act none, no residual/rowadd, plain output
     long slab_stride;  // elements between slabs
     int stage_out;     // set by the launcher: large-M outputs leave through LDS as 8/16-byte row-contiguous pieces
+    int tile_map;      // set by the launcher (prefill): 1 = every XCD works on one half of the N tiles of a quarter of the
+                       // M tiles, so that its share of W (N/2 x K) stays L2-resident while the A panels stream through
     int vt_pack4;      // set by the launcher: transposed (time-contiguous) segments take 4 packed rows per store
 };
 
@@ -168,6 +170,10 @@ void gemm_args_init(GemmArgs& a);
 // plain row-major output helper
 void gemm_set_plain_out(GemmArgs& a, void* C, int ldc);
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// the 256 x 256 phase-pipelined prefill kernel (gemm256.hip): taken by launch_gemm when eligible
+bool gemm256_eligible(const GemmArgs& a);
+int launch_gemm256(const GemmArgs& a, hipStream_t s);
+int launch_gemm256_segs(const GemmArgs& a, const OutSeg* segs, int nseg, int seg_width, hipStream_t s);
 // number of K splits launch_gemm will use for an out_slabs GEMM (the consumer needs it)
 int gemm_plan_splits(const GemmArgs& a);
 
@@ -258,6 +264,7 @@ struct ChainArgs {
     unsigned* seen;  // [8][32] this launch site's (XCD, CU slot) claim stamps (zeroed with the counters)
     const int32_t* step;
     unsigned* err;
+    unsigned long long* prof;  // tuning only: [256 blocks][16] wall-clock stamps (100 MHz) of the phase boundaries
     int nbar;                                                // set by the launcher
     int offA1, offW1, offRed1, offA2, offW2, offRed2;        // LDS plan, set by the launcher
 };

@@ -613,7 +613,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     // and land on the same XCD -- its L2 then fetches every weight byte once instead of once per row tile (the A
     // panel is tiny and stays resident everywhere).  Many row tiles (prefill): m-major, A panels are the big operand.
     int tile_m, tile_n;
-    if (tiles_m <= 8) {
+    if (a.tile_map == 1) {
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int tq = (tiles_m + 3) >> 2, tnh = tiles_n >> 1;
+        const int im = i / tnh;
+        tile_m = (x >> 1) * tq + im;
+        tile_n = (x & 1) * tnh + (i - im * tnh);
+        if (tile_m >= tiles_m) return;
+    } else if (tiles_m <= 8) {
         tile_n = tile / tiles_m;
         tile_m = tile - tile_n * tiles_m;
     } else {
@@ -752,6 +759,7 @@ template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES,
 static int launch_glds(const GemmArgs& a, hipStream_t s) {
     const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
     dim3 grid(tiles * a.splitk), block(WM * WN * 64);
+    if (a.tile_map == 1) grid = dim3(8 * ((ceil_div(a.M, BM) + 3) / 4) * (ceil_div(a.N, BN) / 2));
     // one 32-row slice per wave (MI == 1) is where staging pays (128x128 on 8 waves: -12..-39 %); with two slices per
     // wave (the 4-wave 128x128 and the 256-wide tiles) it measured 30-40 % slower than direct stores
     if constexpr (BM * BN >= 128 * 128 && ABL == 0 && BM / (WM * 32) == 1) {
@@ -789,6 +797,9 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 14: return launch_glds<T, OutT, 128, 128, 4, 2, 2>(a, s);  // 8 waves
         case 18: return launch_glds<T, OutT, 256, 128, 4, 2, 2>(a, s);  // 8 waves, 96 KB ring
         case 19: return launch_glds<T, OutT, 256, 256, 4, 2, 2>(a, s);  // 8 waves, 128 KB ring
+        case 31: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 144 KB ring, 2 tiles in flight
+        case 29: return launch_glds<T, OutT, 128, 128, 4, 2, 4>(a, s);  // 8 waves, 128 KB ring, 3 tiles in flight
+        case 30: return launch_glds<T, OutT, 128, 128, 4, 2, 3>(a, s);  // 8 waves, 96 KB ring
         default: break;
     }
     set_error("gemm: unknown cfg %d", cfg);
@@ -797,10 +808,10 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
 
 static inline void cfg_tile(int cfg, int& bm, int& bn) {
     switch (cfg) {
-        case 1: case 2: case 11: case 14: case 15: case 22: case 23: case 25: case 26: bm = 128; bn = 128; break;
+        case 1: case 2: case 11: case 14: case 15: case 22: case 23: case 25: case 26: case 29: case 30: bm = 128; bn = 128; break;
         case 6: case 7: case 12: case 13: case 24: bm = 128; bn = 64; break;
         case 16: bm = 256; bn = 64; break;
-        case 17: case 18: case 27: bm = 256; bn = 128; break;
+        case 17: case 18: case 27: case 31: bm = 256; bn = 128; break;
         case 19: case 28: bm = 256; bn = 256; break;
         case 8: bm = 64; bn = 128; break;
         default: bm = 64; bn = 64; break;
@@ -825,6 +836,13 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;
+    }
+    static const int tile_map_env = getenv("DIMX_TILE_MAP") ? atoi(getenv("DIMX_TILE_MAP")) : 0;
+    {
+        int bm, bn;
+        cfg_tile(cfg, bm, bn);
+        const int tm = ceil_div(a.M, bm), tn = ceil_div(a.N, bn);
+        a.tile_map = (tile_map_env == 1 && a.splitk == 1 && tm >= 32 && tn >= 2 && tn % 2 == 0) ? 1 : 0;
     }
     // large-M outputs leave through LDS as 16-byte row pieces (epilogue_staged) when the output map allows it
     a.stage_out = 0;
@@ -901,6 +919,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
                          a.conv_T == 0 && a.K == (a.kloop ? a.kloop : a.ldw),
                      DIMX_ERR_ARG, "gemm: slab output needs a plain f32 GEMM without activation/residual");
     if (a.in_dtype == DIMX_BF16) {
+        if (a.cfg == 0 && gemm256_eligible(a)) return launch_gemm256(a, s);
         if (a.out_dtype == DIMX_BF16) return launch_typed<bf16, bf16>(a, s);
         return launch_typed<bf16, float>(a, s);
     }

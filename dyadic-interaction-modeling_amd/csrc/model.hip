@@ -312,9 +312,8 @@ static int pack_vq(dimx_ctx* c, int which) {
 
 static int pack_xattn(dimx_ctx* c, const std::string& p, bool cross, XAttn* a) {
     DIMX_TRY(upload_f32(c, p + "0.0.weight", &a->ln_g));
-    if (cross) {
+    if (cross) {  // K/V of all layers are packed as one matrix by the caller (cross_kv_all)
         DIMX_TRY(pack_linear(c, {p + "1.to_q.weight"}, "", false, &a->qkv));
-        DIMX_TRY(pack_linear(c, {p + "1.to_k.weight", p + "1.to_v.weight"}, "", false, &a->kv));
     } else {
         DIMX_TRY(pack_linear(c, {p + "1.to_q.weight", p + "1.to_k.weight", p + "1.to_v.weight"}, "", false, &a->qkv));
     }
@@ -423,6 +422,22 @@ static int ensure_packed(dimx_ctx* c, int need) {
             }
             DIMX_TRY(upload_f32(c, dp + "attn_layers.final_norm.weight", &c->dec.final_g));
             DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, "", false, &c->dec.logits));
+            {
+                std::vector<std::string> parts;
+                for (int i = 0; i < c->decg.depth; ++i) {
+                    parts.push_back(xl(dp, 3 * i + 1) + "1.to_k.weight");
+                    parts.push_back(xl(dp, 3 * i + 1) + "1.to_v.weight");
+                }
+                DIMX_TRY(pack_linear(c, parts, "", false, &c->dec.cross_kv_all));
+                const Linear& all = c->dec.cross_kv_all;
+                const int per = all.N / c->decg.depth;
+                for (int i = 0; i < c->decg.depth; ++i) {
+                    Linear& kv = c->dec.cross[i].kv;
+                    kv = all;
+                    kv.N = per;
+                    kv.w = (unsigned char*)all.w + (size_t)i * per * all.Kp * dtype_size(c->at);
+                }
+            }
         }
         c->packed_mask |= comp;
     }
@@ -1255,6 +1270,27 @@ namespace dimx {
 int project_cross_kv(dimx_handle h, const void* ctx, const CtxPersist& cp, int B, int T, int for_generate,
                      hipStream_t st) {
     const int M = B * T, D = h->decg.dim_head, heads = h->decg.heads, Tp = tpad(T);
+    if (for_generate && h->at == DIMX_BF16 && 2 * h->decg.depth <= 8 && D % 8 == 0) {
+        // every layer's K | V cache in ONE launch of the phase-pipelined kernel: the context panel is read once
+        GemmArgs g;
+        gemm_lin(h, ctx, h->decg.ctx_dim, h->dec.cross_kv_all, M, g);
+        g.out_dtype = h->at;
+        g.rowT = T;
+        OutSeg segs[8];
+        for (int l = 0; l < h->decg.depth; ++l)
+            for (int i = 0; i < 2; ++i) {
+                OutSeg& sg = segs[2 * l + i];
+                sg.ptr = i == 0 ? cp.ck[l] : cp.cv[l];
+                sg.sb = (long)heads * Tp * D;
+                sg.sh = (long)Tp * D;
+                sg.st = D;
+                sg.sd = 1;
+                sg.D = D;
+            }
+        GemmArgs probe = g;
+        gemm_set_plain_out(probe, cp.ck[0], g.N);
+        if (gemm256_eligible(probe)) return launch_gemm256_segs(g, segs, 2 * h->decg.depth, heads * D, st);
+    }
     for (int l = 0; l < h->decg.depth; ++l) {
         GemmArgs g;
         gemm_lin(h, ctx, h->decg.ctx_dim, h->dec.cross[l].kv, M, g);
@@ -1753,6 +1789,43 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int dimx_op_gemm_headmajor(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int M, int N, int K,
+                           int rowT, int Tp, int nlayers, void* stream) {
+    DIMX_REQUIRE(nlayers >= 1 && nlayers <= 4 && N % (nlayers * 128) == 0, DIMX_ERR_ARG, "op_gemm_headmajor: bad shape");
+    GemmArgs g;
+    gemm_args_init(g);
+    g.in_dtype = dtype;
+    g.out_dtype = dtype;
+    g.A = A;
+    g.lda = lda;
+    g.W = W;
+    g.ldw = ldw;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.rowT = rowT;
+    // column segments K_0 | V_0 | K_1 | V_1 ... each a [B, H, Tp, 64] cache (project_cross_kv's for_generate layout)
+    const int nseg = 2 * nlayers, segw = N / nseg, H = segw / 64;
+    OutSeg segs[8];
+    for (int i = 0; i < nseg; ++i) {
+        segs[i].ptr = (unsigned char*)out + (size_t)i * (M / rowT) * H * Tp * 64 * dtype_size(dtype);
+        segs[i].sb = (long)H * Tp * 64;
+        segs[i].sh = (long)Tp * 64;
+        segs[i].st = 64;
+        segs[i].sd = 1;
+        segs[i].D = 64;
+    }
+    GemmArgs probe = g;
+    gemm_set_plain_out(probe, out, N);
+    if (dtype == DIMX_BF16 && gemm256_eligible(probe)) return launch_gemm256_segs(g, segs, nseg, segw, (hipStream_t)stream);
+    DIMX_REQUIRE(nlayers == 1, DIMX_ERR_ARG, "op_gemm_headmajor: the fused multi-layer form needs the bf16 256-tile kernel");
+    g.nseg = 2;
+    g.seg_width = segw;
+    g.seg[0] = segs[0];
+    g.seg[1] = segs[1];
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 int dimx_op_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta, int M, int C,
                       void* stream) {
     return launch_layernorm(out_dtype, x, y, gamma, beta, M, C, (hipStream_t)stream);
@@ -1869,6 +1942,7 @@ int dimx_op_chain(const void* A1, int K1, const void* W1, float* x, const float*
     c.err = u + 129;
     DIMX_REQUIRE(chain_supported(c, cus), DIMX_ERR_ARG, "op_chain: shape not supported on this device (%d CUs)", cus);
     DIMX_HIP(hipMemsetAsync(u, 0, 512 * 4, (hipStream_t)stream));
+    if (getenv("DIMX_CHAIN_PROF")) c.prof = (unsigned long long*)(u + 512 + (size_t)B * C);  // tools/chain_phases.py
     return launch_chain(c, (hipStream_t)stream);
 }
 

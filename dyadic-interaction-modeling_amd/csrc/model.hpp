@@ -55,6 +55,7 @@ struct XDec {
     XFF ff[8];
     const float* final_g = nullptr;
     Linear logits;
+    Linear cross_kv_all;  // [depth * 2 * inner][Kp]: every layer's [Wk; Wv] stacked (cross[l].kv are views into it)
 };
 
 // geometry of the three network families of a handle (variant 0 = SLMFT, 1 = legacy ListenerGenerator,

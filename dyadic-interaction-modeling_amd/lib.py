@@ -73,6 +73,8 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "dimx_op_gemm_headmajor": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_void_p]),
     "dimx_op_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dimx_op_instnorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dimx_op_attention": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -158,27 +158,33 @@ def decode_gemm(B, mode, device, iters=40):
 
 
 def cross_kv_gemm(B, T, mode, device, iters=12):
-    """The MFMA GEMM of the cross-attention bundle: K/V projection of the speaker context for one decoder
-    layer, [B*T, 1152] x [1536, 1152]^T (SURVEY.md section 8d "cross-attention GEMM").  BASELINE.json's
-    'cross-attn MFMA util %' is quoted on it: achieved TFLOP/s / dense MFMA peak of the operand type."""
+    """The MFMA GEMM of the cross-attention bundle as dimx_encode_ctx launches it: the K/V projection of the speaker
+    context, [B*T, 1152] x [N, 1152]^T into head-major [B,12,Tp,64] caches.  bf16: all four decoder layers in one launch
+    of the 256 x 256 phase-pipelined kernel (N = 6144); f32: one layer per launch (N = 1536).  BASELINE.json's
+    'cross-attn MFMA util %' is quoted on it: achieved TFLOP/s / dense MFMA peak of the operand type (2.5 PFLOP/s is
+    the 2.4 GHz figure; the clock under this load is lower, see profiles/)."""
     from . import lib as L
     lib = L.load()
-    M, N, K = B * T, 1536, 1152
     bf = mode == "bf16"
+    nlayers = 4 if bf else 1
+    M, N, K = B * T, nlayers * 1536, 1152
+    Tp = (T + 7) // 8 * 8
     dt = torch.bfloat16 if bf else torch.float32
     a = torch.randn(M, K, device=device).to(dt)
     w = [(torch.randn(N, K, device=device) / 34.0).to(dt) for _ in range(2)]
-    out = torch.empty(M, N, device=device, dtype=dt)
+    out = torch.empty(2 * nlayers, B, 12, Tp, 64, device=device, dtype=dt)
 
     def run(i):
-        L.check(lib.dimx_op_gemm(L.BF16 if bf else L.F32, L.BF16 if bf else L.F32, L.ptr(a), K, L.ptr(w[i % 2]), K,
-                                 L.ptr(out), N, M, N, K, None, 0, None, 0, 0, None, 0, L.stream_ptr(device)), "gemm")
+        L.check(lib.dimx_op_gemm_headmajor(L.BF16 if bf else L.F32, L.ptr(a), K, L.ptr(w[i % 2]), K, L.ptr(out), M, N, K, T,
+                                           Tp, nlayers, L.stream_ptr(device)), "gemm_headmajor")
     sec = _time_launches(run, 3, iters)
     flops = 2.0 * M * N * K
     tf = flops / sec / 1e12
     peak = MFMA_PEAK_TFLOPS[mode]
-    return {"kernel": "gemm_glds_kernel (cross-attention K/V projection) M=%d N=%d K=%d" % (M, N, K), "bound": "mfma",
-            "achieved": tf, "peak": peak, "unit": "TFLOP/s", "util_pct": 100.0 * tf / peak, "avg_launch_us": sec * 1e6}
+    return {"kernel": "%s (cross-attention K/V projection, %d layer%s per launch) M=%d N=%d K=%d" % (
+                "gemm256_kernel<bf16>" if bf else "gemm_glds_kernel<float>", nlayers, "s" if nlayers > 1 else "", M, N, K),
+            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "util_pct": 100.0 * tf / peak,
+            "avg_launch_us": sec * 1e6}
 
 
 def dominant_kernel(eng, B, T, mode):

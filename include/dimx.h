@@ -207,6 +207,11 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
 int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void* W, int ldw, void* C,
                  int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
                  int ldr, int conv_T, const int32_t* conv_lens, int flags, void* stream);
+/* The cross-attention K/V projection as dimx_encode_ctx(for_generate=1) launches it: [M = B*rowT, K] . W[N, K]^T, the
+ * N columns being nlayers x (K | V) segments of H*64 columns; segment i goes to the i-th [B, H, Tp, 64] cache inside
+ * `out`.  bf16 with nlayers = 4 is the fused all-layers launch of the 256 x 256 kernel; f32 supports nlayers = 1. */
+int dimx_op_gemm_headmajor(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int M, int N, int K,
+                           int rowT, int Tp, int nlayers, void* stream);
 /* y = LayerNorm(x) over the last dim (C in {384,1152}), eps 1e-5; beta optional. */
 int dimx_op_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta,
                       int M, int C, void* stream);

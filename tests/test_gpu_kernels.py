@@ -253,3 +253,52 @@ def test_chain_kernels_match_torch(B):
     r1 = engine.op_chain(x1, gamma, a1=a1, w1=w1, w2=w2)
     r2 = engine.op_chain(x2, gamma, a1=a1, w1=w1, w2=w2)
     assert torch.equal(x1, x2) and torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 384), (8192, 384, 1536), (4096 + 256 * 3, 1152, 448), (6000, 768, 64)])
+def test_gemm256_prefill_kernel(M, N, K):
+    """csrc/gemm256.hip (phase-pipelined 256 x 256 kernel, taken for M >= 4096): plain / bias + GELU / f32 residual
+    epilogues against float64 on the bf16-rounded operands, and against the one-barrier kernel (cfg 14) bit for bit
+    where both produce f32 (same products, different summation order -> tolerance, not equality)."""
+    from dimx import engine
+    torch.manual_seed(M + N + K)
+    dev = torch.device("cuda:0")
+    a = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    ab, wb = a.bfloat16().double(), w.bfloat16().double()
+    ref = ab @ wb.t()
+    out = engine.op_gemm(a, w, bf16=True, out_bf16=True)
+    assert (out.double() - ref).abs().max() < 0.06
+    out = engine.op_gemm(a, w, bias=bias, act=2, bf16=True, out_bf16=True)
+    r2 = torch.nn.functional.gelu(ref + bias.double(), approximate="tanh")
+    assert (out.double() - r2).abs().max() < 0.06
+    out = engine.op_gemm(a, w, bias=bias, residual=res, bf16=True)
+    old = engine.op_gemm(a, w, bias=bias, residual=res, bf16=True, cfg=14)
+    assert (out.double() - (ref + bias.double() + res.double())).abs().max() < 2e-3
+    assert (out - old).abs().max() < 1e-3
+    # repeated launches are bit-identical (the pipeline has no timing-dependent summation order / races)
+    for _ in range(3):
+        assert torch.equal(out, engine.op_gemm(a, w, bias=bias, residual=res, bf16=True))
+
+
+@pytest.mark.parametrize("nlayers", [1, 4])
+def test_gemm256_head_major_kv_layout(nlayers):
+    """the cross-attention K/V projection's destination: [B,H,Tp,64] K and V caches of 1 or all 4 decoder layers in one
+    launch (dimx_op_gemm_headmajor)."""
+    from dimx import lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, T, H, K = 24, 300, 12, 1152
+    nseg = 2 * nlayers
+    Tp, N, M = 304, nseg * H * 64, B * T
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    out = torch.zeros(nseg, B, H, Tp, 64, device=dev, dtype=torch.bfloat16)
+    L.check(lib.dimx_op_gemm_headmajor(L.BF16, L.ptr(a), K, L.ptr(w), K, L.ptr(out), M, N, K, T, Tp, nlayers,
+                                       L.stream_ptr(dev)), "gemm_headmajor")
+    ref = (a.double() @ w.double().t()).view(B, T, nseg, H, 64).permute(2, 0, 3, 1, 4)     # [nseg,B,H,T,64]
+    assert (out[:, :, :, :T].double() - ref).abs().max() < 0.06
+    assert float(out[:, :, :, T:].abs().max()) == 0.0                                      # padding rows untouched
