@@ -199,17 +199,23 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
                 gm[i] = a.gamma[c];
             }
         }
+        if (a.nslab > 0) {
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl)
+            for (int sl = 0; sl < 8; ++sl) {
+                const float* sp = a.slabs + (size_t)(sl < a.nslab ? sl : 0) * a.slab_stride + (size_t)row * C;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int c = tid + i * 256;
-                t[sl][i] = (sl < a.nslab && c < C) ? a.slabs[(size_t)sl * a.slab_stride + (size_t)row * C + c] : 0.f;
+                for (int i = 0; i < 6; ++i) {
+                    const int c = tid + i * 256;
+                    t[sl][i] = sp[c < C ? c : 0];  // unconditional loads (all in flight together), masked below
+                }
             }
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl)  // slab order = the order the one-kernel-per-op step adds them in
+            for (int sl = 0; sl < 8; ++sl)  // slab order = the order the one-kernel-per-op step adds them in
+                if (sl < a.nslab) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] += t[sl][i];
+                    for (int i = 0; i < 6; ++i) v[i] += (tid + i * 256 < C) ? t[sl][i] : 0.f;
+                }
+        }
     }
 
     // ---- burst 1 + first projection: partial[32 rows][this CU's columns] -> xr

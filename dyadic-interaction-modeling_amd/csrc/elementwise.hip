@@ -199,20 +199,22 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                 }
             }
         }
+        // Only the <= top_k (+ ties) survivors need a probability and a noise draw: compact them to one per lane
+        // (2 rounds cover up to 128 survivors; more than that -- massive ties -- falls back to the per-element loop).
         const float inv_t = 1.0f / temperature;
-        float p[8];
-        float zsum = 0.f;
+        int nsurv_lane = 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            p[c] = key[c] >= thr ? expf((v[c] - mx) * inv_t) : 0.f;
-            zsum += p[c];
+        for (int c = 0; c < 8; ++c) nsurv_lane += key[c] >= thr ? 1 : 0;
+        int incl = nsurv_lane;  // inclusive prefix over lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
         }
-        zsum = wave_sum(zsum);
+        const int total = __shfl(incl, 63);
         float best = -1.f;
         int bi = 0x7fffffff;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int i = lane + 64 * c;
+        auto score = [&](float pv, float zs, int i) {
             float q;
             if (noise) {
                 q = noise[((size_t)step * rows_total + row0 + row) * 512 + i];
@@ -221,11 +223,54 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                 const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
                 q = fmaxf(-log1pf(-u), 9.313225746154785e-10f);
             }
-            const float sc = (p[c] / zsum) / q;
+            const float sc = (pv / zs) / q;
             if (sc > best || (sc == best && i < bi)) {
                 best = sc;
                 bi = i;
             }
+        };
+        if (total <= 128) {
+            __shared__ float cand_v[4][128];
+            __shared__ int cand_i[4][128];
+            float* cv = cand_v[threadIdx.x >> 6];
+            int* ci = cand_i[threadIdx.x >> 6];
+            int pos = incl - nsurv_lane;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (key[c] >= thr) {
+                    cv[pos] = v[c];
+                    ci[pos] = lane + 64 * c;
+                    ++pos;
+                }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float pv[2] = {0.f, 0.f};
+            int pi[2] = {0, 0};
+            float zsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int k = lane + 64 * r;
+                if (k < total) {
+                    pv[r] = expf((cv[k] - mx) * inv_t);
+                    pi[r] = ci[k];
+                    zsum += pv[r];
+                }
+            }
+            zsum = wave_sum(zsum);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (lane + 64 * r < total) score(pv[r], zsum, pi[r]);
+        } else {
+            float p[8];
+            float zsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                p[c] = key[c] >= thr ? expf((v[c] - mx) * inv_t) : 0.f;
+                zsum += p[c];
+            }
+            zsum = wave_sum(zsum);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) score(p[c], zsum, lane + 64 * c);
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {

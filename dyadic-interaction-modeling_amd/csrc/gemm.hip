@@ -585,7 +585,10 @@ template <int MI, int NI> struct FragMma<float, MI, NI> {
 };
 
 // ABL (ablation, tuning only): 0 normal, 1 = no MFMA/ds_read in the loop (DMA only), 2 = no DMA in the loop
-template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0, bool STG = false>
+// KPI: k-tiles per loop iteration (one vmcnt wait + one barrier per KPI tiles; the ring holds STAGES groups of KPI tiles).
+// The decode GEMMs (M = batch) do 4 MFMAs per wave and k-tile, so the per-iteration wait / barrier / DMA-issue overhead
+// (~1000 cycles) is what they cost: KPI = 2 halves the number of iterations.
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0, bool STG = false, int KPI = 1>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a) {
     constexpr int NW = WM * WN;
     constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
@@ -595,8 +598,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     constexpr int LPT = LA + LW;
     constexpr int TILE_BYTES = (BM + BN) * 128;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA pieces per wave");
-    static_assert(STAGES >= 1 && (STAGES - 1) * LPT < 64, "vmcnt range");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
+    static_assert(STAGES >= 1 && (STAGES - 1) * LPT * KPI < 64, "vmcnt range");
+    static_assert(KPI == 1 || (STAGES >= 2 && ABL == 0 && !STG), "KPI > 1: plain ring only");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * KPI * TILE_BYTES];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
@@ -691,30 +695,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk && (ABL != 2 || s == 0)) issue(s, s);
-
-    for (int it = 0; it < nk; ++it) {
-        if (STAGES == 1) {
-            // single LDS buffer: latency is hidden by the other resident blocks (up to 5 per CU), not by a ring
-            if (it > 0) __builtin_amdgcn_s_barrier();  // everyone is done reading the previous tile
-            issue(it, 0);
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-        } else {
-            // tile `it` has landed once at most min(STAGES-2, nk-1-it) younger tiles are still in flight
-            if (ABL == 2 || nk - 1 - it < STAGES - 2)
-                wait_vmcnt<0>();
-            else
-                wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LPT>();
-            __builtin_amdgcn_s_barrier();
-            if (ABL != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
-        }
-        if (ABL == 1) continue;
-        const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
-        // all fragment reads of a group of k-steps are issued back to back; the MFMAs of k-step s start as
-        // soon as the reads of steps <= s have returned (LDS returns in order: counted lgkmcnt)
+    // one k-tile from ring slot `slot`: all fragment reads of a group of k-steps are issued back to back; the MFMAs of
+    // k-step s start as soon as the reads of steps <= s have returned (LDS returns in order: counted lgkmcnt)
+    auto compute_tile = [&](int slot) {
+        const unsigned boff = (unsigned)(slot * TILE_BYTES);
         constexpr int RPK = MI + NI;                      // ds_read_b128 per k-step
         constexpr int GROUP = (4 * RPK <= 12) ? 4 : (2 * RPK <= 12 ? 2 : 1);  // k-steps per group (lgkmcnt: 4 bits)
 #pragma unroll
@@ -742,6 +726,56 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
                 FragMma<T, MI, NI>::run(acc, fa[q], fw[q]);
             }
         }
+    };
+
+    if constexpr (KPI > 1) {
+        // groups of KPI k-tiles: group gi = tiles [gi*KPI, gi*KPI + KPI) in ring slots (gi % STAGES)*KPI + j
+        const int ng = (nk + KPI - 1) / KPI;
+        auto issue_group = [&](int gi) {
+#pragma unroll
+            for (int jj = 0; jj < KPI; ++jj) {
+                const int kt = gi * KPI + jj;
+                issue(kt < nk ? kt : nk - 1, (gi % STAGES) * KPI + jj);  // a short last group re-reads the last tile
+            }
+        };
+#pragma unroll
+        for (int s2 = 0; s2 < STAGES - 1; ++s2)
+            if (s2 < ng) issue_group(s2);
+        for (int gi = 0; gi < ng; ++gi) {
+            if (ng - 1 - gi < STAGES - 2)
+                wait_vmcnt<0>();
+            else
+                wait_vmcnt<(STAGES - 2) * LPT * KPI>();
+            __builtin_amdgcn_s_barrier();
+            if (gi + STAGES - 1 < ng) issue_group(gi + STAGES - 1);
+#pragma unroll
+            for (int jj = 0; jj < KPI; ++jj)
+                if (gi * KPI + jj < nk) compute_tile((gi % STAGES) * KPI + jj);
+        }
+    } else {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk && (ABL != 2 || s == 0)) issue(s, s);
+
+    for (int it = 0; it < nk; ++it) {
+        if (STAGES == 1) {
+            // single LDS buffer: latency is hidden by the other resident blocks (up to 5 per CU), not by a ring
+            if (it > 0) __builtin_amdgcn_s_barrier();  // everyone is done reading the previous tile
+            issue(it, 0);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        } else {
+            // tile `it` has landed once at most min(STAGES-2, nk-1-it) younger tiles are still in flight
+            if (ABL == 2 || nk - 1 - it < STAGES - 2)
+                wait_vmcnt<0>();
+            else
+                wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LPT>();
+            __builtin_amdgcn_s_barrier();
+            if (ABL != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        }
+        if (ABL == 1) continue;
+        compute_tile(it % STAGES);
+    }
     }
 
     // ---- epilogue (split-K: this split's partial sums go to its own f32 slab)
@@ -753,6 +787,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
     } else {
         epilogue<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, split);
     }
+}
+
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int KPI>
+static int launch_glds_kpi(const GemmArgs& a, hipStream_t s) {
+    const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
+    dim3 grid(tiles * a.splitk), block(WM * WN * 64);
+    hipLaunchKernelGGL((gemm_glds_kernel<T, OutT, BM, BN, WM, WN, STAGES, 0, false, KPI>), grid, block, 0, s, a);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
 }
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int ABL = 0>
@@ -800,6 +843,8 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 31: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 144 KB ring, 2 tiles in flight
         case 29: return launch_glds<T, OutT, 128, 128, 4, 2, 4>(a, s);  // 8 waves, 128 KB ring, 3 tiles in flight
         case 30: return launch_glds<T, OutT, 128, 128, 4, 2, 3>(a, s);  // 8 waves, 96 KB ring
+        case 32: return launch_glds_kpi<T, OutT, 64, 64, 2, 2, 2, 2>(a, s);  // 64x64, 2 k-tiles per iteration, 64 KB
+        case 33: return launch_glds_kpi<T, OutT, 64, 64, 2, 2, 3, 2>(a, s);  // ... 3 groups deep, 96 KB
         default: break;
     }
     set_error("gemm: unknown cfg %d", cfg);

@@ -33,6 +33,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kHalf = 16384;        // one half-tile: 128 rows x 128 B
 constexpr int kBuf = 4 * kHalf;     // one k-tile: A0h A1h B0h B1h
+constexpr bool kPrio = true;  // s_setprio(1) around the MFMA segments: +7 % (without it 35.8 -> 33.3 % on the fused K/V projection)
 constexpr int kLds = 2 * kBuf;
 constexpr int kLdsTotal = kLds + 8 * 4096;  // + one 4 KiB epilogue scratch per wave = all 160 KiB
 
@@ -332,14 +333,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         raw_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
+        if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
                 acc[0][0][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb0[ks]),
                                                                        __builtin_bit_cast(bf16x8_t, fa[rb][ks]), acc[0][0][rb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (kPrio) __builtin_amdgcn_s_setprio(0);
         raw_barrier();
         // ================= phase 2: quadrant (0,1) -- read W(col half 1); stage A1h of g + 1
         {
@@ -350,14 +351,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         raw_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
+        if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
                 acc[0][1][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb1[ks]),
                                                                        __builtin_bit_cast(bf16x8_t, fa[rb][ks]), acc[0][1][rb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (kPrio) __builtin_amdgcn_s_setprio(0);
         raw_barrier();
         advance(c1);
         // ================= phase 3: quadrant (1,1) -- read A(row half 1); stage A0h of g + 2
@@ -372,27 +373,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         raw_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
+        if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
                 acc[1][1][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb1[ks]),
                                                                        __builtin_bit_cast(bf16x8_t, fa[rb][ks]), acc[1][1][rb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (kPrio) __builtin_amdgcn_s_setprio(0);
         raw_barrier();
         // ================= phase 4: quadrant (1,0) -- everything is in registers; stage B0h of g + 2
         stage_b(c2, buf);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         raw_barrier();
-        __builtin_amdgcn_s_setprio(1);
+        if (kPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
                 acc[1][0][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb0[ks]),
                                                                        __builtin_bit_cast(bf16x8_t, fa[rb][ks]), acc[1][0][rb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (kPrio) __builtin_amdgcn_s_setprio(0);
         raw_barrier();
         advance(c2);
         bo ^= (unsigned)kBuf;

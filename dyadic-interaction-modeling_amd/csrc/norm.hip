@@ -78,13 +78,27 @@ __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restr
         v[i] = xr[lane + 64 * i];
         gv[i] = g2[lane + 64 * i];
     }
-    for (int sidx = 0; sidx < nslab; ++sidx) {
-        const float2* sr = (const float2*)(slabs + (size_t)sidx * slab_stride + (size_t)row * C);
+    // the slabs come from another kernel's split-K blocks (memory-side latency): all loads of up to 4 slabs are in flight
+    // together, the adds stay in slab order (deterministic)
+    for (int s0 = 0; s0 < nslab; s0 += 4) {
+        float2 t[4][NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const float2 p = sr[lane + 64 * i];
-            v[i].x += p.x;
-            v[i].y += p.y;
+        for (int k = 0; k < 4; ++k) {
+            const bool on = s0 + k < nslab;
+            const float2* sr = (const float2*)(slabs + (size_t)(on ? s0 + k : 0) * slab_stride + (size_t)row * C);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) t[k][i] = sr[lane + 64 * i];  // unconditional (a select per element would
+                                                                        // serialise the loads); masked below
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (s0 + k < nslab) {  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    v[i].x += t[k][i].x;
+                    v[i].y += t[k][i].y;
+                }
+            }
         }
     }
     float s = 0.f;

@@ -152,11 +152,64 @@ class SLMFT(_EngineOwner):
         t = target.reshape(-1, target.shape[-1])[m]
         return torch.mean(F.pairwise_distance(p[:, 6:], t[:, 6:])) + torch.mean(F.pairwise_distance(p[:, 0:6], t[:, 0:6]))
 
+    # ------------------------------------------------------------------ training
+    def _wants_grad(self, mode):
+        return (mode == "train" and self.training and torch.is_grad_enabled()
+                and any(p.requires_grad for p in self.parameters()))
+
+    def train(self, mode=True):
+        """nn.Module.train, with the reference's frozen parts kept in eval (code/seq2seq_pretrain.py:348-366)."""
+        super().train(mode)
+        self.speaker_vq.eval()
+        self.listener_vq.eval()
+        return self
+
+    def _forward_autograd(self, v_speaker, v_listener, v_audio, mask, kv_mask=None, z_l=None, return_tokens=False):
+        """mode='train' with a graph: differentiable cross entropy (dimx.train.slmft_loss on this module's own
+        parameters); listener codes and decoded motion come from the HIP engine without a graph."""
+        from . import train as T
+        mask = mask.bool()
+        B, Tn = mask.shape
+        on_gpu = v_speaker.is_cuda
+        if z_l is None:
+            with torch.no_grad():
+                _, z_l = self.forward_vq(v_speaker, v_listener, mask, with_speaker=False)
+        if kv_mask is None:
+            kv_mask = self.draw_kv_mask(B, Tn, v_speaker.device)
+        elif kv_mask is False:
+            kv_mask = None
+        P = dict(self.named_parameters())
+        l_ce_l, logits = T.slmft_loss(P, self.s2s, v_speaker.float(), v_audio.float(), mask, z_l.long(),
+                                      kv_mask.bool() if kv_mask is not None else None)
+        pred, l_cont_l = None, torch.zeros((), device=v_speaker.device)
+        if on_gpu:     # the continuous loss has no gradient path in the reference either (argmax -> one-hot, :454-464)
+            with torch.no_grad():
+                pred = self.forward_vq_decoder(logits.detach(), mode="train")
+                l_cont_l = self.forward_continuous_loss(pred, v_listener, mask)
+        total_loss = l_ce_l + l_cont_l
+        d = {"l_ce_s": 0, "l_ce_l": l_ce_l.detach(), "l_cont_s": 0, "l_cont_l": l_cont_l, "nce": 0, "c_acc": 0}
+        if return_tokens:
+            return total_loss, d, pred, logits.detach().argmax(-1)
+        return total_loss, d, pred
+
     # ------------------------------------------------------------------ forward
-    @torch.no_grad()
     def forward(self, v_speaker, v_listener, v_audio, mask, mode="train", speaker_ids=None, listener_ids=None,
                 noise=None, kv_mask=None, greedy=False, seed=None, temperature=1.0, batch_row_offset=0,
-                return_tokens=False, n_samples=1, shard=None):
+                return_tokens=False, n_samples=1, shard=None, z_l=None):
+        """reference :496-514.  In training (``model.train()``, grad enabled, parameters requiring grad) the
+        teacher-forced pass returns a loss with an autograd graph; everything else is the HIP inference path."""
+        if self._wants_grad(mode):
+            return self._forward_autograd(v_speaker, v_listener, v_audio, mask, kv_mask=kv_mask, z_l=z_l,
+                                          return_tokens=return_tokens)
+        return self._forward_nograd(v_speaker, v_listener, v_audio, mask, mode=mode, noise=noise, kv_mask=kv_mask,
+                                    greedy=greedy, seed=seed, temperature=temperature,
+                                    batch_row_offset=batch_row_offset, return_tokens=return_tokens,
+                                    n_samples=n_samples, shard=shard)
+
+    @torch.no_grad()
+    def _forward_nograd(self, v_speaker, v_listener, v_audio, mask, mode="train", speaker_ids=None, listener_ids=None,
+                        noise=None, kv_mask=None, greedy=False, seed=None, temperature=1.0, batch_row_offset=0,
+                        return_tokens=False, n_samples=1, shard=None):
         """reference :496-514 -> (total_loss, dict, pred_cont_seq_l [B,T-1,56]).
 
         ``n_samples`` S > 1 (mode 'val' only): S independent generations per clip in ONE pass -- what the

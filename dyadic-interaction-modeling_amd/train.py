@@ -1,0 +1,162 @@
+"""Training step of the DIM-Listener fine-tuning model: reference ``train_epoch``
+(code/x_engine_pt.py:9-60) as driven by code/finetune_s2s_pretrain.py:105-143 (AdamW lr 1e-5, clip 1.0, frozen VQ-VAEs).
+
+What is differentiated is the teacher-forced path of ``SLMFT.forward(mode='train')`` (code/seq2seq_pretrain.py:496-514):
+encoder_s -> encoder_joint -> norm_s -> context -> AutoregressiveWrapper.forward -> cross entropy.  The continuous
+loss has no gradient path in the reference either (its ``pred`` comes from an argmax / one-hot of the logits, :454-464),
+and both VQ-VAEs are frozen (:348-366), so the listener code targets and the decoded motion are taken from the HIP engine
+(no graph) and only the transformer stack is restated here with differentiable PyTorch-ROCm ops (rocBLAS / hipBLASLt
+GEMMs, fused softmax): the backward pass runs on autograd, not on hand-written HIP kernels -- those are the inference
+path; hand-written backward kernels are the next step of this row.  After ``optimizer.step()`` the
+engine notices the changed parameters and re-packs them before its next launch.
+
+Multi-GPU: one process per GPU, replicated weights, per-rank batch shard; ``all_reduce_grads`` averages the gradients in
+~64 MiB flat buckets over RCCL (xGMI ring: a few large collectives instead of one per tensor) before clipping.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import dist as ddist
+
+FROZEN_PREFIXES = ("speaker_vq.", "listener_vq.")
+
+
+def trainable_parameters(model):
+    """(name, parameter) of everything the reference trains: all but the two VQ-VAEs (and their ``pe`` buffers)."""
+    return [(n, p) for n, p in model.named_parameters() if not n.startswith(FROZEN_PREFIXES)]
+
+
+def set_trainable(model, flag=True):
+    for _, p in trainable_parameters(model):
+        p.requires_grad_(flag)
+    return model
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# x-transformers 1.30.16 layers, functional, on a {key: tensor} view of the module's own parameters
+# ---------------------------------------------------------------------------------------------------------------------
+def _ln(x, w, b=None):
+    return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+def _attention(x, ctx, P, pre, heads, key_mask=None, attn_mask=None):
+    B, n, _ = x.shape
+    q = F.linear(x, P[pre + "to_q.weight"]).view(B, n, heads, -1).transpose(1, 2)
+    k = F.linear(ctx, P[pre + "to_k.weight"]).view(B, ctx.shape[1], heads, -1).transpose(1, 2)
+    v = F.linear(ctx, P[pre + "to_v.weight"]).view(B, ctx.shape[1], heads, -1).transpose(1, 2)
+    dots = torch.matmul(q, k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+    neg = -torch.finfo(dots.dtype).max
+    if key_mask is not None:
+        dots = dots.masked_fill(~key_mask[:, None, None, :], neg)
+    if attn_mask is not None:
+        dots = dots.masked_fill(~attn_mask, neg)
+    out = torch.matmul(dots.softmax(dim=-1, dtype=torch.float32).to(dots.dtype), v)
+    return F.linear(out.transpose(1, 2).reshape(B, n, -1), P[pre + "to_out.weight"])
+
+
+def _ff(x, P, pre):
+    h = F.gelu(F.linear(x, P[pre + "ff.0.0.weight"], P[pre + "ff.0.0.bias"]))
+    return F.linear(h, P[pre + "ff.2.weight"], P[pre + "ff.2.bias"])
+
+
+def xt_encoder(P, pre, x, mask, causal, depth, heads):
+    """ContinuousTransformerWrapper(..., return_embeddings=True) with an Encoder of (attention, feed-forward) x depth."""
+    T = x.shape[1]
+    h = F.linear(x, P[pre + "project_in.weight"])
+    h = h + P[pre + "pos_emb.emb.weight"][:T] * (h.shape[-1] ** -0.5)
+    am = torch.ones(T, T, dtype=torch.bool, device=x.device).tril() if causal else None
+    L = pre + "attn_layers.layers."
+    for i in range(depth):
+        h = h + _self(h, P, L, 2 * i, heads, mask, am)
+        h = h + _ff(_ln(h, P[L + "%d.0.0.weight" % (2 * i + 1)]), P, L + "%d.1." % (2 * i + 1))
+    return _ln(h, P[pre + "attn_layers.final_norm.weight"])
+
+
+def _self(h, P, L, li, heads, key_mask, attn_mask):
+    y = _ln(h, P[L + "%d.0.0.weight" % li])
+    return _attention(y, y, P, L + "%d.1." % li, heads, key_mask, attn_mask)
+
+
+def xt_decoder_logits(P, pre, tokens, context, context_mask, self_kv_mask, depth, heads, pos_emb=False):
+    """TransformerWrapper(num_tokens, attn_layers=Decoder(cross_attend=True)) on a token prefix -> logits."""
+    n = tokens.shape[1]
+    h = P[pre + "token_emb.emb.weight"][tokens]
+    if pos_emb:
+        h = h + P[pre + "pos_emb.emb.weight"][:n] * (h.shape[-1] ** -0.5)
+    causal = torch.ones(n, n, dtype=torch.bool, device=tokens.device).tril()
+    L = pre + "attn_layers.layers."
+    for i in range(depth):
+        h = h + _self(h, P, L, 3 * i, heads, self_kv_mask, causal)
+        y = _ln(h, P[L + "%d.0.0.weight" % (3 * i + 1)])
+        h = h + _attention(y, context, P, L + "%d.1." % (3 * i + 1), heads, context_mask, None)
+        h = h + _ff(_ln(h, P[L + "%d.0.0.weight" % (3 * i + 2)]), P, L + "%d.1." % (3 * i + 2))
+    h = _ln(h, P[pre + "attn_layers.final_norm.weight"])
+    return F.linear(h, P[pre + "to_logits.weight"])
+
+
+def slmft_loss(P, dims, v_speaker, v_audio, mask, z_l, kv_mask=None):
+    """Differentiable l_ce_l of SLMFT.forward(mode='train').  P: {key: tensor} (parameters carry the graph); z_l [B,T]
+    listener codes with -100 on padding (from the frozen VQ-VAE); kv_mask [B,T-1] keep-mask (AutoregressiveWrapper's
+    mask_prob draw) or None.  Returns (loss, logits)."""
+    x = v_speaker + P["patch_embed_s"]
+    x = xt_encoder(P, "encoder_s.", x, mask, True, dims.enc_depth, dims.heads)
+    x = xt_encoder(P, "encoder_joint.", x, mask, True, dims.enc_depth, dims.heads)
+    x_s = _ln(x, P["norm_s.weight"], P["norm_s.bias"])
+    ctx = torch.cat([x_s + P["patch_embed_dec_s"], v_audio], dim=-1)
+    inp = z_l[:, :-1].clamp(min=0)                                   # pad_value 0 where the target is ignored
+    logits = xt_decoder_logits(P, "decoder_joint.net.", inp, ctx, mask, kv_mask, dims.dec_depth, dims.heads)
+    loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), z_l[:, 1:].reshape(-1), ignore_index=-100)
+    return loss, logits
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gradient synchronisation
+# ---------------------------------------------------------------------------------------------------------------------
+def all_reduce_grads(params, bucket_bytes=64 << 20):
+    """Average .grad over the ranks of the default process group in flat buckets (sum all-reduce, then / world).
+    xGMI is point-to-point, ring collectives are per-link bound: few large buckets beat one collective per tensor."""
+    world = ddist.world_size()
+    if world == 1:
+        return 0
+    import torch.distributed as dist
+    grads = [p.grad for p in params if p.grad is not None]
+    n_coll, i = 0, 0
+    while i < len(grads):
+        j, size = i, 0
+        while j < len(grads) and (size == 0 or size + grads[j].numel() * grads[j].element_size() <= bucket_bytes):
+            size += grads[j].numel() * grads[j].element_size()
+            j += 1
+        flat = torch.cat([g.reshape(-1) for g in grads[i:j]])
+        dist.all_reduce(flat)
+        flat.div_(world)
+        o = 0
+        for g in grads[i:j]:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+        n_coll += 1
+        i = j
+    return n_coll
+
+
+def train_step(model, optimizer, v_speaker, v_listener, v_audio, mask, clip=1.0, kv_mask=None, scheduler=None):
+    """One optimisation step exactly as the reference's loop body (zero_grad, forward(mode='train'), backward, clip,
+    step), with the gradient all-reduce in between for N > 1."""
+    optimizer.zero_grad()
+    loss, d, pred = model(v_speaker, v_listener, v_audio, mask, mode="train", kv_mask=kv_mask)
+    loss.mean().backward()
+    params = [p for _, p in trainable_parameters(model)]
+    all_reduce_grads(params)
+    if clip > 0:
+        torch.nn.utils.clip_grad_norm_(params, clip)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss.detach(), d, pred
+
+
+def make_optimizer(model, lr=1e-5):
+    """reference code/finetune_s2s_pretrain.py:119: AdamW over the trainable parameters."""
+    set_trainable(model, True)
+    return torch.optim.AdamW([p for _, p in trainable_parameters(model)], lr=lr)

@@ -71,8 +71,10 @@ def evaluate_epoch(model, loader, device, generate_kw=None, verbose=True):
 
 
 def train_epoch(*args, **kwargs):
-    """Import-compatibility placeholder for reference code/x_engine.py:8-36; training is not built."""
-    raise NotImplementedError("dimx is forward/inference only: train_epoch (backward + AdamW) is not built")
+    """Import-compatibility placeholder for reference code/x_engine.py:8-36 (the LEGACY ListenerGenerator's loop).
+    The training step that is built is the DIM-Listener one: dimx.x_engine_pt.train_epoch / dimx.train."""
+    raise NotImplementedError("the legacy ListenerGenerator's training loop is not built; the DIM-Listener (SLMFT) "
+                              "training step is dimx.x_engine_pt.train_epoch")
 
 
 train_continuous_epoch = train_epoch

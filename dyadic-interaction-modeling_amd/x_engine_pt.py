@@ -168,7 +168,35 @@ def generate_sharded(model, v_speaker, v_listener, v_audio, mask, **forward_kw):
     return tokens, pred
 
 
-def train_epoch(*args, **kwargs):
-    """Import-compatibility placeholder for reference code/x_engine_pt.py:9-60 (``test_s2s_pretrain.py:6`` imports it
-    next to the evaluation functions).  Backward / optimiser steps are SURVEY 8(f3) and not built: calling it fails."""
-    raise NotImplementedError("dimx is forward/inference only: train_epoch (backward + AdamW) is not built")
+def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, print_freq=2000, epoch=0, log=print):
+    """reference code/x_engine_pt.py:9-60: one pass over the loader with zero_grad / forward(mode='train') / backward /
+    clip / step.  For N > 1 processes the gradients are averaged over RCCL before clipping (dimx.train.all_reduce_grads);
+    every rank feeds its own loader shard.  Returns the mean loss of the epoch."""
+    from . import train as T
+    model.train()
+    T.set_trainable(model, True)
+    params = [p for _, p in T.trainable_parameters(model)]
+    d = {k: 0.0 for k in ("l_ce_s", "l_ce_l", "l_cont_s", "l_cont_l", "nce", "c_acc")}
+    losses, all_losses = [], []
+    for i, batch in enumerate(loader):
+        src_s_v, src_s_a, tgt, mask, _, _ = _prepare(batch, device)
+        optimizer.zero_grad()
+        loss, d_step, _ = model(src_s_v, tgt, src_s_a, mask, mode="train")
+        loss.mean().backward()
+        T.all_reduce_grads(params)
+        if clip > 0:
+            torch.nn.utils.clip_grad_norm_(params, clip)
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        for k in d:
+            v = d_step.get(k, 0)
+            d[k] += float(v.mean().item()) if torch.is_tensor(v) else float(v)
+        losses.append(float(loss.mean().item()))
+        all_losses.append(losses[-1])
+        if i % print_freq == 0:
+            log("Epoch %d Batch %d:\tLoss %.4f\t" % (epoch, i, float(np.mean(losses))) +
+                "\t".join("%s %.4f" % (k, d[k] / print_freq) for k in d))
+            d = {k: 0.0 for k in d}
+            losses = []
+    return float(np.mean(all_losses)) if all_losses else float("nan")

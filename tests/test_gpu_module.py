@@ -170,3 +170,35 @@ def test_multi_sample_generation_matches_independent_runs(model, full_sd):
         assert (pred[:, s_i] - p1).abs().max() < 1e-5
     # distinct samples really differ
     assert not torch.equal(tok[:, 0], tok[:, 1])
+
+
+def test_train_epoch_on_gpu_updates_the_engine_weights():
+    """SURVEY 8 row f3 on the device: x_engine_pt.train_epoch (AdamW, clip 1.0) with the listener codes and the decoded
+    motion from the HIP engine and the transformer's backward on PyTorch-ROCm autograd; the next HIP inference call
+    must see the updated parameters (the engine re-packs changed weights)."""
+    from dimx import train as T
+    from dimx import x_engine_pt
+    from dimx.seq2seq_pretrain import SLMFT
+    dev = torch.device("cuda:0")
+    B, Tn, lens = 4, 32, [32, 32, 20, 11]
+    v_s, v_l, v_a, mask = _clips(B, Tn, lens, seed=33)
+    src = torch.cat([v_s, v_a], -1) * mask[..., None]
+    loader = [(src, v_l * mask[..., None], lens, None, ["a", "b", "c", "d"])] * 3
+    with torch.enable_grad():
+        m = SLMFT().to(dev)
+        m.eval()
+        args = (v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev))
+        _, _, before = m(*args, mode="val", greedy=True)
+        opt = T.make_optimizer(m, lr=1e-4)
+        l0 = x_engine_pt.train_epoch(m, loader[:1], opt, dev, clip=1.0, log=lambda *_: None)
+        l1 = x_engine_pt.train_epoch(m, loader, opt, dev, clip=1.0, log=lambda *_: None)
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0
+    m.eval()
+    with torch.no_grad():
+        _, _, after = m(*args, mode="val", greedy=True)
+    assert torch.isfinite(after).all() and not torch.equal(before, after)
+    # the frozen VQ-VAEs did not move
+    ref = SLMFT()
+    for k, v in ref.state_dict().items():
+        if k.startswith("listener_vq.") and v.dtype.is_floating_point:
+            assert torch.equal(v, m.state_dict()[k].cpu()), k
