@@ -181,10 +181,19 @@ def cross_kv_gemm(B, T, mode, device, iters=12):
     flops = 2.0 * M * N * K
     tf = flops / sec / 1e12
     peak = MFMA_PEAK_TFLOPS[mode]
-    return {"kernel": "%s (cross-attention K/V projection, %d layer%s per launch) M=%d N=%d K=%d" % (
-                "gemm256_kernel<bf16>" if bf else "gemm_glds_kernel<float>", nlayers, "s" if nlayers > 1 else "", M, N, K),
-            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "util_pct": 100.0 * tf / peak,
-            "avg_launch_us": sec * 1e6}
+    out = {"kernel": "%s (cross-attention K/V projection, %d layer%s per launch) M=%d N=%d K=%d" % (
+               "gemm256_kernel<bf16>" if bf else "gemm_glds_kernel<float>", nlayers, "s" if nlayers > 1 else "", M, N, K),
+           "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "util_pct": 100.0 * tf / peak,
+           "avg_launch_us": sec * 1e6, "pmc_mfma_busy_pct": None}
+    # MFMA busy cycles / kernel cycles from the PMC pass recorded for THIS kernel source (same rule as `traffic`): the
+    # flop-rate figure above is against the 2.4 GHz peak, the counter figure is against the clock the kernel really ran at
+    path = os.path.join(PROFILES, "pmc_gemm256_%s.json" % kernel_source_hash("gemm256.hip"))
+    if bf and (B, T) == (256, 300) and os.path.exists(path):
+        with open(path) as fh:
+            rec = json.load(fh)
+        out["pmc_mfma_busy_pct"] = rec.get("mfma_busy_pct")
+        out["pmc_shader_clock_GHz"] = rec.get("shader_clock_GHz_under_pmc")
+    return out
 
 
 def dominant_kernel(eng, B, T, mode):
