@@ -161,6 +161,7 @@ struct GemmArgs {
                        // reduction by the consumer kernel); requires act none, no residual/rowadd, plain output
     long slab_stride;  // elements between slabs
     int stage_out;     // set by the launcher: large-M outputs leave through LDS as 8/16-byte row-contiguous pieces
+    unsigned long long* prof;  // tuning only (tools/gemm_phases.py): per-block wall-clock stamps, ABL = 3 instantiation
     int tile_map;      // set by the launcher (prefill): 1 = every XCD works on one half of the N tiles of a quarter of the
                        // M tiles, so that its share of W (N/2 x K) stays L2-resident while the A panels stream through
     int vt_pack4;      // set by the launcher: transposed (time-contiguous) segments take 4 packed rows per store

@@ -753,11 +753,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
                 if (gi * KPI + jj < nk) compute_tile((gi % STAGES) * KPI + jj);
         }
     } else {
+    auto stamp = [&](int i) {
+        if (ABL == 3 && tid == 0 && i < 32) a.prof[(size_t)blockIdx.x * 32 + i] = wall_clock64();
+    };
+    stamp(0);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk && (ABL != 2 || s == 0)) issue(s, s);
+    stamp(1);
 
     for (int it = 0; it < nk; ++it) {
+        if (ABL == 3 && it < 24) stamp(2 + it);
         if (STAGES == 1) {
             // single LDS buffer: latency is hidden by the other resident blocks (up to 5 per CU), not by a ring
             if (it > 0) __builtin_amdgcn_s_barrier();  // everyone is done reading the previous tile
@@ -776,6 +782,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
         if (ABL == 1) continue;
         compute_tile(it % STAGES);
     }
+    stamp(28);
     }
 
     // ---- epilogue (split-K: this split's partial sums go to its own f32 slab)
@@ -786,6 +793,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
         epilogue_stg<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, smem + wave * SLICE);
     } else {
         epilogue<T, OutT, MI, NI>(a, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, half, l31, split);
+    }
+    if (ABL == 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) a.prof[(size_t)blockIdx.x * 32 + 29] = wall_clock64();
     }
 }
 
@@ -835,7 +846,9 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
         case 1: return launch_glds<T, OutT, 128, 128, 2, 2, 2>(a, s);
-        case 3: return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
+        case 3:
+            if (a.prof) return launch_glds<T, OutT, 64, 64, 2, 2, 4, 3>(a, s);
+            return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
         case 4: return launch_glds<T, OutT, 64, 64, 2, 2, 3>(a, s);
         case 14: return launch_glds<T, OutT, 128, 128, 4, 2, 2>(a, s);  // 8 waves
         case 18: return launch_glds<T, OutT, 256, 128, 4, 2, 2>(a, s);  // 8 waves, 96 KB ring

@@ -1696,7 +1696,20 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
         if (!h->ev_fork) DIMX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         DIMX_HIP(hipEventRecord(h->ev_fork, st));
         for (int g = 0; g < G; ++g) {
-            if (!h->grp_stream[g]) DIMX_HIP(hipStreamCreateWithFlags(&h->grp_stream[g], hipStreamNonBlocking));
+            if (!h->grp_stream[g]) {
+                static const bool cumask = getenv("DIMX_GEN_CUMASK") != nullptr;
+                if (cumask && h->cu_count > 0 && h->cu_count % 32 == 0) {
+                    // group g runs on its own 1/G of the CUs of every XCD (a CU mask spreads evenly over the XCDs:
+                    // tools/ubench/cumask_probe): the groups then never compete for a CU, only for HBM and L2
+                    const int words = h->cu_count / 32;
+                    std::vector<uint32_t> mask(words, 0u);
+                    const int lo = h->cu_count * g / G, hi = h->cu_count * (g + 1) / G;
+                    for (int i = lo; i < hi; ++i) mask[i >> 5] |= 1u << (i & 31);
+                    DIMX_HIP(hipExtStreamCreateWithCUMask(&h->grp_stream[g], (uint32_t)words, mask.data()));
+                } else {
+                    DIMX_HIP(hipStreamCreateWithFlags(&h->grp_stream[g], hipStreamNonBlocking));
+                }
+            }
             if (!h->ev_join[g]) DIMX_HIP(hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
             gs[g] = h->grp_stream[g];
             DIMX_HIP(hipStreamWaitEvent(gs[g], h->ev_fork, 0));
@@ -1780,6 +1793,10 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     g.cfg = (flags >> 8) & 0xff;           /* tuning: tile/stage config id */
     g.force_splitk = (flags >> 16) & 0xff; /* tuning: split count */
     if (ldw > K && K % (in_dtype == DIMX_BF16 ? 64 : 32) == 0) g.kloop = K; /* padded row stride, exact k extent */
+    if (getenv("DIMX_GEMM_PROF") && residual && !g.out_slabs && out_dtype == DIMX_BF16 && M <= 1024) {
+        g.prof = (unsigned long long*)residual; /* tools/gemm_phases.py smuggles its stamp buffer in here */
+        g.residual = nullptr;
+    }
     if (conv_T > 0) {
         g.conv_T = conv_T;
         g.conv_lens = conv_lens;
