@@ -202,3 +202,36 @@ def test_train_epoch_on_gpu_updates_the_engine_weights():
     for k, v in ref.state_dict().items():
         if k.startswith("listener_vq.") and v.dtype.is_floating_point:
             assert torch.equal(v, m.state_dict()[k].cpu()), k
+
+
+def test_reference_sub_apis_with_the_reference_call_shapes(model, full_sd):
+    """SURVEY 8b sub-APIs: forward_encoder alone (dimx_encode_speaker), forward_decoder(x_s, z_l, x_a, mask, mode)
+    positionally with the x_s that forward_encoder returned (dimx_set_context), and VQAutoEncoder.decode(quant) on
+    latents that are NOT codebook rows (dimx_vq_decode_latent)."""
+    from dimx import prng
+    from oracle import ref_cpu
+    B, T, lens = 3, 40, [40, 31, 9]
+    v_s, v_l, v_a, mask = _clips(B, T, lens, seed=44)
+    dev = torch.device("cuda:0")
+    x_s = model.forward_encoder(v_s.to(dev), mask.to(dev))
+    ref_xs = ref_cpu.slmft_forward_encoder(full_sd, v_s, mask)
+    for b, n in enumerate(lens):
+        assert (x_s[b, :n].cpu() - ref_xs[b, :n]).abs().max() < 1e-4
+    _, z_l = model.forward_vq(v_s.to(dev), v_l.to(dev), mask.to(dev), with_speaker=False)
+    kv = ref_cpu.ar_kv_mask(B, T, 0.15, torch.Generator().manual_seed(9))
+    loss, logits = model.forward_decoder(x_s, z_l, v_a.to(dev), mask.to(dev), "train", kv_mask=kv.to(dev))
+    ctx = ref_cpu.slmft_context(full_sd, ref_xs, v_a)
+    r_loss, r_logits = ref_cpu.ar_forward(full_sd, z_l.cpu(), ctx, mask, kv)
+    valid = mask[:, 1:]
+    assert (logits.cpu() - r_logits)[valid].abs().max() < 1e-3 and abs(float(loss) - float(r_loss)) < 1e-3
+    noise = torch.from_numpy(prng.exponential(44, "sub.noise", (T - 1, B, 512)))
+    _, tok = model.forward_decoder(x_s, z_l, v_a.to(dev), mask.to(dev), "val", noise=noise.to(dev))
+    r_tok = ref_cpu.ar_generate(full_sd, z_l[:, 0].cpu(), T - 1, ctx, mask, noise)
+    assert torch.equal(tok.cpu(), r_tok)
+    # decode(quant) on arbitrary latents: the oracle decoder run on the same latents (a codebook made of them)
+    lat = torch.from_numpy(prng.normal(45, "sub.lat", (2, 128, 26)))          # [B,128,L] like encode returns
+    out = model.listener_vq.decode(lat.to(dev))
+    sd2 = dict(full_sd)
+    sd2["listener_vq.quantize.embedding.weight"] = lat.permute(0, 2, 1).reshape(-1, 128)
+    ref = ref_cpu.vq_decode(sd2, torch.arange(2 * 26).view(2, 26), prefix="listener_vq.")
+    assert out.shape == (2, 26, 56) and (out.cpu() - ref).abs().max() < 1e-4
