@@ -776,11 +776,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
                 wait_vmcnt<0>();
             else
                 wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LPT>();
+            if (ABL == 3 && it == 8) stamp(20);
             __builtin_amdgcn_s_barrier();
+            if (ABL == 3 && it == 8) stamp(21);
+            // Measured on this sequence (tools/gemm_phases.py, tools/gemm_ab.py, same box): wave 0 spends 0.07 us in the
+            // vmcnt wait, 0.04 in the barrier, 0.14 issuing its 4 DMA pieces, 0.15 on 8 ds_reads + 4 MFMAs.  Issuing the
+            // fragment reads before the DMAs: qkv 10.3 -> 11.2 us; non-temporal DMA loads of W: ff1 13.5 -> 15.9 us (every
+            // M tile re-reads the W tile from L2); a wave-uniform branch per DMA piece: +1 us per kernel.
             if (ABL != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+            if (ABL == 3 && it == 8) stamp(22);
         }
         if (ABL == 1) continue;
         compute_tile(it % STAGES);
+        if (ABL == 3 && it == 8) stamp(23);
     }
     stamp(28);
     }
@@ -798,6 +806,164 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) a.prof[(size_t)blockIdx.x * 32 + 29] = wall_clock64();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode GEMM (M = batch, a few 64-row tiles): the same 64 x 64 tile, ring and swizzle as gemm_glds_kernel, but the
+// loop's two halves run on different waves.  In the 4-wave kernel a wave does wait -> barrier -> 4 DMA issues ->
+// 8 ds_reads -> 4 MFMAs in sequence, and with ONE wave per SIMD nothing overlaps them: 0.385 us per 16 KiB k-tile,
+// of which 0.14 is DMA issue and 0.15 fragment reads + MFMA.  Here waves 0-3 only consume (barrier -> reads -> MFMA)
+// and waves 4-7 only load (wait for their pieces of tile t -> barrier -> issue tile t + STAGES - 1); a SIMD holds
+// one of each, so its loader's issue time hides behind its consumer's matrix time.  One s_barrier per k-tile does both
+// hand-offs: tile t is complete (every loader waited for its own pieces before arriving) and slot (t - 1) % STAGES is
+// free (every consumer finished its reads of tile t - 1 before arriving).
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename OutT, int STAGES, bool PROF = false>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
+    constexpr int BM = 64, BN = 64, NL = 4;
+    constexpr int EPC = Elem<T>::kPerChunk;
+    constexpr int BK = 8 * EPC;
+    constexpr int LA = BM / 8 / NL, LW = BN / 8 / NL;  // DMA pieces per tile per loader wave
+    constexpr int LPT = LA + LW;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    static_assert(STAGES >= 3 && (STAGES - 1) * LPT < 64, "ring depth");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;  // XCD-aware order, n-major for few row tiles: see gemm_glds_kernel
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int split = bid / ntiles, tile = bid - split * ntiles;
+    int tile_m, tile_n;
+    if (tiles_m <= 8) {
+        tile_n = tile / tiles_m;
+        tile_m = tile - tile_n * tiles_m;
+    } else {
+        tile_m = tile / tiles_n;
+        tile_n = tile - tile_m * tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk_all = (a.kloop ? a.kloop : a.ldw) / BK;
+    const int per = (nk_all + a.splitk - 1) / a.splitk;
+    const int kt0 = split * per;
+    int nk = nk_all - kt0;
+    nk = nk > per ? per : nk;
+    if (nk <= 0) return;
+    // PROF (tools/gemm_phases.py): 64 wall-clock stamps per block, 0-31 by consumer wave 0, 32-63 by loader wave 4
+    auto stamp = [&](int i) {
+        if (PROF && lane == 0 && (wave == 0 || wave == 4) && i < 32)
+            a.prof[(size_t)blockIdx.x * 64 + (wave == 4 ? 32 : 0) + i] = wall_clock64();
+    };
+    stamp(0);
+
+    if (wave >= 4) {
+        // ---------------- loader waves
+        const int lw = wave - 4;
+        const T* __restrict__ A = (const T*)a.A;
+        const T* __restrict__ W = (const T*)a.W;
+        const T* gA[LA];
+        const T* gW[LW];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int row = (lw * LA + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            gA[j] = A + (size_t)m * a.lda + c * EPC + (size_t)kt0 * BK;
+        }
+#pragma unroll
+        for (int j = 0; j < LW; ++j) {
+            const int row = (lw * LW + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int n = n0 + row;
+            n = n < a.N ? n : a.N - 1;
+            gW[j] = W + (size_t)n * a.ldw + c * EPC + (size_t)kt0 * BK;
+        }
+        auto issue = [&](int kt, int buf) {
+            unsigned char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+            for (int j = 0; j < LA; ++j)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gA[j] + (size_t)kt * BK),
+                                                 (lds_void_t*)(base + (lw * LA + j) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int j = 0; j < LW; ++j)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gW[j] + (size_t)kt * BK),
+                                                 (lds_void_t*)(base + BM * 128 + (lw * LW + j) * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int st = 0; st < STAGES - 1; ++st)
+            if (st < nk) issue(st, st);
+        stamp(1);
+        for (int it = 0; it < nk; ++it) {
+            if (it < 12) stamp(2 + 2 * it);
+            // this wave's pieces of tile `it` have landed once at most min(STAGES-2, nk-1-it) younger tiles are in flight
+            if (nk - 1 - it < STAGES - 2)
+                wait_vmcnt<0>();
+            else
+                wait_vmcnt<(STAGES - 2) * LPT>();
+            if (it < 12) stamp(3 + 2 * it);
+            __builtin_amdgcn_s_barrier();
+            if (it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+        }
+        stamp(28);
+        return;
+    }
+
+    // ---------------- consumer waves: 2 x 2, one 32 x 32 accumulator each
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+    unsigned aoff[4], woff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        aoff[ks] = lds0 + lds_off(wm * 32 + l31, 2 * ks + half);
+        woff[ks] = lds0 + BM * 128 + lds_off(wn * 32 + l31, 2 * ks + half);
+    }
+    f32x16_t acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    for (int it = 0; it < nk; ++it) {
+        const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
+        if (it < 12) stamp(2 + 2 * it);
+        __builtin_amdgcn_s_barrier();
+        if (it < 12) stamp(3 + 2 * it);
+        u32x4_t fa[4][1], fw[4][1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ds_read128<0>(fa[q][0], aoff[q] + boff);
+            ds_read128<0>(fw[q][0], woff[q] + boff);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q == 0) wait_lgkm<6>();
+            if (q == 1) wait_lgkm<4>();
+            if (q == 2) wait_lgkm<2>();
+            if (q == 3) wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            FragMma<T, 1, 1>::run(acc, fa[q], fw[q]);
+        }
+    }
+    stamp(28);
+    epilogue<T, OutT, 1, 1>(a, acc, m0 + wm * 32, n0 + wn * 32, half, l31, split);
+    if (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(29);
+    }
+}
+
+template <typename T, typename OutT, int STAGES> static int launch_ws(const GemmArgs& a, hipStream_t s) {
+    const int tiles = ceil_div(a.M, 64) * ceil_div(a.N, 64);
+    if (a.prof && STAGES == 4)
+        hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, 4, true>), dim3(tiles * a.splitk), dim3(512), 0, s, a);
+    else
+    hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, STAGES>), dim3(tiles * a.splitk), dim3(512), 0, s, a);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
 }
 
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int STAGES, int KPI>
@@ -858,6 +1024,10 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 30: return launch_glds<T, OutT, 128, 128, 4, 2, 3>(a, s);  // 8 waves, 96 KB ring
         case 32: return launch_glds_kpi<T, OutT, 64, 64, 2, 2, 2, 2>(a, s);  // 64x64, 2 k-tiles per iteration, 64 KB
         case 33: return launch_glds_kpi<T, OutT, 64, 64, 2, 2, 3, 2>(a, s);  // ... 3 groups deep, 96 KB
+        case 34: return launch_ws<T, OutT, 4>(a, s);  // 64x64, 4 consumer + 4 loader waves, 64 KB ring
+        case 35: return launch_ws<T, OutT, 6>(a, s);  // ... 96 KB ring (one block per CU)
+        case 36: return launch_ws<T, OutT, 5>(a, s);  // ... 80 KB ring (two blocks per CU just fit)
+        case 37: return launch_ws<T, OutT, 8>(a, s);  // ... 128 KB ring
         default: break;
     }
     set_error("gemm: unknown cfg %d", cfg);
@@ -889,8 +1059,11 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
         return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
     }
     int cfg = a.cfg;
-    static const int cfg_small = getenv("DIMX_GEMM_CFG_SMALL") ? atoi(getenv("DIMX_GEMM_CFG_SMALL")) : 3;
-    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : cfg_small;  // measured on MI355X: 128x128 8-wave for large M; 64x64 with a 4-deep ring for decode (3: -0.4 %, 5: -1 %)
+    // measured on MI355X: 128x128 8-wave for large M; 64x64 with a 4-deep ring for decode, loader + consumer waves
+    // (34) over the 4-wave kernel (3): qkv 10.3 -> 8.8, ff1 13.1 -> 12.1, ff2 11.9 -> 11.0 us, +1.0..1.5 % end to end on
+    // the same box; deeper rings (36: 5, 35: 6, 37: 8 slots) are slower (tools/gemm_ab.py)
+    static const int cfg_small = getenv("DIMX_GEMM_CFG_SMALL") ? atoi(getenv("DIMX_GEMM_CFG_SMALL")) : 34;
+    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : cfg_small;
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;

@@ -81,6 +81,28 @@ def test_gemm_splitk_slabs_and_simple_kernel(dev, M, N, K, S, bf16):
     assert _err(o2, o3) < (1e-5 if not bf16 else 1e-4)   # same products, only the summation order differs
 
 
+@pytest.mark.parametrize("M,N,K,S,act", [(256, 4608, 1152, 0, 3), (256, 3456, 1152, 0, 0), (256, 1152, 4608, 4, 0),
+                                         (200, 1100, 1152, 0, 0), (1, 512, 1152, 0, 0), (64, 384, 64, 0, 1),
+                                         (256, 1152, 192, 3, 0)])
+@pytest.mark.parametrize("cfg", [34, 35])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gemm_loader_consumer_kernel(dev, M, N, K, S, act, cfg, bf16):
+    """the decode GEMM with loader and consumer waves (cfg 34 / 35): same tiles, same k order, same epilogue as the
+    4-wave kernel (cfg 3) -> bit-identical results, ragged M / N edges, 1..18 k-tiles, split-K slabs included."""
+    from dimx import engine
+    g = torch.Generator().manual_seed(M + N + K + S)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    aa, ww = (_bf(a), _bf(w)) if bf16 else (a, w)
+    ref = ACTS[act](aa.double() @ ww.double().t() + bias.double())
+    kw = dict(bf16=bf16, slabs=S) if S else dict(bf16=bf16, out_bf16=bf16 and act == 3)
+    new = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, cfg=cfg, **kw)
+    old = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, cfg=3, **kw)
+    assert torch.equal(new, old)
+    out = new.sum(0) if S else new.float()
+    assert _err(out, ref) < (0.05 if kw.get("out_bf16") else (2e-3 if bf16 else 1e-4))
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_gemm_bf16_out(dev, bf16):
     from dimx import engine
