@@ -67,7 +67,8 @@ __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + (((
 // 48 MFMAs -- the epilogue, not the main loop, was the bottleneck -- so it is specialised:
 //   * ACT is a compile-time parameter (the caller switches once, outside the element loops);
 //   * FAST (bf16 perf mode): GELU through v_exp_f32 / v_rcp_f32 approximations (error far below bf16
-//     rounding); the f32 parity mode keeps tanhf / erff;
+//     rounding; the bare v_rcp_f32 -- __frcp_rn expands to a 12-instruction IEEE division, and the decode ff1
+//     epilogue spent 1.5 us in 16 GELUs per lane, tools/gemm_phases.py); the f32 parity mode keeps tanhf / erff;
 //   * a plain row-major destination gets a dedicated path (one 64-bit base per column, 32-bit row offsets);
 //     the generic path handles head-major K/V caches, transposed V^T and per-row positional adds.
 // ------------------------------------------------------------------------------------------------
@@ -77,7 +78,7 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_fn(float x) {
         const float u = 0.7978845608028654f * (x + 0.044715f * (x * x * x));
         if (FAST) {  // tanh(u) = 1 - 2 / (1 + e^{2u})
             const float e = __expf(2.0f * u);
-            const float t = 1.0f - 2.0f * __frcp_rn(1.0f + e);
+            const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
             return x * (0.5f * (1.0f + t));
         }
         return x * (0.5f * (1.0f + tanhf(u)));
@@ -85,7 +86,7 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_fn(float x) {
     if (ACT == ACT_GELU_ERF) {
         if (FAST) {  // Abramowitz-Stegun 7.1.26, |error| < 1.5e-7
             const float z = fabsf(x) * 0.7071067811865476f;
-            const float t = __frcp_rn(1.0f + 0.3275911f * z);
+            const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
             const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
             const float er = 1.0f - poly * __expf(-z * z);
             return 0.5f * x * (1.0f + (x < 0.f ? -er : er));
@@ -97,7 +98,7 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_fn(float x) {
 
 template <typename OutT, int MI, int NI, int ACT, bool FAST>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w,
-                                              int half, int l31, int split) {
+                                              int half, int l31, int split, unsigned long long* st = nullptr) {
     const bool first = split == 0;
     const bool plain = a.nseg == 1 && a.seg[0].sd == 1 && a.seg[0].sh == 0 && a.seg[0].sb == a.seg[0].st * (long)a.rowT;
     if (plain && a.rowadd_mode == 0) {
@@ -107,20 +108,46 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
         for (int j = 0; j < NI; ++j) {
             const int n = n0w + j * 32 + l31;
             if (n >= a.N) continue;
-            const float bias_v = (a.bias && first) ? a.bias[n] : 0.f;
+            float bias_v = (a.bias && first) ? a.bias[n] : 0.f;
+            if (st) {  // tools/gemm_phases.py: kernel arguments + bias in registers
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bias_v)::"memory");
+                st[24] = wall_clock64();
+            }
             OutT* col = C + n;
             const float* rcol = a.residual ? a.residual + n : nullptr;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int mb = m0w + i * 32 + 4 * half;
+                float vals[16];
+                if (rcol) {  // all 16 residual loads in flight together, rows past M read row M - 1 (never stored)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m >= a.M) continue;
-                    float v = act_fn<ACT, FAST>(acc[i][j][r] + bias_v);
-                    if (rcol) v += rcol[(size_t)m * a.ldr];
-                    store_from_f32<OutT>(col + (size_t)m * ldc, v);
+                    for (int r = 0; r < 16; ++r) {
+                        int m = mb + (r & 3) + 8 * (r >> 2);
+                        m = m < a.M ? m : a.M - 1;
+                        vals[r] = rcol[(size_t)m * a.ldr];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vals[r] += act_fn<ACT, FAST>(acc[i][j][r] + bias_v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vals[r] = act_fn<ACT, FAST>(acc[i][j][r] + bias_v);
                 }
+                if (st) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(vals[r]));
+                    st[25] = wall_clock64();
+                }
+                if (mb + 27 < a.M) {  // the lane's last row is mb + 27: no per-row checks for interior tiles
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) store_from_f32<OutT>(col + (size_t)(mb + (r & 3) + 8 * (r >> 2)) * ldc, vals[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        if (m < a.M) store_from_f32<OutT>(col + (size_t)m * ldc, vals[r]);
+                    }
+                }
+                if (st) st[26] = wall_clock64();
             }
         }
         return;
@@ -179,13 +206,13 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
 
 template <typename T, typename OutT, int MI, int NI>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w, int half,
-                                         int l31, int split) {
+                                         int l31, int split, unsigned long long* st = nullptr) {
     constexpr bool FAST = sizeof(T) == 2;
     switch (a.act) {
-        case ACT_LEAKY: epilogue_tile<OutT, MI, NI, ACT_LEAKY, FAST>(a, acc, m0w, n0w, half, l31, split); break;
-        case ACT_GELU_TANH: epilogue_tile<OutT, MI, NI, ACT_GELU_TANH, FAST>(a, acc, m0w, n0w, half, l31, split); break;
-        case ACT_GELU_ERF: epilogue_tile<OutT, MI, NI, ACT_GELU_ERF, FAST>(a, acc, m0w, n0w, half, l31, split); break;
-        default: epilogue_tile<OutT, MI, NI, ACT_NONE, FAST>(a, acc, m0w, n0w, half, l31, split); break;
+        case ACT_LEAKY: epilogue_tile<OutT, MI, NI, ACT_LEAKY, FAST>(a, acc, m0w, n0w, half, l31, split, st); break;
+        case ACT_GELU_TANH: epilogue_tile<OutT, MI, NI, ACT_GELU_TANH, FAST>(a, acc, m0w, n0w, half, l31, split, st); break;
+        case ACT_GELU_ERF: epilogue_tile<OutT, MI, NI, ACT_GELU_ERF, FAST>(a, acc, m0w, n0w, half, l31, split, st); break;
+        default: epilogue_tile<OutT, MI, NI, ACT_NONE, FAST>(a, acc, m0w, n0w, half, l31, split, st); break;
     }
 }
 
@@ -818,7 +845,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
 // hand-offs: tile t is complete (every loader waited for its own pieces before arriving) and slot (t - 1) % STAGES is
 // free (every consumer finished its reads of tile t - 1 before arriving).
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename OutT, int STAGES, bool PROF = false>
+//
+// (Replacing the barrier by two LDS counters -- loaders add to `landed`, consumers to `consumed`, each side polls the
+// other's -- so that loaders never wait for each other measured slower: qkv 8.6 -> 10.5 us, the polls sit on both
+// critical paths.)
+// ABLW (tuning only, tools/gemm_ab.py): 1 = consumers skip reads + MFMA, 2 = loaders issue no DMA after the prologue,
+// 3 = the W pieces are replaced by a second copy of the A pieces (every DMA an L2 hit).
+template <typename T, typename OutT, int STAGES, bool PROF = false, int ABLW = 0>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
     constexpr int BM = 64, BN = 64, NL = 4;
     constexpr int EPC = Elem<T>::kPerChunk;
@@ -883,6 +916,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
             int n = n0 + row;
             n = n < a.N ? n : a.N - 1;
             gW[j] = W + (size_t)n * a.ldw + c * EPC + (size_t)kt0 * BK;
+            if (ABLW == 3) gW[j] = gA[j < LA ? j : 0];
         }
         auto issue = [&](int kt, int buf) {
             unsigned char* base = smem + buf * TILE_BYTES;
@@ -908,7 +942,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
                 wait_vmcnt<(STAGES - 2) * LPT>();
             if (it < 12) stamp(3 + 2 * it);
             __builtin_amdgcn_s_barrier();
-            if (it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+            if (ABLW != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
         }
         stamp(28);
         return;
@@ -931,6 +965,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
         const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
         if (it < 12) stamp(2 + 2 * it);
         __builtin_amdgcn_s_barrier();
+        if (ABLW == 1) continue;
         if (it < 12) stamp(3 + 2 * it);
         u32x4_t fa[4][1], fw[4][1];
 #pragma unroll
@@ -949,19 +984,20 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
         }
     }
     stamp(28);
-    epilogue<T, OutT, 1, 1>(a, acc, m0 + wm * 32, n0 + wn * 32, half, l31, split);
+    epilogue<T, OutT, 1, 1>(a, acc, m0 + wm * 32, n0 + wn * 32, half, l31, split,
+                            (PROF && wave == 0 && lane == 0) ? a.prof + (size_t)blockIdx.x * 64 : nullptr);
     if (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(29);
     }
 }
 
-template <typename T, typename OutT, int STAGES> static int launch_ws(const GemmArgs& a, hipStream_t s) {
+template <typename T, typename OutT, int STAGES, int ABLW = 0> static int launch_ws(const GemmArgs& a, hipStream_t s) {
     const int tiles = ceil_div(a.M, 64) * ceil_div(a.N, 64);
     if (a.prof && STAGES == 4)
-        hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, 4, true>), dim3(tiles * a.splitk), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, 4, true, ABLW>), dim3(tiles * a.splitk), dim3(512), 0, s, a);
     else
-    hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, STAGES>), dim3(tiles * a.splitk), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((gemm_ws_kernel<T, OutT, STAGES, false, ABLW>), dim3(tiles * a.splitk), dim3(512), 0, s, a);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
@@ -1028,6 +1064,9 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 35: return launch_ws<T, OutT, 6>(a, s);  // ... 96 KB ring (one block per CU)
         case 36: return launch_ws<T, OutT, 5>(a, s);  // ... 80 KB ring (two blocks per CU just fit)
         case 37: return launch_ws<T, OutT, 8>(a, s);  // ... 128 KB ring
+        case 38: return launch_ws<T, OutT, 4, 1>(a, s);  // ablations of 34 (wrong results by construction)
+        case 39: return launch_ws<T, OutT, 4, 2>(a, s);
+        case 40: return launch_ws<T, OutT, 4, 3>(a, s);
         default: break;
     }
     set_error("gemm: unknown cfg %d", cfg);

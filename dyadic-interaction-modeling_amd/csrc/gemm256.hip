@@ -65,11 +65,11 @@ template <int ACT> __device__ __forceinline__ float act256(float x) {
     if (ACT == ACT_GELU_TANH) {  // same fast forms as gemm.hip's bf16 epilogue
         const float u = 0.7978845608028654f * (x + 0.044715f * (x * x * x));
         const float e = __expf(2.0f * u);
-        return x * (0.5f * (1.0f + (1.0f - 2.0f * __frcp_rn(1.0f + e))));
+        return x * (0.5f * (1.0f + (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e))));
     }
     if (ACT == ACT_GELU_ERF) {
         const float z = fabsf(x) * 0.7071067811865476f;
-        const float t = __frcp_rn(1.0f + 0.3275911f * z);
+        const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
         const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
         const float er = 1.0f - poly * __expf(-z * z);
         return 0.5f * x * (1.0f + (x < 0.f ? -er : er));

@@ -59,7 +59,8 @@ else:
     for it in range(12):
         cols += [2 + 2 * it, 3 + 2 * it]
         names += ["it %d: at the barrier" % it, "it %d: released" % it]
-    table(cols + [28, 29], names + ["main loop done", "epilogue stored"])
+    table(cols + [28, 24, 25, 26, 29], names + ["main loop done", "epilogue: arguments + bias loaded", "epilogue: activation done",
+                                                "epilogue: stores issued", "epilogue: stores acknowledged"])
     print(" loader wave 4:")
     names = ["start", "prologue DMAs issued"]
     cols = [32, 33]
