@@ -169,6 +169,23 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int mb = m0w + i * 32 + 4 * half;
+            if (rowT == 1 && a.rowadd_mode == 0 && !a.residual) {
+                // decode step (one row per clip, e.g. the fused q/k/v projection writing q and the K/V cache rows): the
+                // destination of row m is obase + m * sb; interior tiles store without per-row checks
+                OutT* p = obase + (long)mb * sg.sb;
+                if (mb + 27 < a.M) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        store_from_f32<OutT>(p + (long)((r & 3) + 8 * (r >> 2)) * sg.sb, act_fn<ACT, FAST>(acc[i][j][r] + bias_v));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = (r & 3) + 8 * (r >> 2);
+                        if (mb + off < a.M) store_from_f32<OutT>(p + (long)off * sg.sb, act_fn<ACT, FAST>(acc[i][j][r] + bias_v));
+                    }
+                }
+                continue;
+            }
             int b0, t0;
             if (rowT == 1) {
                 b0 = mb;
