@@ -162,6 +162,10 @@ struct GemmArgs {
     long slab_stride;  // elements between slabs
     int stage_out;     // set by the launcher: large-M outputs leave through LDS as 8/16-byte row-contiguous pieces
     unsigned long long* prof;  // tuning only (tools/gemm_phases.py): per-block wall-clock stamps, ABL = 3 instantiation
+    int w_tiled;       // W is stored as [N/8][ldw/BK] blocks of 8 rows x 128 B (1 KiB, contiguous): an LDS-DMA piece then reads one
+                       // contiguous KiB instead of 8 row segments (tools/ubench/cu_load_rate.hip: 122-143 vs 70-78 GB/s per CU).
+                       // gemm_ws_kernel only.  Measured: -0.2 us per decode GEMM, nothing end to end (1467 vs 1467 clips/s) -- the
+                       // model keeps row-major weights; the switch stays for tools/gemm_ab.py and the kernel test.
     int tile_map;      // set by the launcher (prefill): 1 = every XCD works on one half of the N tiles of a quarter of the
                        // M tiles, so that its share of W (N/2 x K) stays L2-resident while the A panels stream through
     int vt_pack4;      // set by the launcher: transposed (time-contiguous) segments take 4 packed rows per store

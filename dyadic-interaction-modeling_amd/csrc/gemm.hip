@@ -20,6 +20,8 @@
 
 namespace dimx {
 
+static int gemm_cfg_small();
+
 void gemm_args_init(GemmArgs& a) {
     memset(&a, 0, sizeof(a));
     a.in_dtype = DIMX_F32;
@@ -933,8 +935,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
             int n = n0 + row;
             n = n < a.N ? n : a.N - 1;
             gW[j] = W + (size_t)n * a.ldw + c * EPC + (size_t)kt0 * BK;
+            if (a.w_tiled)  // block (n / 8, k-tile) = 8 rows x 128 B, contiguous; the k-tiles of a row group follow each other
+                gW[j] = W + ((size_t)(n >> 3) * (a.ldw / BK) + kt0) * (8 * BK) + (n & 7) * BK + c * EPC;
             if (ABLW == 3) gW[j] = gA[j < LA ? j : 0];
         }
+        const int wstep = a.w_tiled ? 8 * BK : BK;  // elements from one k-tile of a piece to the next
         auto issue = [&](int kt, int buf) {
             unsigned char* base = smem + buf * TILE_BYTES;
 #pragma unroll
@@ -943,7 +948,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
                                                  (lds_void_t*)(base + (lw * LA + j) * 1024), 16, 0, 0);
 #pragma unroll
             for (int j = 0; j < LW; ++j)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(gW[j] + (size_t)kt * BK),
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gW[j] + (size_t)kt * wstep),
                                                  (lds_void_t*)(base + BM * 128 + (lw * LW + j) * 1024), 16, 0, 0);
         };
 #pragma unroll
@@ -1063,6 +1068,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 //  1: 128x128 2 stages   2: 128x128 3 stages   3: 64x64 4 stages   4: 64x64 3 stages   5: 64x64 2 stages
 //  6: 128x64 3 stages    7: 128x64 2 stages    8: 64x128 3 stages
 template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
+    DIMX_REQUIRE(!a.w_tiled || (cfg >= 34 && cfg <= 40), DIMX_ERR_ARG, "gemm: block-tiled W is read by the decode kernel only (cfg %d)", cfg);
     switch (cfg) {
         case 1: return launch_glds<T, OutT, 128, 128, 2, 2, 2>(a, s);
         case 3:
@@ -1115,11 +1121,7 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
         return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
     }
     int cfg = a.cfg;
-    // measured on MI355X: 128x128 8-wave for large M; 64x64 with a 4-deep ring for decode, loader + consumer waves
-    // (34) over the 4-wave kernel (3): qkv 10.3 -> 8.8, ff1 13.1 -> 12.1, ff2 11.9 -> 11.0 us, +1.0..1.5 % end to end on
-    // the same box; deeper rings (36: 5, 35: 6, 37: 8 slots) are slower (tools/gemm_ab.py)
-    static const int cfg_small = getenv("DIMX_GEMM_CFG_SMALL") ? atoi(getenv("DIMX_GEMM_CFG_SMALL")) : 34;
-    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : cfg_small;
+    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : gemm_cfg_small();  // measured on MI355X: 128x128 8-wave for large M
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;
@@ -1183,6 +1185,14 @@ int gemm_plan_splits(const GemmArgs& a) {
     return sp < 1 ? 1 : sp;
 }
 
+static int gemm_cfg_small() {
+    // measured on MI355X: 64x64 with a 4-deep ring for decode, loader + consumer waves (34) over the 4-wave kernel (3):
+    // qkv 10.3 -> 8.8, ff1 13.1 -> 12.1, ff2 11.9 -> 11.0 us, +1.0..1.5 % end to end on the same box; deeper rings
+    // (36: 5, 35: 6, 37: 8 slots) are slower (tools/gemm_ab.py)
+    static const int cfg_small = getenv("DIMX_GEMM_CFG_SMALL") ? atoi(getenv("DIMX_GEMM_CFG_SMALL")) : 34;
+    return cfg_small;
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int epc = a.in_dtype == DIMX_BF16 ? 8 : 4;
     const int bk = 8 * epc;
@@ -1205,6 +1215,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         DIMX_REQUIRE(a.out_dtype == DIMX_F32 && a.act == ACT_NONE && !a.residual && a.rowadd_mode == 0 && a.nseg == 1 &&
                          a.conv_T == 0 && a.K == (a.kloop ? a.kloop : a.ldw),
                      DIMX_ERR_ARG, "gemm: slab output needs a plain f32 GEMM without activation/residual");
+    if (a.w_tiled)
+        DIMX_REQUIRE(a.N % 8 == 0 && a.conv_T == 0 && !a.force_simple && a.K % bk == 0 && a.M < 4096 && a.kloop == 0, DIMX_ERR_ARG,
+                     "gemm: block-tiled W needs N %% 8 == 0, K %% %d == 0 and a decode-sized M (N=%d K=%d M=%d)", bk, a.N, a.K, a.M);
     if (a.in_dtype == DIMX_BF16) {
         if (a.cfg == 0 && gemm256_eligible(a)) return launch_gemm256(a, s);
         if (a.out_dtype == DIMX_BF16) return launch_typed<bf16, bf16>(a, s);

@@ -1789,6 +1789,7 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     g.allow_splitk = flags & 1;
     g.force_simple = (flags >> 1) & 1;
     g.out_slabs = (flags >> 2) & 1;        /* C = [splits][M, ldc] f32 slabs (split count = flags bits 16..23) */
+    g.w_tiled = (flags >> 3) & 1;          /* W in 8-row x 128-byte blocks (tools/gemm_ab.py; N % 8 == 0) */
     g.slab_stride = (long)M * ldc;
     g.cfg = (flags >> 8) & 0xff;           /* tuning: tile/stage config id */
     g.force_splitk = (flags >> 16) & 0xff; /* tuning: split count */

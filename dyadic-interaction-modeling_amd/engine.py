@@ -254,8 +254,16 @@ def _pad_k(w, mult):
     return out
 
 
+def tile_weight(w_, bk):
+    """[N, Kp] -> blocks of 8 rows x bk elements (128 B), block (n // 8, k // bk) contiguous: the layout the decode-step
+    GEMM reads with one contiguous KiB per LDS-DMA piece (GemmArgs.w_tiled)."""
+    N, Kp = w_.shape
+    assert N % 8 == 0 and Kp % bk == 0
+    return w_.view(N // 8, 8, Kp // bk, bk).permute(0, 2, 1, 3).contiguous().view(N, Kp)
+
+
 def op_gemm(a, w, bias=None, act=0, residual=None, bf16=False, out_bf16=False, conv_T=0, conv_lens=None,
-            slabs=0, force_simple=False, cfg=0):
+            slabs=0, force_simple=False, cfg=0, w_tiled=False):
     """epilogue(a[M,K] @ w[N,K]^T); conv_T > 0: a is [B*conv_T, C], w is [N, C, 5]."""
     lib = L.load()
     dev = a.device
@@ -269,12 +277,14 @@ def op_gemm(a, w, bias=None, act=0, residual=None, bf16=False, out_bf16=False, c
     dt = torch.bfloat16 if bf16 else torch.float32
     a_ = a.to(dt).contiguous()
     w_ = _pad_k(wk.to(dt), 64 if bf16 else 32)
+    if w_tiled:
+        w_ = tile_weight(w_, 64 if bf16 else 32)
     M = a_.shape[0]
     if slabs:   # split-K partial sums as `slabs` f32 slabs [slabs, M, N] (the decode-step projections)
         out = torch.full((slabs, M, N), float("nan"), dtype=torch.float32, device=dev)
     else:
         out = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=dev)
-    flags = (5 if slabs else 0) | (2 if force_simple else 0) | (cfg << 8) | (slabs << 16)
+    flags = (5 if slabs else 0) | (2 if force_simple else 0) | (8 if w_tiled else 0) | (cfg << 8) | (slabs << 16)
     L.check(lib.dimx_op_gemm(L.BF16 if bf16 else L.F32, L.BF16 if out_bf16 else L.F32, L.ptr(a_), a_.shape[1],
                              L.ptr(w_), w_.shape[1], L.ptr(out), N, M, N, K, L.ptr(bias), act, L.ptr(residual),
                              residual.shape[1] if residual is not None else 0, conv_T, L.ptr(conv_lens), flags,

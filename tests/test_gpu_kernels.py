@@ -99,6 +99,9 @@ def test_gemm_loader_consumer_kernel(dev, M, N, K, S, act, cfg, bf16):
     new = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, cfg=cfg, **kw)
     old = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, cfg=3, **kw)
     assert torch.equal(new, old)
+    if N % 8 == 0:   # the same weights in 8-row x 128-byte blocks (the decode step's layout): same bits
+        til = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, cfg=cfg, w_tiled=True, **kw)
+        assert torch.equal(til, old)
     out = new.sum(0) if S else new.float()
     assert _err(out, ref) < (0.05 if kw.get("out_bf16") else (2e-3 if bf16 else 1e-4))
 

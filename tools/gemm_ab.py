@@ -17,9 +17,13 @@ for name, N, K, act, odt, S in (("qkv", 3456, 1152, 0, L.F32, 0), ("ff1", 4608, 
                                 ("ff2 (4 slabs)", 1152, 4608, 0, L.F32, 4), ("cross-q", 1152, 1152, 0, L.F32, 0)):
     a = torch.randn(M, K, device=dev).bfloat16()
     ws = [(torch.randn(N, K, device=dev) / K ** 0.5).bfloat16() for _ in range(12)]
+    TILED = os.environ.get("GEMM_AB_TILED") == "1"
+    if TILED:
+        from dimx.engine import tile_weight
+        ws = [tile_weight(w, 64) for w in ws]
     bias = torch.randn(N, device=dev)
     out = torch.empty(max(S, 1) * M, N, device=dev, dtype=torch.bfloat16 if odt == L.BF16 else torch.float32)
-    flags = (5 | (S << 16)) if S else 0
+    flags = ((5 | (S << 16)) if S else 0) | (8 if TILED else 0)
 
     def run(i):
         L.check(lib.dimx_op_gemm(L.BF16, odt, L.ptr(a), K, L.ptr(ws[i % 12]), K, L.ptr(out), N, M, N, K, L.ptr(None if S else bias), act,
@@ -37,4 +41,4 @@ for name, N, K, act, odt, S in (("qkv", 3456, 1152, 0, L.F32, 0), ("ff1", 4608, 
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 240 * 1e3)
     res.append("%s %.2f us" % (name, best))
-print("DIMX_GEMM_CFG_SMALL=%s: back-to-back launches, best of 5: %s" % (os.environ.get("DIMX_GEMM_CFG_SMALL", "default"), ", ".join(res)))
+print("tiled W=%s " % os.environ.get("GEMM_AB_TILED", "0") + "DIMX_GEMM_CFG_SMALL=%s: back-to-back launches, best of 5: %s" % (os.environ.get("DIMX_GEMM_CFG_SMALL", "default"), ", ".join(res)))
