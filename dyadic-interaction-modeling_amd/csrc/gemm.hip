@@ -297,6 +297,17 @@ __device__ __forceinline__ void stage_copy_out(const GemmArgs& a, const unsigned
                 t -= rowT;
                 ++b;
             }
+            // the residual pieces of all NIT rows in flight together (one dependent global load per row otherwise: the
+            // f32 residual GEMMs of the encoders spent most of their epilogue waiting for them); rows past M read row M - 1
+            float4 res[NIT];
+            if (a.residual) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    int m = mb + it * RPI + crow;
+                    m = m < a.M ? m : a.M - 1;
+                    res[it] = *(const float4*)(a.residual + (size_t)m * a.ldr + nc);
+                }
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int row = it * RPI + crow;
@@ -317,7 +328,7 @@ __device__ __forceinline__ void stage_copy_out(const GemmArgs& a, const unsigned
                         v.w += q.w * a.rowadd_scale;
                     }
                     if (a.residual) {
-                        const float4 q = *(const float4*)(a.residual + (size_t)m * a.ldr + nc);
+                        const float4 q = res[it];
                         v.x += q.x;
                         v.y += q.y;
                         v.z += q.z;
