@@ -29,7 +29,7 @@ constexpr int kThreads = kWaves * 64;
 constexpr int kGroupCUs = 32;   // CUs (= blocks) per XCD
 constexpr int kGroupRows = 32;  // clips per group = one MFMA row block
 constexpr int AUX_PLAIN = 0, AUX_SC1 = 16;
-constexpr size_t kMaxDynLds = 160 * 1024 - 64;  // the kernel also has a few bytes of static LDS
+constexpr size_t kMaxDynLds = 160 * 1024 - 512;  // the kernel also has static LDS (row statistics, < 512 B)
 
 __device__ __forceinline__ unsigned xcc_id() {
     unsigned v;
@@ -140,6 +140,84 @@ __device__ __forceinline__ void reduce_store(const f32x16_t (&acc)[NCB], float* 
     }
 }
 
+// Deferred-LayerNorm form of reduce_store (ChainArgs.defer): the summed projection gets the residual of the CU's own
+// column slice (xs, loaded at kernel start with the same element mapping), x and bf16(x) are written, and the partial
+// row sums of the slice go to stats[row][2].  Thread t holds rows (t >> 5) and (t >> 5) + 16, one column per 32-lane half.
+template <int NCB>
+__device__ __forceinline__ void reduce_store_defer(const f32x16_t (&acc)[NCB], float* red, const float (&xs)[2 * NCB], float* x,
+                                                   bf16* y, int C, float* stats, int row0, int nrows, int n0, int ncols,
+                                                   int wave, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+    __syncthreads();  // every wave is done with the panels the scratch aliases
+#pragma unroll
+    for (int j = 0; j < NCB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[((wave * NCB + j) * 32 + m) * 32 + l31] = acc[j][r];
+        }
+    __syncthreads();
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2 * NCB; ++i) {
+        const int e = threadIdx.x + i * kThreads;
+        const int j = e >> 10, m = (e >> 5) & 31, n = e & 31;
+        float v = red[((0 * NCB + j) * 32 + m) * 32 + n];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[((w * NCB + j) * 32 + m) * 32 + n];
+        const int col = j * 32 + n;
+        if (col < ncols && m < nrows) {
+            const float xp = xs[i] + v;
+            const size_t o = (size_t)(row0 + m) * C + n0 + col;
+            x[o] = xp;
+            y[o].x = f32_to_bf16(xp);
+            s1[i & 1] += xp;
+            s2[i & 1] += xp * xp;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            s1[k] += __shfl_xor(s1[k], o);
+            s2[k] += __shfl_xor(s2[k], o);
+        }
+    }
+    if (l31 == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = (threadIdx.x >> 5) + 16 * k;
+            stats[2 * m] = s1[k];
+            stats[2 * m + 1] = s2[k];
+        }
+    }
+}
+
+// second projection of the deferred form: out = rstd[m] * (sum - mean[m] * colsum[col])
+template <int NCB>
+__device__ __forceinline__ void reduce_store_ln(const f32x16_t (&acc)[NCB], float* red, float* out, long ld_out, int row0,
+                                                int nrows, int n0, int ncols, const float* mr, const float* colsum, int wave,
+                                                int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NCB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[((wave * NCB + j) * 32 + m) * 32 + l31] = acc[j][r];
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NCB * 1024; e += kThreads) {
+        const int j = e >> 10, m = (e >> 5) & 31, n = e & 31;
+        float v = red[((0 * NCB + j) * 32 + m) * 32 + n];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[((w * NCB + j) * 32 + m) * 32 + n];
+        const int col = j * 32 + n;
+        if (col < ncols && m < nrows) out[(size_t)(row0 + m) * ld_out + n0 + col] = mr[2 * m + 1] * (v - mr[2 * m] * colsum[n0 + col]);
+    }
+}
+
 #define CHAIN_STAMP(i)                                                            \
     do {                                                                          \
         if (a.prof && threadIdx.x == 0) a.prof[blockIdx.x * 16 + (i)] = wall_clock64(); \
@@ -154,10 +232,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // NCB1 / NCB2: 32-column blocks of a CU's slice of the two projections.
 // Wave roles after the first group barrier: waves 0-3 normalise the CU's row, waves 4-7 stream the second
 // projection's weight slice into LDS (vmcnt is per wave, so the row's loads do not queue behind that burst).
-template <bool HAS_G1, bool HAS_G2, int NCB1, int NCB2>
+// DEFER: deferred LayerNorm (ChainArgs.defer, needs HAS_G1): no row phase, one group barrier less.
+template <bool HAS_G1, bool HAS_G2, int NCB1, int NCB2, bool DEFER = false>
 __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ float sm_s[4], sm_q[4];
+    __shared__ float sm_mr[2 * kGroupRows];  // DEFER: {mean, rstd} of the group's rows
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // The group IS the XCD the block really runs on: consecutive block ids go to consecutive XCDs, but the first block of
     // a launch does not always land on XCD 0 (the rotation continues from the previous dispatch: observed after kernels
@@ -180,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
     CHAIN_STAMP(0);
     // ---- row waves: everything of the CU's own row that is already there goes into registers now (x, gamma, the
     // split-K slabs of a preceding chip-wide GEMM, all loads in flight together); only xr has to wait for barrier 1
-    const bool own = li < nrows && wave < 4;
+    const bool own = !DEFER && li < nrows && wave < 4;
     const int row = row0 + (li < nrows ? li : 0), C = a.C;
     float* xrow = a.x + (size_t)row * C;
     float v[6], gm[6];
@@ -224,6 +304,16 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
         const int n0 = li * a.g1.cols;
         issue_panel<AUX_PLAIN>((const bf16*)a.g1.W, a.g1.ldw, n0, n0 + a.g1.cols - 1, a.g1.rows_pad, a.g1.nkt,
                                lds + a.offW1, wave, lane);
+        float xs[2 * NCB1];  // DEFER: the residual of this CU's column slice, element mapping of reduce_store_defer
+        if (DEFER) {
+#pragma unroll
+            for (int i = 0; i < 2 * NCB1; ++i) {
+                const int e = tid + i * kThreads;
+                const int j = e >> 10, m = (e >> 5) & 31, col = j * 32 + (e & 31);
+                const int mm = m < nrows ? m : nrows - 1, cc = col < a.g1.cols ? col : a.g1.cols - 1;
+                xs[i] = a.x[(size_t)(row0 + mm) * C + n0 + cc];
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         CHAIN_STAMP(1);
@@ -234,11 +324,61 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         mfma_panel<NCB1>(lds + a.offA1, lds + a.offW1, a.g1.nkt, a.g1.rows_pad, acc, wave, lane);
         CHAIN_STAMP(2);
-        reduce_store<NCB1>(acc, (float*)(lds + a.offRed1), a.xr, a.C, row0, nrows, n0, a.g1.cols, wave, lane);
-        CHAIN_STAMP(3);
+        if (DEFER) {
+            reduce_store_defer<NCB1>(acc, (float*)(lds + a.offRed1), xs, a.x, (bf16*)a.y, C,
+                                     a.stats + ((size_t)(g * kGroupCUs + li) * kGroupRows) * 2, row0, nrows, n0, a.g1.cols, wave,
+                                     lane);
+            CHAIN_STAMP(3);
+            if (tid == 0 && seen_old == stamp) atomicOr(a.err, 1u);
+            if (!HAS_G2) return;  // x, y and the partial sums are complete at the end of the launch: no group barrier
+        } else {
+            reduce_store<NCB1>(acc, (float*)(lds + a.offRed1), a.xr, a.C, row0, nrows, n0, a.g1.cols, wave, lane);
+            CHAIN_STAMP(3);
+        }
         target += kGroupCUs;
         xcd_barrier(ctr, target, a.err);
         CHAIN_STAMP(4);
+    }
+    if (DEFER) {
+        // ---- deferred form, after the only group barrier: W2 slice (waves 4-7), the un-normalised rows of the group, the
+        // 32 x 32 partial sums -> {mean, rstd} per row; second projection with the LayerNorm folded into its epilogue
+        if (wave >= 4) {
+            const int n0 = li * a.g2.cols;
+            issue_panel4<AUX_PLAIN>((const bf16*)a.g2.W, a.g2.ldw, n0, n0 + a.g2.cols - 1, a.g2.rows_pad, a.g2.nkt,
+                                    lds + a.offW2, wave - 4, lane);
+        }
+        issue_panel<AUX_SC1>((const bf16*)a.y, a.C, row0, r_last, kGroupRows, a.g2.nkt, lds + a.offA2, wave, lane);
+        {
+            const int m = tid >> 4, part = tid & 15;
+            const float* sp = a.stats + ((size_t)(g * kGroupCUs + 2 * part) * kGroupRows + m) * 2;
+            float t1 = ld_sc1_f32(sp) + ld_sc1_f32(sp + 2 * kGroupRows);
+            float t2 = ld_sc1_f32(sp + 1) + ld_sc1_f32(sp + 2 * kGroupRows + 1);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                t1 += __shfl_xor(t1, o);
+                t2 += __shfl_xor(t2, o);
+            }
+            if (part == 0) {
+                const float mean = t1 * (1.0f / C);
+                const float var = fmaxf(t2 * (1.0f / C) - mean * mean, 0.f);
+                sm_mr[2 * m] = mean;
+                sm_mr[2 * m + 1] = rsqrtf(var + 1e-5f);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CHAIN_STAMP(7);
+        f32x16_t acc[NCB2];
+#pragma unroll
+        for (int j = 0; j < NCB2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        mfma_panel<NCB2>(lds + a.offA2, lds + a.offW2, a.g2.nkt, a.g2.rows_pad, acc, wave, lane);
+        CHAIN_STAMP(8);
+        reduce_store_ln<NCB2>(acc, (float*)(lds + a.offRed2), a.out2, a.ld_out2, row0, nrows, li * a.g2.cols, a.g2.cols, sm_mr,
+                              a.colsum2, wave, lane);
+        CHAIN_STAMP(9);
+        return;
     }
 
     // ---- loader waves: the second projection's weight slice (independent of everything computed here)
@@ -396,6 +536,10 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
     const size_t lds = chain_plan(a);
     DIMX_REQUIRE(lds <= kMaxDynLds, DIMX_ERR_ARG, "chain: LDS plan %zu bytes", lds);
     a.nbar = (a.g1.W ? 1 : 0) + (a.g2.W ? 1 : 0);
+    if (a.defer) {
+        DIMX_REQUIRE(a.g1.W && a.stats && (!a.g2.W || a.colsum2), DIMX_ERR_ARG, "chain: deferred LayerNorm needs g1, stats (and colsum2)");
+        a.nbar = a.g2.W ? 1 : 0;
+    }
     dim3 grid(8 * kGroupCUs), block(kThreads);
 #define CH(G1, G2, N1, N2)                                                                                      \
     do {                                                                                                        \
@@ -403,8 +547,24 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);                      \
         hipLaunchKernelGGL((xcd_chain_kernel<G1, G2, N1, N2>), grid, block, lds, s, a);                         \
     } while (0)
+#define CHD(G2, N1, N2)                                                                                         \
+    do {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)xcd_chain_kernel<true, G2, N1, N2, true>,                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);                 \
+        hipLaunchKernelGGL((xcd_chain_kernel<true, G2, N1, N2, true>), grid, block, lds, s, a);                 \
+    } while (0)
     const int n1 = a.g1.W ? a.g1.ncb : 1, n2 = a.g2.W ? a.g2.ncb : 1;
-    if (a.g1.W && a.g2.W) {
+    if (a.defer) {
+        if (a.g2.W) {
+            if (n1 == 1 && n2 == 1) CHD(true, 1, 1);
+            else if (n1 == 2 && n2 == 1) CHD(true, 2, 1);
+            else if (n1 == 1 && n2 == 2) CHD(true, 1, 2);
+            else CHD(true, 2, 2);
+        } else {
+            if (n1 == 1) CHD(false, 1, 1);
+            else CHD(false, 2, 1);
+        }
+    } else if (a.g1.W && a.g2.W) {
         if (n1 == 1 && n2 == 1) CH(true, true, 1, 1);
         else if (n1 == 2 && n2 == 1) CH(true, true, 2, 1);
         else if (n1 == 1 && n2 == 2) CH(true, true, 1, 2);
@@ -419,6 +579,7 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
         CH(false, false, 1, 1);
     }
 #undef CH
+#undef CHD
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

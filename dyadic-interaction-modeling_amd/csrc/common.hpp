@@ -162,6 +162,12 @@ struct GemmArgs {
     long slab_stride;  // elements between slabs
     int stage_out;     // set by the launcher: large-M outputs leave through LDS as 8/16-byte row-contiguous pieces
     unsigned long long* prof;  // tuning only (tools/gemm_phases.py): per-block wall-clock stamps, ABL = 3 instantiation
+    // deferred LayerNorm of the A operand (gemm_ws_kernel only; see ChainArgs.defer): A holds bf16(x) un-normalised, W the
+    // gamma-scaled weights; acc <- rstd[m] * (acc - mean[m] * ln_colsum[n]) before bias / activation.  ln_stats =
+    // [M / 32][32][32][2] partial {sum x, sum x^2} over ln_C columns.
+    const float* ln_stats;
+    const float* ln_colsum;
+    int ln_C;
     int w_tiled;       // W is stored as [N/8][ldw/BK] blocks of 8 rows x 128 B (1 KiB, contiguous): an LDS-DMA piece then reads one
                        // contiguous KiB instead of 8 row segments (tools/ubench/cu_load_rate.hip: 122-143 vs 70-78 GB/s per CU).
                        // gemm_ws_kernel only.  Measured: -0.2 us per decode GEMM, nothing end to end (1467 vs 1467 clips/s) -- the
@@ -270,6 +276,14 @@ struct ChainArgs {
     const int32_t* step;
     unsigned* err;
     unsigned long long* prof;  // tuning only: [256 blocks][16] wall-clock stamps (100 MHz) of the phase boundaries
+    // Deferred LayerNorm (defer = 1, needs g1): the CU that owns a column slice of the first projection adds the residual
+    // itself, writes x (f32) and y = bf16(x) UN-normalised plus the partial row sums {sum x, sum x^2} of its columns into
+    // stats[group][CU][row][2]; the consumer of y multiplies with gamma-scaled weights W' = gamma o W and corrects its
+    // result: LN(x) . W^T = rstd * (x . W'^T - mean * colsum(W')).  No row phase and no second group barrier; with no
+    // second projection the kernel has no group barrier at all (the next launch -- ff1 -- is the consumer).
+    int defer;
+    float* stats;            // [8][32][32][2] f32
+    const float* colsum2;    // [g2.N] f32: row sums of the gamma-scaled second projection (defer && g2)
     int nbar;                                                // set by the launcher
     int offA1, offW1, offRed1, offA2, offW2, offRed2;        // LDS plan, set by the launcher
 };

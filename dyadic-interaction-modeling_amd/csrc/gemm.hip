@@ -994,6 +994,19 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
     f32x16_t acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    // deferred LayerNorm of the A rows (GemmArgs.ln_stats): lane l gathers half of the 32 per-CU partial sums of row
+    // wm * 32 + (l >> 1); the loads fly during the main loop, the correction runs on the accumulators before the epilogue
+    float ln_s1 = 0.f, ln_s2 = 0.f, ln_cs = 0.f;
+    float2 ln_p[16];
+    if (a.ln_stats) {
+        int m = m0 + wm * 32 + (lane >> 1);
+        m = m < a.M ? m : a.M - 1;
+        const float2* sp = (const float2*)a.ln_stats + ((size_t)(m >> 5) * 32 + (lane & 1) * 16) * 32 + (m & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ln_p[i] = sp[(size_t)i * 32];
+        const int n = n0 + wn * 32 + l31;
+        ln_cs = a.ln_colsum[n < a.N ? n : a.N - 1];
+    }
     for (int it = 0; it < nk; ++it) {
         const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
         if (it < 12) stamp(2 + 2 * it);
@@ -1017,6 +1030,24 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
         }
     }
     stamp(28);
+    if (a.ln_stats) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ln_s1 += ln_p[i].x;
+            ln_s2 += ln_p[i].y;
+        }
+        ln_s1 += __shfl_xor(ln_s1, 1);
+        ln_s2 += __shfl_xor(ln_s2, 1);
+        const float inv_c = 1.0f / (float)a.ln_C;
+        const float mean = ln_s1 * inv_c;
+        const float rstd = rsqrtf(fmaxf(ln_s2 * inv_c - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;  // lanes 2 * row, 2 * row + 1 hold that row's statistics
+            const float mr = __shfl(mean, 2 * row), rr = __shfl(rstd, 2 * row);
+            acc[0][0][r] = rr * (acc[0][0][r] - mr * ln_cs);
+        }
+    }
     epilogue<T, OutT, 1, 1>(a, acc, m0 + wm * 32, n0 + wn * 32, half, l31, split,
                             (PROF && wave == 0 && lane == 0) ? a.prof + (size_t)blockIdx.x * 64 : nullptr);
     if (PROF) {
@@ -1080,6 +1111,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 //  6: 128x64 3 stages    7: 128x64 2 stages    8: 64x128 3 stages
 template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
     DIMX_REQUIRE(!a.w_tiled || (cfg >= 34 && cfg <= 40), DIMX_ERR_ARG, "gemm: block-tiled W is read by the decode kernel only (cfg %d)", cfg);
+    DIMX_REQUIRE(!a.ln_stats || (cfg >= 34 && cfg <= 37 && a.splitk == 1 && a.ln_colsum && a.ln_C > 0), DIMX_ERR_ARG,
+                 "gemm: the deferred-LayerNorm epilogue exists in the decode kernel only, without split-K (cfg %d)", cfg);
     switch (cfg) {
         case 1: return launch_glds<T, OutT, 128, 128, 2, 2, 2>(a, s);
         case 3:

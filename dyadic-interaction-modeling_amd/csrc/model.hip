@@ -256,6 +256,41 @@ static int pack_linear(dimx_ctx* c, const std::vector<std::string>& parts, const
     return DIMX_OK;
 }
 
+// W' = gamma o W (columns scaled by the LayerNorm weight that precedes the projection) in bf16, plus the f32 row sums of
+// the ROUNDED W': LN(x) . W^T = rstd * (x . W'^T - mean * colsum(W')) (deferred LayerNorm of the decode step, bf16 mode)
+static int pack_linear_scaled(dimx_ctx* c, const std::string& wname, const std::string& gname, const std::string& bias,
+                              Linear* out, const float** colsum) {
+    auto wi = c->host.find(wname), gi = c->host.find(gname);
+    DIMX_REQUIRE(wi != c->host.end() && gi != c->host.end(), DIMX_ERR_WEIGHT, "missing weight %s / %s", wname.c_str(), gname.c_str());
+    const int N = (int)wi->second.shape[0], K = (int)wi->second.shape[1];
+    DIMX_REQUIRE((int)gi->second.data.size() == K && K % 64 == 0, DIMX_ERR_WEIGHT, "%s: gamma / K mismatch", wname.c_str());
+    std::vector<uint16_t> wb((size_t)N * K);
+    std::vector<float> cs(N);
+    for (int n = 0; n < N; ++n) {
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const uint16_t b = host_f32_to_bf16(wi->second.data[(size_t)n * K + k] * gi->second.data[k]);
+            wb[(size_t)n * K + k] = b;
+            const uint32_t u = (uint32_t)b << 16;
+            float f;
+            memcpy(&f, &u, 4);
+            acc += f;
+        }
+        cs[n] = (float)acc;
+    }
+    void *p, *q;
+    DIMX_TRY(dev_upload(c, wb.data(), wb.size() * 2, &p));
+    DIMX_TRY(dev_upload(c, cs.data(), cs.size() * 4, &q));
+    out->w = p;
+    out->N = N;
+    out->K = K;
+    out->Kp = K;
+    out->bias = nullptr;
+    if (!bias.empty()) DIMX_TRY(upload_f32(c, bias, &out->bias));
+    *colsum = (const float*)q;
+    return DIMX_OK;
+}
+
 static int pack_vq(dimx_ctx* c, int which) {
     VQNet& v = c->vq[which];
     const VQGeom& vg = c->vqg[which];
@@ -419,6 +454,13 @@ static int ensure_packed(dimx_ctx* c, int need) {
                 DIMX_TRY(pack_xattn(c, xl(dp, 3 * i), false, &c->dec.self_[i]));
                 DIMX_TRY(pack_xattn(c, xl(dp, 3 * i + 1), true, &c->dec.cross[i]));
                 DIMX_TRY(pack_xff(c, xl(dp, 3 * i + 2), &c->dec.ff[i]));
+                if (c->at == DIMX_BF16 && c->decg.dim % 64 == 0) {
+                    const std::string cp = xl(dp, 3 * i + 1), fp = xl(dp, 3 * i + 2);
+                    DIMX_TRY(pack_linear_scaled(c, cp + "1.to_q.weight", cp + "0.0.weight", "", &c->dec.cross[i].q_ln,
+                                                &c->dec.cross[i].q_ln_colsum));
+                    DIMX_TRY(pack_linear_scaled(c, fp + "1.ff.0.0.weight", fp + "0.0.weight", fp + "1.ff.0.0.bias",
+                                                &c->dec.ff[i].f1_ln, &c->dec.ff[i].f1_ln_colsum));
+                }
             }
             DIMX_TRY(upload_f32(c, dp + "attn_layers.final_norm.weight", &c->dec.final_g));
             DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, "", false, &c->dec.logits));
@@ -710,6 +752,7 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     c->use_graph = (ng && ng[0] == '1') ? 0 : 1;
     const char* nc = getenv("DIMX_NO_CHAIN");
     c->use_chain = (nc && nc[0] == '1') ? 0 : 1;
+    c->defer_ln = getenv("DIMX_NO_DEFER_LN") ? 0 : 1;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess) c->cu_count = cus;
@@ -732,6 +775,7 @@ int dimx_destroy(dimx_handle h) {
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->chain_err_ev) (void)hipEventDestroy(h->chain_err_ev);
     if (h->chain_err_dev) (void)hipFree(h->chain_err_dev);
+    if (h->chain_stats_dev) (void)hipFree(h->chain_stats_dev);
     if (h->chain_err_host) (void)hipHostFree(h->chain_err_host);
     free_packed(h);
     delete h;
@@ -1528,11 +1572,19 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     };
     // XCD-local chain kernels (chain.hip) replace {projection, residual + LayerNorm, projection} triples by one launch
     const bool chain = gen_use_chain(h, B, S, grp);
+    // deferred LayerNorm (chain.hip): the two chain launches of a layer write x and bf16(x) un-normalised + partial row
+    // sums; cross-q (inside chain A) and ff1 (the next launch) run on gamma-scaled weights and correct their results
+    const bool defer = chain && h->defer_ln && h->chain_stats_dev && h->dec.cross[0].q_ln.w && h->dec.ff[0].f1_ln.w;
     auto chain_site = [&](int site, const void* A1, int lda1, const Linear* W1, int nslab, const float* gamma,
-                          const Linear* W2, float* out2, int ld_out2) -> int {
+                          const Linear* W2, float* out2, int ld_out2, const float* colsum2 = nullptr) -> int {
         ChainArgs c;
         memset(&c, 0, sizeof(c));
         c.B = B;
+        if (defer && W1) {
+            c.defer = 1;
+            c.stats = h->chain_stats_dev;
+            c.colsum2 = colsum2;
+        }
         if (W1) {
             c.g1.W = W1->w;
             c.g1.N = W1->N;
@@ -1591,8 +1643,12 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         a.scale = scale;
         DIMX_TRY(launch_decode_attn(a, st));
         if (chain) {  // self out-projection -> x += . -> LayerNorm -> cross q-projection
-            DIMX_TRY(chain_site(3 * l, s.o, inner, &h->dec.self_[l].out, 0, h->dec.cross[l].ln_g, &h->dec.cross[l].qkv,
-                                s.qc, inner));
+            if (defer)
+                DIMX_TRY(chain_site(3 * l, s.o, inner, &h->dec.self_[l].out, 0, h->dec.cross[l].ln_g, &h->dec.cross[l].q_ln,
+                                    s.qc, inner, h->dec.cross[l].q_ln_colsum));
+            else
+                DIMX_TRY(chain_site(3 * l, s.o, inner, &h->dec.self_[l].out, 0, h->dec.cross[l].ln_g, &h->dec.cross[l].qkv,
+                                    s.qc, inner));
             ns = 1;
         } else {
             DIMX_TRY(slab_gemm(s.o, inner, h->dec.self_[l].out, s.xr, s0.st_xr, &pending));
@@ -1625,7 +1681,12 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
             DIMX_TRY(slab_gemm(s.o, inner, h->dec.cross[l].out, s.xr, s0.st_xr, &pending));
             DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.ff[l].ln_g, B, DD, st));
         }
-        gemm_lin(h, s.y, DD, h->dec.ff[l].f1, B, g);
+        gemm_lin(h, s.y, DD, defer ? h->dec.ff[l].f1_ln : h->dec.ff[l].f1, B, g);
+        if (defer) {
+            g.ln_stats = h->chain_stats_dev;
+            g.ln_colsum = h->dec.ff[l].f1_ln_colsum;
+            g.ln_C = DD;
+        }
         g.out_dtype = h->at;
         g.act = ACT_GELU_ERF;
         gemm_set_plain_out(g, s.f, DD * dg.ff_mult);
@@ -1671,6 +1732,8 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     if (h->use_chain && h->at == DIMX_BF16 && !h->chain_err_dev) {
         DIMX_HIP(hipMalloc((void**)&h->chain_err_dev, 64));
         DIMX_HIP(hipMemset(h->chain_err_dev, 0, 64));
+        DIMX_HIP(hipMalloc((void**)&h->chain_stats_dev, 8 * 32 * 32 * 2 * sizeof(float)));
+        DIMX_HIP(hipMemset(h->chain_stats_dev, 0, 8 * 32 * 32 * 2 * sizeof(float)));
         DIMX_HIP(hipHostMalloc((void**)&h->chain_err_host, 64, hipHostMallocDefault));
         *h->chain_err_host = 0;
         DIMX_HIP(hipEventCreateWithFlags(&h->chain_err_ev, hipEventDisableTiming));
@@ -1962,6 +2025,59 @@ int dimx_op_chain(const void* A1, int K1, const void* W1, float* x, const float*
     DIMX_HIP(hipMemsetAsync(u, 0, 512 * 4, (hipStream_t)stream));
     if (getenv("DIMX_CHAIN_PROF")) c.prof = (unsigned long long*)(u + 512 + (size_t)B * C);  // tools/chain_phases.py
     return launch_chain(c, (hipStream_t)stream);
+}
+
+int dimx_op_chain_ln(const void* A1, int K1, const void* W1, float* x, void* y, float* stats, const void* W2s,
+                     const float* colsum2, int N2, float* out2, int B, int C, void* scratch, void* stream) {
+    DIMX_REQUIRE(scratch && x && y && stats && A1 && W1, DIMX_ERR_ARG, "op_chain_ln: null argument");
+    int dev = 0, cus = 0;
+    DIMX_HIP(hipGetDevice(&dev));
+    DIMX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    ChainArgs c;
+    memset(&c, 0, sizeof(c));
+    unsigned* u = (unsigned*)scratch;
+    c.B = B;
+    c.C = C;
+    c.g1.W = W1; c.g1.N = C; c.g1.K = K1; c.g1.ldw = K1;
+    c.A1 = A1; c.lda1 = K1;
+    c.xr = (float*)(u + 512);
+    c.x = x;
+    c.y = y;
+    c.gamma = (const float*)x;  /* unused by the deferred form, must be non-null */
+    c.defer = 1;
+    c.stats = stats;
+    if (W2s) {
+        c.g2.W = W2s; c.g2.N = N2; c.g2.K = C; c.g2.ldw = C;
+        c.out2 = out2; c.ld_out2 = N2;
+        c.colsum2 = colsum2;
+    }
+    c.counters = u;
+    c.seen = u + 256;
+    c.step = (const int32_t*)(u + 128);
+    c.err = u + 129;
+    DIMX_REQUIRE(chain_supported(c, cus), DIMX_ERR_ARG, "op_chain_ln: shape not supported on this device (%d CUs)", cus);
+    DIMX_HIP(hipMemsetAsync(u, 0, 512 * 4, (hipStream_t)stream));
+    if (getenv("DIMX_CHAIN_PROF")) c.prof = (unsigned long long*)(u + 512 + (size_t)B * C);
+    return launch_chain(c, (hipStream_t)stream);
+}
+
+int dimx_op_gemm_ln(int out_dtype, const void* A, const void* Ws, void* C, int M, int N, int K, const float* bias, int act,
+                    const float* stats, const float* colsum, void* stream) {
+    DIMX_REQUIRE(A && Ws && C && stats && colsum && M >= 1 && M <= 256, DIMX_ERR_ARG, "op_gemm_ln: bad argument");
+    GemmArgs g;
+    gemm_args_init(g);
+    g.in_dtype = DIMX_BF16;
+    g.out_dtype = out_dtype;
+    g.A = A; g.lda = K;
+    g.W = Ws; g.ldw = K;
+    g.M = M; g.N = N; g.K = K;
+    g.bias = bias;
+    g.act = act;
+    g.ln_stats = stats;
+    g.ln_colsum = colsum;
+    g.ln_C = K;
+    gemm_set_plain_out(g, C, N);
+    return launch_gemm(g, (hipStream_t)stream);
 }
 
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise, uint64_t seed,

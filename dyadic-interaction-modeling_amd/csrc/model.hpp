@@ -36,10 +36,16 @@ struct XAttn {
     Linear qkv;  // self: fused [3*inner][dim]; cross: q only [inner][dim]
     Linear kv;   // cross: fused [2*inner][dim]
     Linear out;
+    // decoder cross attention, bf16 mode: q projection with the pre-norm's gamma folded in (W' = gamma o W) and the row
+    // sums of W' -- the deferred-LayerNorm form of the decode step (ChainArgs.defer)
+    Linear q_ln;
+    const float* q_ln_colsum = nullptr;
 };
 struct XFF {
     const float* ln_g;
     Linear f1, f2;
+    Linear f1_ln;  // decoder, bf16 mode: gamma-scaled first projection + row sums (GemmArgs.ln_stats)
+    const float* f1_ln_colsum = nullptr;
 };
 struct XEnc {
     Linear proj_in;
@@ -146,6 +152,8 @@ struct dimx_ctx {
     // XCD-local chain kernels of the decode step (chain.hip): bf16 mode, one sample per clip, 256-CU device
     int use_chain = 1;                  // DIMX_NO_CHAIN=1 keeps the one-kernel-per-op step
     int cu_count = 0;
+    float* chain_stats_dev = nullptr;   // [8][32][32][2] partial row sums of the deferred-LayerNorm chain kernels
+    int defer_ln = 1;                   // DIMX_NO_DEFER_LN=1 keeps the row-phase LayerNorm inside the chain kernels
     unsigned* chain_err_dev = nullptr;  // bit 0: two blocks claimed one (XCD, CU slot), bit 1: a group barrier timed out
     unsigned* chain_err_host = nullptr; // pinned copy, refreshed at the end of every generate call
     hipEvent_t chain_err_ev = nullptr;

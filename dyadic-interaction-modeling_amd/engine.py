@@ -360,6 +360,38 @@ def op_chain(x, gamma, a1=None, w1=None, slabs=None, w2=None):
     return y, out2
 
 
+def op_chain_ln(x, a1, w1, w2s=None, colsum2=None):
+    """Deferred-LayerNorm chain launch: x [B,C] f32 += a1 . w1^T in place; returns (y = bf16(x) [B,C], stats [8,32,32,2],
+    out2 [B,N2] or None) with out2 = LayerNorm(x) * gamma . W2^T when w2s = gamma o W2 (bf16) and colsum2 = w2s row sums."""
+    lib = L.load()
+    dev = x.device
+    B, C = x.shape
+    a1, w1 = a1.to(torch.bfloat16).contiguous(), w1.to(torch.bfloat16).contiguous()
+    y = torch.empty(B, C, dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros(8, 32, 32, 2, dtype=torch.float32, device=dev)
+    out2 = torch.empty(B, w2s.shape[0], dtype=torch.float32, device=dev) if w2s is not None else None
+    scratch = torch.zeros(512 + B * C, dtype=torch.int32, device=dev)
+    L.check(lib.dimx_op_chain_ln(L.ptr(a1), a1.shape[1], L.ptr(w1), L.ptr(x), L.ptr(y), L.ptr(stats), L.ptr(w2s),
+                                 L.ptr(colsum2), w2s.shape[0] if w2s is not None else 0, L.ptr(out2), B, C, L.ptr(scratch),
+                                 L.stream_ptr(dev)), "dimx_op_chain_ln")
+    torch.cuda.synchronize(dev)
+    flags = int(scratch[129].item())
+    if flags:
+        raise L.DimxError("chain kernel error flags 0x%x (1 = (XCD, slot) claimed twice, 2 = group barrier timeout)" % flags)
+    return y, stats, out2
+
+
+def op_gemm_ln(a, ws, stats, colsum, bias=None, act=0, out_bf16=False):
+    """act(LayerNorm-corrected a . ws^T + bias): a = bf16(x) un-normalised, ws = gamma o W (bf16), stats from op_chain_ln."""
+    lib = L.load()
+    M, K = a.shape
+    N = ws.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    L.check(lib.dimx_op_gemm_ln(L.BF16 if out_bf16 else L.F32, L.ptr(a), L.ptr(ws), L.ptr(out), M, N, K, L.ptr(bias), act,
+                                L.ptr(stats), L.ptr(colsum), L.stream_ptr(a.device)), "dimx_op_gemm_ln")
+    return out
+
+
 def op_decode_attn(q, kcache, vcache, n_keys, scale, kmask=None, nsplit=0):
     """q [B,H*64]; kcache/vcache [B,H,Tmax,64] (f32 or bf16) -> [B,H*64]."""
     lib = L.load()

@@ -88,6 +88,10 @@ SIGNATURES = {
                                             c_int, c_void_p]),
     "dimx_op_chain": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                               c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dimx_op_chain_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dimx_op_gemm_ln": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                c_void_p, c_void_p]),
     "dimx_op_sample": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p,
                                c_void_p]),
 }

@@ -246,6 +246,17 @@ int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int
  * claimed the same (XCD, CU slot), bit 1 = a group barrier timed out). */
 int dimx_op_chain(const void* A1, int K1, const void* W1, float* x, const float* slabs, int nslab, const float* gamma,
                   void* y, const void* W2, int N2, float* out2, int B, int C, void* scratch, void* stream);
+/* Deferred-LayerNorm form of the chain launch (what generate() runs in the bf16 mode):
+ *   x[B,C] += A1[B,K1] . W1[C,K1]^T ;  y = bf16(x) (NOT normalised) ;  stats[8][32][32][2] = partial {sum x, sum x^2} per
+ *   (row group, CU, row) ;  [W2s != NULL]  out2[B,N2] = rstd * (y . W2s^T - mean * colsum2), i.e. LayerNorm(x) * gamma . W2^T
+ *   for W2s = gamma o W2 (columns scaled) and colsum2[n] = sum_k W2s[n][k].  scratch / error flags as dimx_op_chain. */
+int dimx_op_chain_ln(const void* A1, int K1, const void* W1, float* x, void* y, float* stats, const void* W2s,
+                     const float* colsum2, int N2, float* out2, int B, int C, void* scratch, void* stream);
+/* C[M,N] = act(LayerNorm-corrected A . Ws^T + bias): the consumer side of dimx_op_chain_ln (decode-step ff1).  A = bf16(x)
+ * un-normalised [M,K], Ws = gamma o W bf16 [N,K], stats as written by dimx_op_chain_ln over K columns, colsum[n] = sum_k
+ * Ws[n][k]; out_dtype DIMX_BF16 / DIMX_F32; M <= 256. */
+int dimx_op_gemm_ln(int out_dtype, const void* A, const void* Ws, void* C, int M, int N, int K, const float* bias, int act,
+                    const float* stats, const float* colsum, void* stream);
 /* tokens = sampler(logits[R,512]) -- see dimx_generate. */
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise,
                    uint64_t seed, uint64_t step, int32_t* tokens, void* stream);

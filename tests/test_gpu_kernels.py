@@ -280,6 +280,59 @@ def test_chain_kernels_match_torch(B):
     assert torch.equal(x1, x2) and torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
 
 
+@pytest.mark.parametrize("B", [256, 200, 33, 8])
+def test_chain_deferred_layernorm_matches_torch(B):
+    """The deferred-LayerNorm form of the decode step (chain.hip defer = 1 + the decode GEMM's ln epilogue): the chain writes
+    x and bf16(x) un-normalised with partial row sums; q-projection (inside the chain) and ff1 (next launch) run on
+    gamma-scaled weights and must equal LayerNorm(x) * gamma . W^T; a mean far from zero is included."""
+    from dimx import engine
+    torch.manual_seed(B + 1)
+    dev = torch.device("cuda:0")
+    C, K1, N2, NF = 1152, 768, 768, 4608
+    a1 = torch.randn(B, K1, device=dev)
+    w1 = torch.randn(C, K1, device=dev) / K1 ** 0.5
+    w2 = torch.randn(N2, C, device=dev) / C ** 0.5
+    wf = torch.randn(NF, C, device=dev) / C ** 0.5
+    bf = torch.randn(NF, device=dev)
+    gamma = torch.rand(C, device=dev) * 0.4 + 0.8
+    x0 = torch.randn(B, C, device=dev) * 1.5 + 0.7            # row means ~0.7 at a standard deviation of ~1.8
+    w2s = (w2 * gamma).bfloat16()
+    wfs = (wf * gamma).bfloat16()
+    cs2, csf = w2s.float().sum(1).contiguous(), wfs.float().sum(1).contiguous()
+
+    rx = x0.double() + a1.bfloat16().double() @ w1.bfloat16().double().t()
+    ln = torch.nn.functional.layer_norm(rx, (C,), gamma.double(), None, 1e-5)
+    ro2 = ln @ w2.double().t()
+    rof = torch.nn.functional.gelu(ln @ wf.double().t() + bf.double())
+
+    # {out-projection, residual, q-projection with the LayerNorm folded in}
+    x = x0.clone()
+    y, stats, out2 = engine.op_chain_ln(x, a1, w1, w2s, cs2)
+    assert (x.double() - rx).abs().max() < 2e-4, "residual stream"
+    assert torch.equal(y, x.bfloat16()), "y is the rounded residual stream"
+    s1 = stats[:(B + 31) // 32].sum(1)                      # [groups, 32 rows, 2]
+    got = s1.reshape(-1, 2)[:B].double()
+    assert (got[:, 0] - rx.sum(1)).abs().max() < 2e-2 and ((got[:, 1] - (rx * rx).sum(1)) / (rx * rx).sum(1)).abs().max() < 1e-5
+    e2 = (out2.double() - ro2).abs().max().item()
+    assert e2 < 4e-2, "q projection of the normalised row: %g" % e2   # bf16 operands, K = 1152
+    # {out-projection, residual} + ff1 with the ln epilogue
+    x = x0.clone()
+    y, stats, none = engine.op_chain_ln(x, a1, w1)
+    assert none is None and (x.double() - rx).abs().max() < 2e-4
+    f = engine.op_gemm_ln(y, wfs, stats, csf, bias=bf, act=3, out_bf16=True)
+    ef = (f.float().double() - rof).abs().max().item()
+    assert ef < 6e-2, "ff1 of the normalised row: %g" % ef
+    # against the same arithmetic done in float64 on the kernel's own bf16 operands: only summation order + bf16 output rounding
+    mean, var = rx.mean(1, keepdim=True), rx.var(1, unbiased=False, keepdim=True)
+    own = (y.double() @ w2s.double().t() - mean * cs2.double()) / torch.sqrt(var + 1e-5)
+    assert (out2.double() - own).abs().max() < 2e-3
+    # determinism
+    xa, xb = x0.clone(), x0.clone()
+    ra = engine.op_chain_ln(xa, a1, w1, w2s, cs2)
+    rb = engine.op_chain_ln(xb, a1, w1, w2s, cs2)
+    assert torch.equal(xa, xb) and torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2])
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 384), (8192, 384, 1536), (4096 + 256 * 3, 1152, 448), (6000, 768, 64)])
 def test_gemm256_prefill_kernel(M, N, K):
     """csrc/gemm256.hip (phase-pipelined 256 x 256 kernel, taken for M >= 4096): plain / bias + GELU / f32 residual
