@@ -336,17 +336,38 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
             CHAIN_STAMP(3);
         }
         target += kGroupCUs;
-        xcd_barrier(ctr, target, a.err);
+        if (DEFER) {
+            // the group barrier, with the W2 slice requested between the arrival and the wait (there is no row phase to hide
+            // that burst behind any more): stores drained by every thread, block meets, waves 4-7 issue the DMAs, thread 0
+            // arrives and polls, the block meets again WITHOUT draining vmcnt
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wave >= 4) {
+                const int n2 = li * a.g2.cols;
+                issue_panel4<AUX_PLAIN>((const bf16*)a.g2.W, a.g2.ldw, n2, n2 + a.g2.cols - 1, a.g2.rows_pad, a.g2.nkt,
+                                        lds + a.offW2, wave - 4, lane);
+            }
+            if (tid == 0) {
+                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while ((int)(ld_sc1_u32(ctr) - target) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    if (spins > (1u << 20) || ((spins & 1023u) == 0 && (ld_sc1_u32(a.err) & 2u))) {
+                        atomicOr(a.err, 2u);
+                        break;
+                    }
+                }
+            }
+            lds_barrier();
+        } else {
+            xcd_barrier(ctr, target, a.err);
+        }
         CHAIN_STAMP(4);
     }
     if (DEFER) {
-        // ---- deferred form, after the only group barrier: W2 slice (waves 4-7), the un-normalised rows of the group, the
-        // 32 x 32 partial sums -> {mean, rstd} per row; second projection with the LayerNorm folded into its epilogue
-        if (wave >= 4) {
-            const int n0 = li * a.g2.cols;
-            issue_panel4<AUX_PLAIN>((const bf16*)a.g2.W, a.g2.ldw, n0, n0 + a.g2.cols - 1, a.g2.rows_pad, a.g2.nkt,
-                                    lds + a.offW2, wave - 4, lane);
-        }
+        // ---- deferred form, after the only group barrier: the un-normalised rows of the group, the 32 x 32 partial sums ->
+        // {mean, rstd} per row; second projection with the LayerNorm folded into its epilogue
         issue_panel<AUX_SC1>((const bf16*)a.y, a.C, row0, r_last, kGroupRows, a.g2.nkt, lds + a.offA2, wave, lane);
         {
             const int m = tid >> 4, part = tid & 15;

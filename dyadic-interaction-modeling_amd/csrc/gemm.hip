@@ -891,6 +891,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
     constexpr int TILE_BYTES = (BM + BN) * 128;
     static_assert(STAGES >= 3 && (STAGES - 1) * LPT < 64, "ring depth");
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float ln_sm[4][64];  // deferred LayerNorm: {mean[32], rstd[32]} per consumer wave
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -995,23 +996,26 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
     // deferred LayerNorm of the A rows (GemmArgs.ln_stats): lane l gathers half of the 32 per-CU partial sums of row
-    // wm * 32 + (l >> 1); the loads fly during the main loop, the correction runs on the accumulators before the epilogue
+    // wm * 32 + (l & 31) -- one load instruction reads two contiguous 256-byte runs (the 32 rows of two CUs); the loads fly
+    // during the main loop, the correction runs on the accumulators before the epilogue
     float ln_s1 = 0.f, ln_s2 = 0.f, ln_cs = 0.f;
     float2 ln_p[16];
-    if (a.ln_stats) {
-        int m = m0 + wm * 32 + (lane >> 1);
-        m = m < a.M ? m : a.M - 1;
-        const float2* sp = (const float2*)a.ln_stats + ((size_t)(m >> 5) * 32 + (lane & 1) * 16) * 32 + (m & 31);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ln_p[i] = sp[(size_t)i * 32];
-        const int n = n0 + wn * 32 + l31;
-        ln_cs = a.ln_colsum[n < a.N ? n : a.N - 1];
-    }
     for (int it = 0; it < nk; ++it) {
         const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
         if (it < 12) stamp(2 + 2 * it);
         __builtin_amdgcn_s_barrier();
         if (ABLW == 1) continue;
+        if (it == 0 && a.ln_stats) {
+            // requested once the prologue tiles have landed (the loaders' first DMAs are the kernel's critical path), in
+            // flight during the rest of the loop
+            int m = m0 + wm * 32 + l31;
+            m = m < a.M ? m : a.M - 1;
+            const float2* sp = (const float2*)a.ln_stats + ((size_t)(m >> 5) * 32 + half * 16) * 32 + (m & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ln_p[i] = sp[(size_t)i * 32];
+            const int n = n0 + wn * 32 + l31;
+            ln_cs = a.ln_colsum[n < a.N ? n : a.N - 1];
+        }
         if (it < 12) stamp(3 + 2 * it);
         u32x4_t fa[4][1], fw[4][1];
 #pragma unroll
@@ -1036,16 +1040,26 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
             ln_s1 += ln_p[i].x;
             ln_s2 += ln_p[i].y;
         }
-        ln_s1 += __shfl_xor(ln_s1, 1);
-        ln_s2 += __shfl_xor(ln_s2, 1);
+        ln_s1 += __shfl_xor(ln_s1, 32);
+        ln_s2 += __shfl_xor(ln_s2, 32);
         const float inv_c = 1.0f / (float)a.ln_C;
         const float mean = ln_s1 * inv_c;
         const float rstd = rsqrtf(fmaxf(ln_s2 * inv_c - mean * mean, 0.f) + 1e-5f);
+        // lane l holds the statistics of row l & 31, an accumulator register those of rows 8q + 4 half + (0..3): through a
+        // private 256-byte LDS strip, 8 ds_read_b128 instead of 32 ds_bpermute
+        float* strip = ln_sm[wave];
+        if (half == 0) {
+            strip[l31] = mean;
+            strip[32 + l31] = rstd;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;  // lanes 2 * row, 2 * row + 1 hold that row's statistics
-            const float mr = __shfl(mean, 2 * row), rr = __shfl(rstd, 2 * row);
-            acc[0][0][r] = rr * (acc[0][0][r] - mr * ln_cs);
+        for (int q = 0; q < 4; ++q) {
+            const float4 mq = *(const float4*)(strip + 8 * q + 4 * half);
+            const float4 rq = *(const float4*)(strip + 32 + 8 * q + 4 * half);
+            acc[0][0][4 * q + 0] = rq.x * (acc[0][0][4 * q + 0] - mq.x * ln_cs);
+            acc[0][0][4 * q + 1] = rq.y * (acc[0][0][4 * q + 1] - mq.y * ln_cs);
+            acc[0][0][4 * q + 2] = rq.z * (acc[0][0][4 * q + 2] - mq.z * ln_cs);
+            acc[0][0][4 * q + 3] = rq.w * (acc[0][0][4 * q + 3] - mq.w * ln_cs);
         }
     }
     epilogue<T, OutT, 1, 1>(a, acc, m0 + wm * 32, n0 + wn * 32, half, l31, split,

@@ -41,4 +41,31 @@ for name, N, K, act, odt, S in (("qkv", 3456, 1152, 0, L.F32, 0), ("ff1", 4608, 
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 240 * 1e3)
     res.append("%s %.2f us" % (name, best))
+# ff1 with the deferred-LayerNorm epilogue (GemmArgs.ln_stats) against the plain ff1 above
+N, K = 4608, 1152
+a = torch.randn(M, K, device=dev).bfloat16()
+ws = [(torch.randn(N, K, device=dev) / K ** 0.5).bfloat16() for _ in range(12)]
+bias = torch.randn(N, device=dev)
+cs = torch.randn(N, device=dev)
+stats = torch.rand(8, 32, 32, 2, device=dev) + 1.0
+out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+
+
+def run_ln(i):
+    L.check(lib.dimx_op_gemm_ln(L.BF16, L.ptr(a), L.ptr(ws[i % 12]), L.ptr(out), M, N, K, L.ptr(bias), 3, L.ptr(stats), L.ptr(cs),
+                                L.stream_ptr(dev)), "gemm_ln")
+
+
+for i in range(24):
+    run_ln(i)
+torch.cuda.synchronize()
+best = 1e9
+for rep in range(5):
+    e0.record()
+    for i in range(240):
+        run_ln(i)
+    e1.record()
+    torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) / 240 * 1e3)
+res.append("ff1 + ln epilogue %.2f us" % best)
 print("tiled W=%s " % os.environ.get("GEMM_AB_TILED", "0") + "DIMX_GEMM_CFG_SMALL=%s: back-to-back launches, best of 5: %s" % (os.environ.get("DIMX_GEMM_CFG_SMALL", "default"), ", ".join(res)))

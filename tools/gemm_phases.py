@@ -13,12 +13,14 @@ import dimx  # noqa
 from dimx import lib as L
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+LN = len(sys.argv) > 2 and sys.argv[2] == "ln"   # the deferred-LayerNorm epilogue of ff1 (dimx_op_gemm_ln; cfg 34 only)
 lib = L.load()
 dev = torch.device("cuda:0")
 M, N, K = 256, 4608, 1152
 a = torch.randn(M, K, device=dev).bfloat16()
 ws = [(torch.randn(N, K, device=dev) / K ** 0.5).bfloat16() for _ in range(6)]
 bias = torch.randn(N, device=dev)
+stats = torch.rand(8, 32, 32, 2, device=dev) + 1.0
 out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 nblk = (M // 64) * (N // 64)
 SL = 32 if cfg == 3 else 64
@@ -27,8 +29,12 @@ acc = torch.zeros(nblk, SL, dtype=torch.float64)
 n = 0
 for i in range(20):
     prof.zero_()
-    L.check(lib.dimx_op_gemm(L.BF16, L.BF16, L.ptr(a), K, L.ptr(ws[i % 6]), K, L.ptr(out), N, M, N, K, L.ptr(bias), 3,
-                             L.ptr(prof), N, 0, None, cfg << 8, L.stream_ptr(dev)), "gemm")
+    if LN:
+        L.check(lib.dimx_op_gemm_ln(L.BF16, L.ptr(a), L.ptr(ws[i % 6]), L.ptr(out), M, N, K, L.ptr(prof), 3, L.ptr(stats),
+                                    L.ptr(bias), L.stream_ptr(dev)), "gemm_ln")
+    else:
+        L.check(lib.dimx_op_gemm(L.BF16, L.BF16, L.ptr(a), K, L.ptr(ws[i % 6]), K, L.ptr(out), N, M, N, K, L.ptr(bias), 3,
+                                 L.ptr(prof), N, 0, None, cfg << 8, L.stream_ptr(dev)), "gemm")
     torch.cuda.synchronize()
     st = prof.view(nblk, SL).cpu().double()
     if i >= 6:
