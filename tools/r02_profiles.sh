@@ -32,8 +32,15 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 python tools/pmc_summary.py $O/pmc_mfma | grep -A9 "gemm256" > $O/r02_pmc_mfma_cross_kv.txt
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $O/pmc_l2 -- python /tmp/xkv.py > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_l2 | grep -A5 "gemm256" >> $O/r02_pmc_mfma_cross_kv.txt
+python tools/pmc_gemm256_record.py $O/r02_pmc_mfma_cross_kv.txt $O/r02_cross_kv_line_under_pmc.txt $COMMIT >> $O/r02_pmc_record.txt 2>&1
+cp profiles/pmc_gemm256_*.json $O/ 2>/dev/null
 # 5. phase breakdown of the chain kernels, prefill GEMM table, f32 / other variants
 python tools/chain_phases.py 2>&1 | grep -v amdgpu > $O/r02_chain_phases.txt
+DIMX_GEMM_PROF=1 python tools/gemm_phases.py 34 2>&1 | grep -v amdgpu > $O/r02_gemm_phases.txt
+DIMX_GEMM_PROF=1 python tools/gemm_phases.py 34 ln 2>&1 | grep -v amdgpu >> $O/r02_gemm_phases.txt
+for c in 3 34; do DIMX_GEMM_CFG_SMALL=$c python tools/gemm_ab.py 2>&1 | tail -1; done > $O/r02_gemm_ab.txt
+tools/ubench/cu_load_rate > $O/r02_cu_load_rate.txt 2>&1
+DIMX_NO_DEFER_LN=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-roofline > $O/r02_bench_line_no_defer_ln.json 2>/dev/null
 python tools/bench_prefill.py 0 14 2>&1 | grep -v amdgpu > $O/r02_prefill_gemm.txt
 DIMX_NO_CHAIN=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-roofline > $O/r02_bench_line_no_chain.json 2>/dev/null
 python bench.py --steps 2 --warmup 1 --samples 10 --no-cpu-baseline --no-parity-mode --no-roofline > $O/r02_bench_samples10.json 2>/dev/null
