@@ -152,7 +152,8 @@ def decode_gemm(B, mode, device, iters=40):
     flops = 2.0 * M * N * K
     tf = flops / sec / 1e12
     peak = MFMA_PEAK_TFLOPS[mode]
-    return {"kernel": "gemm_kernel<%s,float> M=%d N=%d K=%d (decode FF down-projection)" % (mode, M, N, K),
+    return {"kernel": "gemm_ws_kernel<%s,float> M=%d N=%d K=%d (decode FF down-projection, split-K slabs; latency-bound: "
+                      "4.7 MB of weights per launch)" % (mode, M, N, K),
             "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
             "algorithmic_flops_per_launch": flops, "avg_launch_us": sec * 1e6}
 
