@@ -181,6 +181,8 @@ void gemm_args_init(GemmArgs& a);
 // plain row-major output helper
 void gemm_set_plain_out(GemmArgs& a, void* C, int ldc);
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// true when small-M GEMMs run on the loader/consumer kernel, the only one with the deferred-LayerNorm epilogue (ln_stats)
+bool gemm_decode_has_ln_epilogue();
 // the 256 x 256 phase-pipelined prefill kernel (gemm256.hip): taken by launch_gemm when eligible
 bool gemm256_eligible(const GemmArgs& a);
 int launch_gemm256(const GemmArgs& a, hipStream_t s);

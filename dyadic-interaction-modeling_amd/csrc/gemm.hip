@@ -1251,6 +1251,11 @@ static int gemm_cfg_small() {
     return cfg_small;
 }
 
+bool gemm_decode_has_ln_epilogue() {
+    const int c = gemm_cfg_small();
+    return c >= 34 && c <= 37;
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int epc = a.in_dtype == DIMX_BF16 ? 8 : 4;
     const int bk = 8 * epc;

@@ -1574,7 +1574,8 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     const bool chain = gen_use_chain(h, B, S, grp);
     // deferred LayerNorm (chain.hip): the two chain launches of a layer write x and bf16(x) un-normalised + partial row
     // sums; cross-q (inside chain A) and ff1 (the next launch) run on gamma-scaled weights and correct their results
-    const bool defer = chain && h->defer_ln && h->chain_stats_dev && h->dec.cross[0].q_ln.w && h->dec.ff[0].f1_ln.w;
+    const bool defer = chain && h->defer_ln && h->chain_stats_dev && h->dec.cross[0].q_ln.w && h->dec.ff[0].f1_ln.w &&
+                       gemm_decode_has_ln_epilogue();
     auto chain_site = [&](int site, const void* A1, int lda1, const Linear* W1, int nslab, const float* gamma,
                           const Linear* W2, float* out2, int ld_out2, const float* colsum2 = nullptr) -> int {
         ChainArgs c;
