@@ -17,6 +17,8 @@ SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attention.hip", "decode_attn.
 HEADERS = ["common.hpp", "model.hpp", os.path.join("..", "..", "include", "dimx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-ffp-contract=on"]
+if os.environ.get("DIMX_TUNING"):   # also instantiate the measured-dead-end GEMM configurations (A/B runs; use --force)
+    FLAGS.append("-DDIMX_GEMM_TUNING")
 
 
 def _hipcc():

@@ -1134,6 +1134,7 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
             return launch_glds<T, OutT, 64, 64, 2, 2, 4>(a, s);
         case 4: return launch_glds<T, OutT, 64, 64, 2, 2, 3>(a, s);
         case 14: return launch_glds<T, OutT, 128, 128, 4, 2, 2>(a, s);  // 8 waves
+#ifdef DIMX_GEMM_TUNING  // measured dead ends, kept for A/B runs: DIMX_TUNING=1 python __graft_entry__.py build
         case 18: return launch_glds<T, OutT, 256, 128, 4, 2, 2>(a, s);  // 8 waves, 96 KB ring
         case 19: return launch_glds<T, OutT, 256, 256, 4, 2, 2>(a, s);  // 8 waves, 128 KB ring
         case 31: return launch_glds<T, OutT, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 144 KB ring, 2 tiles in flight
@@ -1141,13 +1142,14 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 30: return launch_glds<T, OutT, 128, 128, 4, 2, 3>(a, s);  // 8 waves, 96 KB ring
         case 32: return launch_glds_kpi<T, OutT, 64, 64, 2, 2, 2, 2>(a, s);  // 64x64, 2 k-tiles per iteration, 64 KB
         case 33: return launch_glds_kpi<T, OutT, 64, 64, 2, 2, 3, 2>(a, s);  // ... 3 groups deep, 96 KB
-        case 34: return launch_ws<T, OutT, 4>(a, s);  // 64x64, 4 consumer + 4 loader waves, 64 KB ring
-        case 35: return launch_ws<T, OutT, 6>(a, s);  // ... 96 KB ring (one block per CU)
-        case 36: return launch_ws<T, OutT, 5>(a, s);  // ... 80 KB ring (two blocks per CU just fit)
+        case 36: return launch_ws<T, OutT, 5>(a, s);  // loader/consumer kernel, 80 KB ring (two blocks per CU just fit)
         case 37: return launch_ws<T, OutT, 8>(a, s);  // ... 128 KB ring
         case 38: return launch_ws<T, OutT, 4, 1>(a, s);  // ablations of 34 (wrong results by construction)
         case 39: return launch_ws<T, OutT, 4, 2>(a, s);
         case 40: return launch_ws<T, OutT, 4, 3>(a, s);
+#endif
+        case 34: return launch_ws<T, OutT, 4>(a, s);  // 64x64, 4 consumer + 4 loader waves, 64 KB ring
+        case 35: return launch_ws<T, OutT, 6>(a, s);  // ... 96 KB ring (one block per CU)
         default: break;
     }
     set_error("gemm: unknown cfg %d", cfg);
