@@ -80,7 +80,8 @@ def build(force=False):
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+            if os.path.isfile(os.path.join(OBJ, f)):
+                os.remove(os.path.join(OBJ, f))
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         res = list(ex.map(_compile, SOURCES))
     objs = [o for o, _ in res]
