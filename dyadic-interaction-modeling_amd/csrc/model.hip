@@ -753,6 +753,10 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     const char* nc = getenv("DIMX_NO_CHAIN");
     c->use_chain = (nc && nc[0] == '1') ? 0 : 1;
     c->defer_ln = getenv("DIMX_NO_DEFER_LN") ? 0 : 1;
+    if (const char* gu = getenv("DIMX_GRAPH_UNROLL")) {
+        const int u = atoi(gu);
+        if (u >= 1 && u <= 64) c->graph_unroll = u;
+    }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess) c->cu_count = cus;
@@ -767,6 +771,7 @@ int dimx_destroy(dimx_handle h) {
     if (!h) return DIMX_OK;
     (void)hipSetDevice(h->device);
     for (int g = 0; g < dimx_ctx::kMaxGroups; ++g) {
+        if (h->graph_multi[g]) (void)hipGraphExecDestroy(h->graph_multi[g]);
         if (h->graph_exec[g]) (void)hipGraphExecDestroy(h->graph_exec[g]);
         if (h->grp_stream[g]) (void)hipStreamDestroy(h->grp_stream[g]);
         if (h->ev_join[g]) (void)hipEventDestroy(h->ev_join[g]);
@@ -1793,30 +1798,54 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
         if (!(h->graph_valid && h->graph_key == key)) {
             h->graph_valid = false;
             if (!h->cap_stream) DIMX_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-            for (int g = 0; g < dimx_ctx::kMaxGroups; ++g)
+            for (int g = 0; g < dimx_ctx::kMaxGroups; ++g) {
                 if (h->graph_exec[g]) {
                     (void)hipGraphExecDestroy(h->graph_exec[g]);
                     h->graph_exec[g] = nullptr;
                 }
-            for (int g = 0; g < G; ++g) {
-                hipGraph_t graph = nullptr;
-                DIMX_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-                const int rc = gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], R, g, T, temperature, top_k,
-                                        exp_noise, seed, tokens, logits_out, h->cap_stream, false, S);
-                const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
-                if (rc != DIMX_OK) {
-                    if (graph) (void)hipGraphDestroy(graph);
-                    return rc;
+                if (h->graph_multi[g]) {
+                    (void)hipGraphExecDestroy(h->graph_multi[g]);
+                    h->graph_multi[g] = nullptr;
                 }
-                DIMX_HIP(ce);
-                DIMX_HIP(hipGraphInstantiate(&h->graph_exec[g], graph, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(graph);
+            }
+            // The step does not depend on the step index (it lives in device memory), so the same launches can be captured
+            // several times in a row: consecutive graph launches leave ~8 us of idle GPU between them (kernel trace of
+            // round 2: 299 gaps = 2.5 ms per batch), kernels inside one graph follow each other without a gap.  `reps` = 1
+            // for the remainder steps, graph_unroll for the bulk.
+            for (int g = 0; g < G; ++g) {
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int reps = pass == 0 ? 1 : h->graph_unroll;
+                    if (pass == 1 && (reps <= 1 || n < reps)) continue;
+                    hipGraph_t graph = nullptr;
+                    DIMX_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+                    int rc = DIMX_OK;
+                    for (int r = 0; r < reps && rc == DIMX_OK; ++r)
+                        rc = gen_step(h, cp, s, start, ctx_mask, lo[g], lo[g + 1] - lo[g], R, g, T, temperature, top_k,
+                                      exp_noise, seed, tokens, logits_out, h->cap_stream, false, S);
+                    const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+                    if (rc != DIMX_OK) {
+                        if (graph) (void)hipGraphDestroy(graph);
+                        return rc;
+                    }
+                    DIMX_HIP(ce);
+                    DIMX_HIP(hipGraphInstantiate(pass == 0 ? &h->graph_exec[g] : &h->graph_multi[g], graph, nullptr, nullptr, 0));
+                    (void)hipGraphDestroy(graph);
+                }
             }
             h->graph_key = key;
             h->graph_valid = true;
         }
-        for (int t = 0; t < n; ++t)
-            for (int g = 0; g < G; ++g) DIMX_HIP(hipGraphLaunch(h->graph_exec[g], gs[g]));
+        {
+            const int U = h->graph_unroll;
+            int t = 0;
+            for (; U > 1 && t + U <= n; t += U)
+                for (int g = 0; g < G; ++g)
+                    if (h->graph_multi[g]) DIMX_HIP(hipGraphLaunch(h->graph_multi[g], gs[g]));
+                    else
+                        for (int r = 0; r < U; ++r) DIMX_HIP(hipGraphLaunch(h->graph_exec[g], gs[g]));
+            for (; t < n; ++t)
+                for (int g = 0; g < G; ++g) DIMX_HIP(hipGraphLaunch(h->graph_exec[g], gs[g]));
+        }
     }
     if (G > 1) {
         for (int g = 0; g < G; ++g) {

@@ -141,6 +141,8 @@ struct dimx_ctx {
     // generate step graph
     static constexpr int kMaxGroups = 8;
     hipGraphExec_t graph_exec[kMaxGroups] = {};
+    hipGraphExec_t graph_multi[kMaxGroups] = {};  // the same step captured graph_unroll times back to back
+    int graph_unroll = 16;                        // DIMX_GRAPH_UNROLL (1 = one launch per step)
     hipStream_t grp_stream[kMaxGroups] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups] = {};
     int gen_groups = 1;  // independent clip groups decoded concurrently on separate streams (DIMX_GEN_GROUPS;
