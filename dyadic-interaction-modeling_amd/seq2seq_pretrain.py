@@ -24,6 +24,15 @@ from . import weights as W
 from .models import _EngineOwner, build_param_tree, get_model
 
 
+def _masked_pairwise_loss(pred, target, m):
+    """mean_{valid} ||p[6:] - t[6:] + eps|| + mean_{valid} ||p[:6] - t[:6] + eps||  (F.pairwise_distance, eps 1e-6),
+    without a device -> host synchronisation; an all-False mask gives NaN like the mean of an empty selection."""
+    m = m.bool()
+    d = F.pairwise_distance(pred[..., 6:], target[..., 6:]) + F.pairwise_distance(pred[..., 0:6], target[..., 0:6])
+    zero = torch.zeros((), dtype=d.dtype, device=d.device)
+    return torch.where(m, d, zero).sum() / m.sum()
+
+
 def compact_by_mask(x, mask):
     """Left-align the valid frames of every clip (``v[i][mask[i]]`` of the reference, batched).
     Returns (x_compact, lens int32).  A prefix mask (the engine protocol) is returned unchanged."""
@@ -145,12 +154,10 @@ class SLMFT(_EngineOwner):
         return self.engine(pred_seq_l.device).vq_decode(1, pred_seq_l, batch_row_offset, rows_per_clip)
 
     def forward_continuous_loss(self, pred, target, mask):
-        """reference :466-478."""
-        target = target[:, 1:, :]
-        m = mask[:, 1:].reshape(-1)
-        p = pred.reshape(-1, pred.shape[-1])[m]
-        t = target.reshape(-1, target.shape[-1])[m]
-        return torch.mean(F.pairwise_distance(p[:, 6:], t[:, 6:])) + torch.mean(F.pairwise_distance(p[:, 0:6], t[:, 0:6]))
+        """reference :466-478: mean pairwise distance over the valid frames, expression part + pose part.  Written as
+        masked sums / count instead of boolean indexing: ``x[m]`` synchronises with the device (nonzero) and left the GPU
+        idle for ~0.6 ms per call inside the timed forward."""
+        return _masked_pairwise_loss(pred, target[:, 1:, :], mask[:, 1:])
 
     # ------------------------------------------------------------------ training (SURVEY 8 row f3)
     def _wants_grad(self, mode):
@@ -336,11 +343,7 @@ class SLM(_EngineOwner):
         return row_loss.sum() / n_valid, logits, amax
 
     def forward_continuous_loss(self, pred, target, mask):
-        target = target[:, 1:, :]
-        m = mask[:, 1:].reshape(-1)
-        p = pred.reshape(-1, pred.shape[-1])[m]
-        t = target.reshape(-1, target.shape[-1])[m]
-        return torch.mean(F.pairwise_distance(p[:, 6:], t[:, 6:])) + torch.mean(F.pairwise_distance(p[:, 0:6], t[:, 0:6]))
+        return _masked_pairwise_loss(pred, target[:, 1:, :], mask[:, 1:])
 
     @torch.no_grad()
     def forward(self, v_speaker, v_listener, v_audio, mask, speaker_ids=None, listener_ids=None, mode="train",
