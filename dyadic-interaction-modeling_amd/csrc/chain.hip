@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) s += v[i];
-        s = wave_sum(s);
+        s = wave_sum_fast(s);
         if (lane == 0) sm_s[wave] = s;
     }
     lds_barrier();
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
             const float d = c < C ? v[i] - mean : 0.f;
             q += d * d;
         }
-        q = wave_sum(q);
+        q = wave_sum_fast(q);
         if (lane == 0) sm_q[wave] = q;
     }
     lds_barrier();

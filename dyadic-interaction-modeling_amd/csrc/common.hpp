@@ -101,16 +101,73 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     }
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+// Wave-wide reductions on the DPP / readlane paths instead of __shfl_xor (which hipcc lowers to ds_bpermute_b32: an LDS
+// round trip of ~100 cycles per step, six dependent steps per reduction -- the tail of every LayerNorm, softmax and
+// sampler launch of the decode step).  Bit-identical to the ASCENDING xor butterfly (xor 1, 2, 4, ...): quad_perm IS
+// xor 1 / xor 2; after those steps a quad holds one value, so the half-row and row mirrors deliver exactly the partner
+// group's partial sum (a + b == b + a), and the four row totals are combined as (t0 + t1) + (t2 + t3) like the butterfly
+// does in every lane (verified bit for bit by tools/ubench/dpp_check.hip).  All 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+__device__ __forceinline__ float lane_f32(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// sum over aligned groups of 8 (16) lanes, every lane of the group gets it; == the xor-1,2,4(,8) butterfly bit for bit
+// when the operation is commutative, which + and max are
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_f32<DPP_XOR1>(v);
+    v += dpp_f32<DPP_XOR2>(v);
+    v += dpp_f32<DPP_HALF_MIRROR>(v);
     return v;
 }
+__device__ __forceinline__ float row16_sum(float v) {
+    v = group8_sum(v);
+    v += dpp_f32<DPP_ROW_MIRROR>(v);
+    return v;
+}
+// (value, index) of the wave's maximum, ties to the smaller index, in every lane: four in-row steps on DPP, the two
+// cross-row steps on ds_bpermute (12 -> 4 LDS round trips)
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#define DIMX_ARGMAX_STEP(OV, OI)                          \
+    do {                                                  \
+        const float ov_ = (OV);                           \
+        const int oi_ = (OI);                             \
+        if (ov_ > v || (ov_ == v && oi_ < i)) {           \
+            v = ov_;                                      \
+            i = oi_;                                      \
+        }                                                 \
+    } while (0)
+    DIMX_ARGMAX_STEP(dpp_f32<DPP_XOR1>(v), dpp_i32<DPP_XOR1>(i));
+    DIMX_ARGMAX_STEP(dpp_f32<DPP_XOR2>(v), dpp_i32<DPP_XOR2>(i));
+    DIMX_ARGMAX_STEP(dpp_f32<DPP_HALF_MIRROR>(v), dpp_i32<DPP_HALF_MIRROR>(i));
+    DIMX_ARGMAX_STEP(dpp_f32<DPP_ROW_MIRROR>(v), dpp_i32<DPP_ROW_MIRROR>(i));
+    DIMX_ARGMAX_STEP(__shfl_xor(v, 16), __shfl_xor(i, 16));
+    DIMX_ARGMAX_STEP(__shfl_xor(v, 32), __shfl_xor(i, 32));
+#undef DIMX_ARGMAX_STEP
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f32<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
+}
+// The wave sum of the f32 parity mode and of the VQ search keeps its historical association (xor 32, 16, ... 1: the order
+// oracle/vq_argmin.c restates); the bf16 perf mode takes the DPP form, which associates as xor 1, 2, ... 32 -- the two
+// differ in the last bit for about a third of all inputs (tools/ubench/dpp_check.hip).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v = row16_sum(v);
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
+}
+template <bool FAST> __device__ __forceinline__ float wave_sum_sel(float v) { return FAST ? wave_sum_fast(v) : wave_sum(v); }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -167,8 +167,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) d = fmaf(qv[e], kv[e], d);
-#pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o);
+            d = LPK == 8 ? group8_sum(d) : row16_sum(d);  // == the xor butterfly over the key's lanes (common.hpp)
             if (j < n) {
                 float sv = d * scale2;
                 if (masked && s[j] != 0.f) sv = kNegD;
@@ -186,8 +185,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) d = fmaf(qv[e], knv[e], d);
-#pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o);
+        d = LPK == 8 ? group8_sum(d) : row16_sum(d);
         const float sv = d * scale2;
         total = n + 1;
         if (part == 0) {  // the new key belongs to the first wave of the pair
@@ -214,7 +212,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
         s[j] = p;
         lsum += p;
     }
-    lsum = wave_sum(lsum);
+    lsum = wave_sum_sel<sizeof(T) == 2>(lsum);
     if (NSPLIT > 1) {
         if (lane == 0) red_l[wave] = lsum;
         __syncthreads();
@@ -332,8 +330,7 @@ __global__ __launch_bounds__(256) void decode_attn_multi_kernel(const DecodeAttn
                 float d = 0.f;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) d = fmaf(qv[q][e], kv[e], d);
-#pragma unroll
-                for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o);
+                d = LPK == 8 ? group8_sum(d) : row16_sum(d);
                 if (j < n) {
                     const float sv = dead ? kNegD : d * scale2;
                     if (ch == 0) s[q * npad + j] = sv;
@@ -357,7 +354,7 @@ __global__ __launch_bounds__(256) void decode_attn_multi_kernel(const DecodeAttn
             s[q * npad + j] = p;
             l += p;
         }
-        lsum[q] = wave_sum(l);
+        lsum[q] = wave_sum_sel<sizeof(T) == 2>(l);
     }
     __syncthreads();
     float acc[SQ][EPC];

@@ -88,15 +88,7 @@ __global__ __launch_bounds__(256) void ce_argmax_kernel(const float* __restrict_
             mi = lane + 64 * c;
         }
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float om = __shfl_xor(mx, o);
-        const int oi = __shfl_xor(mi, o);
-        if (om > mx || (om == mx && oi < mi)) {
-            mx = om;
-            mi = oi;
-        }
-    }
+    wave_argmax(mx, mi);
     float se = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) se += expf(v[c] - mx);
@@ -169,15 +161,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
 #pragma unroll
         for (int c = 0; c < 8; ++c) lo[lane + 64 * c] = v[c];
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float om = __shfl_xor(mx, o);
-        const int oi = __shfl_xor(mi, o);
-        if (om > mx || (om == mx && oi < mi)) {
-            mx = om;
-            mi = oi;
-        }
-    }
+    wave_argmax(mx, mi);
     const bool greedy = temperature <= 0.f || (noise == nullptr && seed == 0);
     int tok = mi;
     if (!greedy) {
@@ -272,15 +256,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
 #pragma unroll
             for (int c = 0; c < 8; ++c) score(p[c], zsum, lane + 64 * c);
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float ob = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ob > best || (ob == best && oi < bi)) {
-                best = ob;
-                bi = oi;
-            }
-        }
+        wave_argmax(best, bi);
         tok = bi;
     }
     if (lane == 0) tokens[(size_t)row * tok_ld + (tok_col_from_step ? (int)step : 0)] = tok;
@@ -294,7 +270,24 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                 dst[i] = make_float2(__fadd_rn(e.x, __fmul_rn(q.x, pos_scale)), __fadd_rn(e.y, __fmul_rn(q.y, pos_scale)));
             }
         } else {
-            for (int i = lane; i < emb_C / 2; i += 64) dst[i] = src[i];
+            // all of the row's loads in flight together, then the stores (a plain copy loop keeps load -> store order: up to
+            // 9 dependent L2 round trips at the tail of every decode step)
+            const int nv = emb_C / 2;
+            if (nv <= 16 * 64) {
+                float2 v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    v[k] = src[i < nv ? i : nv - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < nv) dst[i] = v[k];
+                }
+            } else {
+                for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+            }
         }
     }
     }  // row < R

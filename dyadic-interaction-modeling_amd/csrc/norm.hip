@@ -36,14 +36,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         gv[i] = g2[lane + 64 * i];
         bv[i] = beta ? b2[lane + 64 * i] : make_float2(0.f, 0.f);
     }
-    const float mean = wave_sum(s) * (1.0f / C);
+    const float mean = wave_sum_sel<sizeof(OutT) == 2>(s) * (1.0f / C);
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float a = v[i].x - mean, b = v[i].y - mean;
         q += a * a + b * b;
     }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+    const float rstd = rsqrtf(wave_sum_sel<sizeof(OutT) == 2>(q) * (1.0f / C) + 1e-5f);
     OutT* yr = y + (size_t)row * C;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -107,14 +107,14 @@ __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restr
         if (nslab > 0) xr[lane + 64 * i] = v[i];
         s += v[i].x + v[i].y;
     }
-    const float mean = wave_sum(s) * (1.0f / C);
+    const float mean = wave_sum_sel<sizeof(OutT) == 2>(s) * (1.0f / C);
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float a = v[i].x - mean, b = v[i].y - mean;
         q += a * a + b * b;
     }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + 1e-5f);
+    const float rstd = rsqrtf(wave_sum_sel<sizeof(OutT) == 2>(q) * (1.0f / C) + 1e-5f);
     OutT* yr = y + (size_t)row * C;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
