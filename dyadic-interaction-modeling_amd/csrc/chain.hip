@@ -176,12 +176,11 @@ __device__ __forceinline__ void reduce_store_defer(const f32x16_t (&acc)[NCB], f
         }
     }
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            s1[k] += __shfl_xor(s1[k], o);
-            s2[k] += __shfl_xor(s2[k], o);
-        }
+    for (int k = 0; k < 2; ++k) {  // the 32 lanes of a row: four in-row steps on DPP (== xor 1, 2, 4, 8), one bpermute
+        s1[k] = row16_sum(s1[k]);
+        s2[k] = row16_sum(s2[k]);
+        s1[k] += __shfl_xor(s1[k], 16);
+        s2[k] += __shfl_xor(s2[k], 16);
     }
     if (l31 == 0) {
 #pragma unroll
@@ -374,11 +373,8 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
             const float* sp = a.stats + ((size_t)(g * kGroupCUs + 2 * part) * kGroupRows + m) * 2;
             float t1 = ld_sc1_f32(sp) + ld_sc1_f32(sp + 2 * kGroupRows);
             float t2 = ld_sc1_f32(sp + 1) + ld_sc1_f32(sp + 2 * kGroupRows + 1);
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                t1 += __shfl_xor(t1, o);
-                t2 += __shfl_xor(t2, o);
-            }
+            t1 = row16_sum(t1);  // == the xor 1, 2, 4, 8 butterfly over the row's 16 parts
+            t2 = row16_sum(t2);
             if (part == 0) {
                 const float mean = t1 * (1.0f / C);
                 const float var = fmaxf(t2 * (1.0f / C) - mean * mean, 0.f);
