@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
                 }
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, xor_lane_f32<32>(mx));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = fast_exp2<T>(m_run - m_new);
         float psum = 0.f;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
     }
 
     // ---- finish: combine the two lane halves' row sums, normalise, store O[q][d]
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + xor_lane_f32<32>(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qi < a.Lq) {
         T* orow = (T*)a.o + (size_t)b * a.o_sb + (size_t)qi * a.o_st + (size_t)h * a.o_sh;

@@ -176,11 +176,11 @@ __device__ __forceinline__ void reduce_store_defer(const f32x16_t (&acc)[NCB], f
         }
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {  // the 32 lanes of a row: four in-row steps on DPP (== xor 1, 2, 4, 8), one bpermute
+    for (int k = 0; k < 2; ++k) {  // the 32 lanes of a row: four in-row steps on DPP (== xor 1, 2, 4, 8), one lane swap
         s1[k] = row16_sum(s1[k]);
         s2[k] = row16_sum(s2[k]);
-        s1[k] += __shfl_xor(s1[k], 16);
-        s2[k] += __shfl_xor(s2[k], 16);
+        s1[k] += xor_lane_f32<16>(s1[k]);
+        s2[k] += xor_lane_f32<16>(s2[k]);
     }
     if (l31 == 0) {
 #pragma unroll

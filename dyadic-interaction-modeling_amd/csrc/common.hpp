@@ -115,6 +115,34 @@ constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW
 __device__ __forceinline__ float lane_f32(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+// v of lane (l ^ O) for O in {1, 2, 4, 8, 16, 32}, entirely on the vector ALU (what __shfl_xor means, without the
+// ds_bpermute round trip): quad_perm for 1 / 2, two bank-masked row shifts for 4, row_ror:8 for 8, the gfx950 lane-swap
+// instructions v_permlane16_swap / v_permlane32_swap for 16 / 32 (forms verified against __shfl_xor on the GPU:
+// tools/ubench/dpp_check.hip).  All 64 lanes must be active.
+__device__ __forceinline__ int wave_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+template <int O> __device__ __forceinline__ int xor_lane_i32(int v) {
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8 || O == 16 || O == 32, "xor distance");
+    if constexpr (O == 1) {
+        return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+    } else if constexpr (O == 2) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+    } else if constexpr (O == 4) {  // quads 0, 2 read lane + 4 (row_shl:4), quads 1, 3 read lane - 4 (row_shr:4)
+        const int r = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);
+        return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xF, 0xA, false);
+    } else if constexpr (O == 8) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);  // row_ror:8
+    } else if constexpr (O == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        return ((wave_lane() >> 4) & 1) ? (int)r[0] : (int)r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        return wave_lane() >= 32 ? (int)r[0] : (int)r[1];
+    }
+}
+template <int O> __device__ __forceinline__ float xor_lane_f32(float v) {
+    return __builtin_bit_cast(float, xor_lane_i32<O>(__builtin_bit_cast(int, v)));
+}
+
 // sum over aligned groups of 8 (16) lanes, every lane of the group gets it; == the xor-1,2,4(,8) butterfly bit for bit
 // when the operation is commutative, which + and max are
 __device__ __forceinline__ float group8_sum(float v) {
@@ -129,7 +157,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 // (value, index) of the wave's maximum, ties to the smaller index, in every lane: four in-row steps on DPP, the two
-// cross-row steps on ds_bpermute (12 -> 4 LDS round trips)
+// cross-row steps on the lane-swap instructions (no LDS round trip left)
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 #define DIMX_ARGMAX_STEP(OV, OI)                          \
     do {                                                  \
@@ -144,8 +172,8 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
     DIMX_ARGMAX_STEP(dpp_f32<DPP_XOR2>(v), dpp_i32<DPP_XOR2>(i));
     DIMX_ARGMAX_STEP(dpp_f32<DPP_HALF_MIRROR>(v), dpp_i32<DPP_HALF_MIRROR>(i));
     DIMX_ARGMAX_STEP(dpp_f32<DPP_ROW_MIRROR>(v), dpp_i32<DPP_ROW_MIRROR>(i));
-    DIMX_ARGMAX_STEP(__shfl_xor(v, 16), __shfl_xor(i, 16));
-    DIMX_ARGMAX_STEP(__shfl_xor(v, 32), __shfl_xor(i, 32));
+    DIMX_ARGMAX_STEP(xor_lane_f32<16>(v), xor_lane_i32<16>(i));
+    DIMX_ARGMAX_STEP(xor_lane_f32<32>(v), xor_lane_i32<32>(i));
 #undef DIMX_ARGMAX_STEP
 }
 __device__ __forceinline__ float wave_max(float v) {
@@ -158,9 +186,13 @@ __device__ __forceinline__ float wave_max(float v) {
 // The wave sum of the f32 parity mode and of the VQ search keeps its historical association (xor 32, 16, ... 1: the order
 // oracle/vq_argmin.c restates); the bf16 perf mode takes the DPP form, which associates as xor 1, 2, ... 32 -- the two
 // differ in the last bit for about a third of all inputs (tools/ubench/dpp_check.hip).
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+__device__ __forceinline__ float wave_sum(float v) {  // the xor 32, 16, ... 1 butterfly, step for step
+    v += xor_lane_f32<32>(v);
+    v += xor_lane_f32<16>(v);
+    v += xor_lane_f32<8>(v);
+    v += xor_lane_f32<4>(v);
+    v += xor_lane_f32<2>(v);
+    v += xor_lane_f32<1>(v);
     return v;
 }
 __device__ __forceinline__ float wave_sum_fast(float v) {

@@ -245,9 +245,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
         for (int e = 0; e < EPC; ++e) acc[e] = fmaf(p, vnv[e], acc[e]);
     }
 #pragma unroll
-    for (int o = LPK; o < 64; o <<= 1)
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) acc[e] += __shfl_xor(acc[e], o);
+    for (int e = 0; e < EPC; ++e) {  // xor LPK .. 32 butterfly over the key sub-groups (common.hpp xor_lane: no LDS round trips)
+        if (LPK <= 8) acc[e] += xor_lane_f32<8>(acc[e]);
+        acc[e] += xor_lane_f32<16>(acc[e]);
+        acc[e] += xor_lane_f32<32>(acc[e]);
+    }
     if (NSPLIT > 1) {  // combine the partial outputs of the pair's waves in wave order
         if (sub == 0) {
 #pragma unroll
@@ -382,9 +384,11 @@ __global__ __launch_bounds__(256) void decode_attn_multi_kernel(const DecodeAttn
 #pragma unroll
     for (int q = 0; q < SQ; ++q) {
 #pragma unroll
-        for (int o = LPK; o < 64; o <<= 1)
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[q][e] += __shfl_xor(acc[q][e], o);
+        for (int e = 0; e < EPC; ++e) {
+            if (LPK <= 8) acc[q][e] += xor_lane_f32<8>(acc[q][e]);
+            acc[q][e] += xor_lane_f32<16>(acc[q][e]);
+            acc[q][e] += xor_lane_f32<32>(acc[q][e]);
+        }
         if (active && sub == 0) {
             const float inv = lsum[q] > 0.f ? 1.0f / lsum[q] : 0.f;
 #pragma unroll

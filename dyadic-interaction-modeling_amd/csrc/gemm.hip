@@ -1040,8 +1040,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
             ln_s1 += ln_p[i].x;
             ln_s2 += ln_p[i].y;
         }
-        ln_s1 += __shfl_xor(ln_s1, 32);
-        ln_s2 += __shfl_xor(ln_s2, 32);
+        ln_s1 += xor_lane_f32<32>(ln_s1);
+        ln_s2 += xor_lane_f32<32>(ln_s2);
         const float inv_c = 1.0f / (float)a.ln_C;
         const float mean = ln_s1 * inv_c;
         const float rstd = rsqrtf(fmaxf(ln_s2 * inv_c - mean * mean, 0.f) + 1e-5f);

@@ -30,6 +30,14 @@ __global__ void k(const float* in, const int* idx, float* out, int* outi) {
     float nv = v;
     int ni = idx[t];
     wave_argmax(nv, ni);
+    int xbad = 0;
+    const int iv = idx[t] * 131 + t;
+    xbad += xor_lane_i32<1>(iv) != __shfl_xor(iv, 1);
+    xbad += xor_lane_i32<2>(iv) != __shfl_xor(iv, 2);
+    xbad += xor_lane_i32<4>(iv) != __shfl_xor(iv, 4);
+    xbad += xor_lane_i32<8>(iv) != __shfl_xor(iv, 8);
+    xbad += xor_lane_i32<16>(iv) != __shfl_xor(iv, 16);
+    xbad += xor_lane_i32<32>(iv) != __shfl_xor(iv, 32);
     out[t * 12 + 0] = a1; out[t * 12 + 1] = wave_sum_fast(v);
     out[t * 12 + 2] = m; out[t * 12 + 3] = wave_max(v);
     out[t * 12 + 4] = g8; out[t * 12 + 5] = group8_sum(v);
@@ -37,6 +45,7 @@ __global__ void k(const float* in, const int* idx, float* out, int* outi) {
     out[t * 12 + 8] = bv; out[t * 12 + 9] = nv;
     out[t * 12 + 10] = a; out[t * 12 + 11] = wave_sum(v);
     outi[t * 2] = bi; outi[t * 2 + 1] = ni;
+    if (xbad) atomicAdd(outi + 2 * 64 * 256, xbad);
 }
 
 int main() {
@@ -46,11 +55,11 @@ int main() {
     srand(1);
     for (int i = 0; i < N; ++i) { h[i] = (float)rand() / RAND_MAX * 2.f - 1.f + (i % 7 == 0 ? 100.f : 0.f); if (i % 97 < 5) h[i] = 0.5f; hi[i] = rand() % 512; }
     float *d, *o; int *di, *oi;
-    hipMalloc(&d, N * 4); hipMalloc(&o, N * 48); hipMalloc(&di, N * 4); hipMalloc(&oi, N * 8);
+    hipMalloc(&d, N * 4); hipMalloc(&o, N * 48); hipMalloc(&di, N * 4); hipMalloc(&oi, N * 8 + 4); hipMemset(oi, 0, N * 8 + 4);
     hipMemcpy(d, h, N * 4, hipMemcpyHostToDevice); hipMemcpy(di, hi, N * 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k, dim3(N / 64), dim3(64), 0, 0, d, di, o, oi);
-    float* ho = (float*)malloc(N * 48); int* hoi = (int*)malloc(N * 8);
-    hipMemcpy(ho, o, N * 48, hipMemcpyDeviceToHost); hipMemcpy(hoi, oi, N * 8, hipMemcpyDeviceToHost);
+    float* ho = (float*)malloc(N * 48); int* hoi = (int*)malloc(N * 8 + 4);
+    hipMemcpy(ho, o, N * 48, hipMemcpyDeviceToHost); hipMemcpy(hoi, oi, N * 8 + 4, hipMemcpyDeviceToHost);
     int bad[6] = {0, 0, 0, 0, 0, 0};
     for (int t = 0; t < N; ++t) {
         for (int p = 0; p < 5; ++p) if (memcmp(&ho[t * 12 + 2 * p], &ho[t * 12 + 2 * p + 1], 4)) ++bad[p];
@@ -63,6 +72,7 @@ int main() {
     }
     printf("mismatches vs the xor butterflies: wave_sum_fast (ascending) %d, wave_sum (descending) %d, wave_max %d, group8 %d, row16 %d, "
            "argmax value %d, argmax index %d\n", bad[0], bad_exact, bad[1], bad[2], bad[3], bad[4], bad[5]);
+    printf("xor_lane<1..32> vs __shfl_xor: %d mismatching lanes\n", hoi[2 * N]);
     printf("descending (32..1) vs ascending (1..32) xor butterfly: %d of %d lanes differ in the last bits\n", dif, N);
     return 0;
 }
