@@ -891,7 +891,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
     constexpr int TILE_BYTES = (BM + BN) * 128;
     static_assert(STAGES >= 3 && (STAGES - 1) * LPT < 64, "ring depth");
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
-    __shared__ __attribute__((aligned(16))) float ln_sm[4][64];  // deferred LayerNorm: {mean[32], rstd[32]} per consumer wave
+    __shared__ __attribute__((aligned(16))) float ln_sm[128];  // deferred LayerNorm: mean[64], rstd[64] of the tile's rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -963,6 +963,18 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
                 __builtin_amdgcn_global_load_lds((glb_void_t*)(gW[j] + (size_t)kt * wstep),
                                                  (lds_void_t*)(base + BM * 128 + (lw * LW + j) * 1024), 16, 0, 0);
         };
+        // Deferred LayerNorm of the A rows (GemmArgs.ln_stats): the LOADER waves reduce the 32 per-CU partial sums of the tile's
+        // 64 rows -- loader lw takes rows lw * 16 + (lane & 15), lane >> 4 picks 8 of the 32 CUs.  The loads are this wave's
+        // oldest memory operations (in-order return: every counted vmcnt wait below covers them), the reduction runs after the
+        // wave's last barrier but one, when it has nothing left to issue; the consumers find {mean, rstd} in LDS after the loop.
+        float2 lp[8];
+        if (a.ln_stats) {
+            int m = m0 + lw * 16 + (lane & 15);
+            m = m < a.M ? m : a.M - 1;
+            const float2* sp = (const float2*)a.ln_stats + ((size_t)(m >> 5) * 32 + (lane >> 4) * 8) * 32 + (m & 31);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lp[i] = sp[(size_t)i * 32];
+        }
 #pragma unroll
         for (int st = 0; st < STAGES - 1; ++st)
             if (st < nk) issue(st, st);
@@ -977,6 +989,26 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
             if (it < 12) stamp(3 + 2 * it);
             __builtin_amdgcn_s_barrier();
             if (ABLW != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+            if (a.ln_stats && it == nk - 2) {  // vmcnt is 0 here (the wait of this iteration), nothing left to issue
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s1 += lp[i].x;
+                    s2 += lp[i].y;
+                }
+                s1 += xor_lane_f32<16>(s1);
+                s2 += xor_lane_f32<16>(s2);
+                s1 += xor_lane_f32<32>(s1);
+                s2 += xor_lane_f32<32>(s2);
+                const float inv_c = 1.0f / (float)a.ln_C;
+                const float mean = s1 * inv_c;
+                const float rstd = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + 1e-5f);
+                if (lane < 16) {
+                    ln_sm[lw * 16 + lane] = mean;
+                    ln_sm[64 + lw * 16 + lane] = rstd;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in LDS before this wave arrives at the last barrier
+            }
         }
         stamp(28);
         return;
@@ -995,24 +1027,15 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
     f32x16_t acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    // deferred LayerNorm of the A rows (GemmArgs.ln_stats): lane l gathers half of the 32 per-CU partial sums of row
-    // wm * 32 + (l & 31) -- one load instruction reads two contiguous 256-byte runs (the 32 rows of two CUs); the loads fly
-    // during the main loop, the correction runs on the accumulators before the epilogue
-    float ln_s1 = 0.f, ln_s2 = 0.f, ln_cs = 0.f;
-    float2 ln_p[16];
+    // deferred LayerNorm of the A rows: {mean, rstd} come from the loader waves through LDS (above); the lane's column sum of
+    // the gamma-scaled weights is requested once the prologue tiles have landed
+    float ln_cs = 0.f;
     for (int it = 0; it < nk; ++it) {
         const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
         if (it < 12) stamp(2 + 2 * it);
         __builtin_amdgcn_s_barrier();
         if (ABLW == 1) continue;
         if (it == 0 && a.ln_stats) {
-            // requested once the prologue tiles have landed (the loaders' first DMAs are the kernel's critical path), in
-            // flight during the rest of the loop
-            int m = m0 + wm * 32 + l31;
-            m = m < a.M ? m : a.M - 1;
-            const float2* sp = (const float2*)a.ln_stats + ((size_t)(m >> 5) * 32 + half * 16) * 32 + (m & 31);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ln_p[i] = sp[(size_t)i * 32];
             const int n = n0 + wn * 32 + l31;
             ln_cs = a.ln_colsum[n < a.N ? n : a.N - 1];
         }
@@ -1035,27 +1058,12 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
     }
     stamp(28);
     if (a.ln_stats) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            ln_s1 += ln_p[i].x;
-            ln_s2 += ln_p[i].y;
-        }
-        ln_s1 += xor_lane_f32<32>(ln_s1);
-        ln_s2 += xor_lane_f32<32>(ln_s2);
-        const float inv_c = 1.0f / (float)a.ln_C;
-        const float mean = ln_s1 * inv_c;
-        const float rstd = rsqrtf(fmaxf(ln_s2 * inv_c - mean * mean, 0.f) + 1e-5f);
-        // lane l holds the statistics of row l & 31, an accumulator register those of rows 8q + 4 half + (0..3): through a
-        // private 256-byte LDS strip, 8 ds_read_b128 instead of 32 ds_bpermute
-        float* strip = ln_sm[wave];
-        if (half == 0) {
-            strip[l31] = mean;
-            strip[32 + l31] = rstd;
-        }
+        // an accumulator register group holds rows 8q + 4 half + (0..3) of the wave's 32: 8 ds_read_b128
+        const float* strip = ln_sm + wm * 32;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 mq = *(const float4*)(strip + 8 * q + 4 * half);
-            const float4 rq = *(const float4*)(strip + 32 + 8 * q + 4 * half);
+            const float4 rq = *(const float4*)(strip + 64 + 8 * q + 4 * half);
             acc[0][0][4 * q + 0] = rq.x * (acc[0][0][4 * q + 0] - mq.x * ln_cs);
             acc[0][0][4 * q + 1] = rq.y * (acc[0][0][4 * q + 1] - mq.y * ln_cs);
             acc[0][0][4 * q + 2] = rq.z * (acc[0][0][4 * q + 2] - mq.z * ln_cs);
@@ -1125,8 +1133,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 //  6: 128x64 3 stages    7: 128x64 2 stages    8: 64x128 3 stages
 template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
     DIMX_REQUIRE(!a.w_tiled || (cfg >= 34 && cfg <= 40), DIMX_ERR_ARG, "gemm: block-tiled W is read by the decode kernel only (cfg %d)", cfg);
-    DIMX_REQUIRE(!a.ln_stats || (cfg >= 34 && cfg <= 37 && a.splitk == 1 && a.ln_colsum && a.ln_C > 0), DIMX_ERR_ARG,
-                 "gemm: the deferred-LayerNorm epilogue exists in the decode kernel only, without split-K (cfg %d)", cfg);
+    DIMX_REQUIRE(!a.ln_stats || (cfg >= 34 && cfg <= 37 && a.splitk == 1 && a.ln_colsum && a.ln_C > 0 &&
+                                 a.K >= 16 * Elem<T>::kPerChunk),
+                 DIMX_ERR_ARG, "gemm: the deferred-LayerNorm epilogue exists in the decode kernel only, without split-K, from two "
+                               "k-tiles up (cfg %d, K %d)", cfg, a.K);
     switch (cfg) {
         case 1: return launch_glds<T, OutT, 128, 128, 2, 2, 2>(a, s);
         case 3:
