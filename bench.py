@@ -28,7 +28,7 @@ import dimx  # noqa: E402,F401
 from dimx import dist as ddist  # noqa: E402
 from dimx import lib as L  # noqa: E402
 from dimx import prng, weights  # noqa: E402
-from dimx.seq2seq_pretrain import SLMFT  # noqa: E402
+from dimx.seq2seq_pretrain import SLMFT, mark_prefix  # noqa: E402
 
 SEED = 20260928
 GFLOP_PER_CLIP_T300 = 73.5  # SURVEY.md section 8d, necessary work
@@ -38,14 +38,14 @@ def synth_batch(B, T, device, salt):
     v_s = torch.from_numpy(prng.normal(SEED + salt, "bench.v_speaker", (B, T, 56))).to(device)
     v_l = torch.from_numpy(prng.normal(SEED + salt, "bench.v_listener", (B, T, 56))).to(device)
     v_a = torch.from_numpy(prng.normal(SEED + salt, "bench.v_audio", (B, T, 768))).to(device)
-    mask = torch.ones(B, T, dtype=torch.bool, device=device)
+    mask = mark_prefix(torch.ones(B, T, dtype=torch.bool, device=device))   # full clips: a prefix mask, like the engine protocol's
     return v_s, v_l, v_a, mask
 
 
 def _cpu_worker(T, b):
-    """(subprocess) BASELINE.md section 3 protocol on the GPU box's host cores: the CPU oracle on b clips, 1 warm-up +
-    3 timed runs (median) of (a) the necessary-work variant (one listener VQ encode per clip) and (b) the
-    reference-faithful variant (+3 redundant VQ encodes per clip, code/seq2seq_pretrain.py:497-500), at the fastest
+    """(subprocess) BASELINE.md section 3 protocol on the GPU box's host cores: the CPU oracle on b clips, 2 warm-ups +
+    median of 5 timed runs of (a) the necessary-work variant (one listener VQ encode per clip), 1 warm-up + median of 3 of
+    (b) the reference-faithful variant (+3 redundant VQ encodes per clip, code/seq2seq_pretrain.py:497-500), at the fastest
     thread count of a short probe (on a 2x64-core host the tiny per-step matmuls of the AR loop get slower with every
     extra thread), plus one single-thread run on 2 clips.  Bounded to about half a minute of CPU work."""
     from oracle import ref_cpu
@@ -80,8 +80,9 @@ def _cpu_worker(T, b):
         ref_cpu.forward_vq(sd, v_s, v_l, mask, with_speaker=True)
         ref_cpu.forward_vq(sd, v_s, v_l, mask, with_speaker=False)
 
-    def median_of(fn, runs=3):
-        fn()                                  # warm-up
+    def median_of(fn, runs, warmups):
+        for _ in range(warmups):
+            fn()
         ts = []
         for _ in range(runs):
             t0 = time.perf_counter()
@@ -90,8 +91,8 @@ def _cpu_worker(T, b):
         return sorted(ts)[len(ts) // 2], ts
 
     torch.set_num_threads(best_thr)
-    t_a, runs_a = median_of(necessary)
-    t_b, runs_b = median_of(faithful)
+    t_a, runs_a = median_of(necessary, 5, 2)
+    t_b, runs_b = median_of(faithful, 3, 1)
     torch.set_num_threads(1)
     n1 = min(2, b)
     t0 = time.perf_counter()
@@ -100,15 +101,15 @@ def _cpu_worker(T, b):
     print("CPU_BASELINE " + json.dumps({
         "value": b / t_a, "unit": "clips/s", "cores": best_thr, "kind": "port",
         "sample": "%d clips x T=%d through oracle/ref_cpu.slmft_forward(mode='val') (torch CPU fp32; %d of %d host threads = "
-                  "fastest in a T=%d probe); necessary-work variant, 1 warm-up + median of 3 runs (%s s)"
+                  "fastest in a T=%d probe); necessary-work variant, 2 warm-ups + median of 5 runs (%s s)"
                   % (b, T, best_thr, ncpu, probe_T, ", ".join("%.2f" % t for t in runs_a)),
         "reference_faithful": {"value": b / t_b, "unit": "clips/s",
-                               "what": "+3 redundant VQ encodes per clip as code/seq2seq_pretrain.py:497-500, median of 3 "
-                                       "runs (%s s)" % ", ".join("%.2f" % t for t in runs_b)},
+                               "what": "+3 redundant VQ encodes per clip as code/seq2seq_pretrain.py:497-500, 1 warm-up + "
+                                       "median of 3 runs (%s s)" % ", ".join("%.2f" % t for t in runs_b)},
         "single_thread": {"value": n1 / t_1, "unit": "clips/s", "cores": 1, "sample": "%d clips, one run of %.1f s" % (n1, t_1)}}))
 
 
-def cpu_baseline(T, timeout_s=240):
+def cpu_baseline(T, timeout_s=300):
     """Run the CPU oracle on a bounded sample in a subprocess (hard timeout: the bench never hangs on it)."""
     import subprocess
     try:
@@ -202,19 +203,21 @@ def main():
         out["rccl_ranks"] = rccl_ranks
     if world == 1 and args.mode == "bf16" and not args.no_parity_mode and args.samples == 1:
         # the same workload in the mode that meets north_star's tolerance (f32 operands, exact-f32 MFMA; VQ indices
-        # and generated tokens bit-identical to the oracle): 1 warm-up + 2 timed steps
+        # and generated tokens bit-identical to the oracle): 2 warm-ups + 5 timed steps
         del model, eng
         torch.cuda.empty_cache()
         pm = SLMFT(synthetic_seed=SEED, numeric_mode=L.MODE_PARITY_F32).eval()
-        pm(v_s, v_l, v_a, mask, mode="val", seed=SEED)
+        PM_WARM, PM_STEPS = 2, 5
+        for i in range(PM_WARM):
+            pm(v_s, v_l, v_a, mask, mode="val", seed=SEED + i)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for i in range(2):
+        for i in range(PM_STEPS):
             pm(v_s, v_l, v_a, mask, mode="val", seed=SEED + 100 + i)
         torch.cuda.synchronize(device)
-        dt = (time.perf_counter() - t0) / 2
-        out["parity_mode"] = {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "dtype": "f32", "steps": 2,
-                              "warmup": 1, "note": "same workload in DIMX_MODE_PARITY_F32 (the mode the oracle parity "
+        dt = (time.perf_counter() - t0) / PM_STEPS
+        out["parity_mode"] = {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "dtype": "f32", "steps": PM_STEPS,
+                              "warmup": PM_WARM, "note": "same workload in DIMX_MODE_PARITY_F32 (the mode the oracle parity "
                               "tests run in: indices bit-exact, coefficients <= 1e-4)"}
         eng = pm.engine(device)
     if not args.no_roofline:   # per-GPU kernel measurement on rank 0's device (for N > 1 the other ranks have left by now)

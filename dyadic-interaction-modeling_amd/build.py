@@ -28,24 +28,39 @@ def _hipcc():
     return "hipcc"
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _file_hash(paths, extra=""):
+    import hashlib
+    hsh = hashlib.sha256(extra.encode())
+    for f in paths:
+        with open(f, "rb") as fh:
+            hsh.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return hsh.hexdigest()
 
 
 def _compile(src):
+    """Compile one source unless its object was built from exactly these bytes (source + headers + flags): a content
+    hash next to the object, not mtimes -- the copy of the tree that travels to a GPU box does not keep timestamps, and a
+    stamp must never be written for an object that was not rebuilt from the hashed sources."""
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
-    if not _stale(obj, deps):
-        return obj, False
-    cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    want = _file_hash(deps, " ".join(FLAGS))
+    stamp = obj + ".srchash"
+    if os.path.exists(obj) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == want:
+                return obj, False
+    tmp = "%s.tmp.%d" % (obj, os.getpid())
+    cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    os.replace(tmp, obj)
+    with open(stamp, "w") as fh:
+        fh.write(want + "\n")
     return obj, True
 
 
@@ -77,21 +92,35 @@ def stale():
 
 
 def build(force=False):
+    """Build (or complete) the in-tree library.  Serialised across processes with an exclusive lock on csrc/_obj/.lock:
+    under torchrun every rank imports the package at once, and two hipcc runs into the same objects / the same .so could
+    hand a rank a half-written library.  The link goes to a temporary file that is renamed into place."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
-    if force:
-        for f in os.listdir(OBJ):
-            if os.path.isfile(os.path.join(OBJ, f)):
-                os.remove(os.path.join(OBJ, f))
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        res = list(ex.map(_compile, SOURCES))
-    objs = [o for o, _ in res]
-    if any(ch for _, ch in res) or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    with open(STAMP, "w") as fh:
-        fh.write(_src_hash() + "\n")
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():
+                return LIB   # another process finished the same build while this one waited for the lock
+            if force:
+                for f in os.listdir(OBJ):
+                    if f != ".lock" and os.path.isfile(os.path.join(OBJ, f)):
+                        os.remove(os.path.join(OBJ, f))
+            with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+                res = list(ex.map(_compile, SOURCES))
+            objs = [o for o, _ in res]
+            tmp = "%s.tmp.%d" % (LIB, os.getpid())
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+            os.replace(tmp, LIB)
+            with open(STAMP, "w") as fh:
+                fh.write(_src_hash() + "\n")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
     // a launch does not always land on XCD 0 (the rotation continues from the previous dispatch: observed after kernels
     // whose grid is not a multiple of 8).  Under any rotation the blocks of one XCD have distinct blockIdx >> 3, which
     // makes (xcc, blockIdx >> 3) a bijection onto (group, CU slot); that is checked, not assumed (seen[] below).
-    const int g = (int)(xcc_id() & 7), li = blockIdx.x >> 3;
+    const int g = (int)(xcc_id() & (a.fault ? 6u : 7u)), li = blockIdx.x >> 3;
     const unsigned stamp = (unsigned)(*a.step) + 1u;
     unsigned seen_old = 0;
     if (tid == 0) seen_old = atomicExch(a.seen + g * kGroupCUs + li, stamp);

@@ -65,8 +65,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round-to-nearest-
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(uint16_t, h);
 }
+// one v_cvt_pk_bf16_f32 (round-to-nearest-even, both halves); the scalar form above costs cvt + shift + or per pair
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
 inline uint16_t host_f32_to_bf16(float f) {
     uint32_t u;
@@ -376,6 +380,7 @@ struct ChainArgs {
     float* stats;            // [8][32][32][2] f32
     const float* colsum2;    // [g2.N] f32: row sums of the gamma-scaled second projection (defer && g2)
     int nbar;                                                // set by the launcher
+    int fault;  // test hook (dimx_debug_chain_fault): the blocks of XCD 2i+1 claim XCD 2i's slots -- a non-bijective placement
     int offA1, offW1, offRed1, offA2, offW2, offRed2;        // LDS plan, set by the launcher
 };
 size_t chain_plan(ChainArgs& a);

@@ -30,9 +30,12 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kHalf = 16384;        // one half-tile: 128 rows x 128 B
 constexpr int kBuf = 4 * kHalf;     // one k-tile: A0h A1h B0h B1h
+constexpr int kDefaultVar = 3;  // DMA placement of the main loop (see gemm256_kernel)
+constexpr bool kOverlapEpi = true;
 constexpr bool kPrio = true;  // s_setprio(1) around the MFMA segments: +7 % (without it 35.8 -> 33.3 % on the fused K/V projection)
 constexpr int kLds = 2 * kBuf;
 constexpr int kLdsTotal = kLds + 8 * 4096;  // + one 4 KiB epilogue scratch per wave = all 160 KiB
@@ -57,7 +60,10 @@ struct Big {
     OutSeg seg[8];
     int nseg, seg_width;
     int tiles_m, tiles_n, n_group, nkt;
-    int abl;  // tuning ablations (DIMX_G256_ABL): 1 no DMA in the loop, 2 no ds_reads, 4 no MFMA, 8 no setprio
+    unsigned long long* prof;  // tuning only (PROF instantiation): interval sums of block 0, waves 0 and 4
+    int nt_max;                // tiles of the busiest block
+    unsigned desync_slack, desync_full;  // start delay (shader cycles) spread over blocks with / without a spare tile slot
+    int abl;                   // tuning (DIMX_G256_ABL): 1 = no global stores in the epilogue, 2 = non-temporal bf16 stores
 };
 
 template <int ACT> __device__ __forceinline__ float act256(float x) {
@@ -77,27 +83,30 @@ template <int ACT> __device__ __forceinline__ float act256(float x) {
     return x;
 }
 
-// XCD-local tile q of XCD x -> (tile_m, tile_n); false when past the XCD's last tile.  Order: column-tile groups of
-// n_group (the last one may be narrower); inside a group row tile major, column tile minor.
+// Tile order (one global sequence): column-tile groups of n_group (the last one may be narrower); inside a group row tile
+// major, column tile minor -- consecutive positions share a row tile (its A panel is fetched once) and a W group that
+// fits the L2.  XCD x owns the contiguous positions [T x / 8, T (x + 1) / 8) (round 3: balanced to +-1 tile; the modulo-8
+// row split of round 2 left half the XCDs a whole row of tiles short), its blocks take them round-robin.
+// XCD-local tile q of XCD x -> (tile_m, tile_n); false when past the XCD's last tile.
 __device__ __forceinline__ bool tile_of(const Big& a, int x, int q, int& tm, int& tn) {
-    const int tml = (a.tiles_m - x + 7) >> 3;  // row tiles of this XCD: tm = x, x + 8, ...
-    if (tml <= 0) return false;
-    const int per_group = tml * a.n_group;
+    const int total = a.tiles_m * a.tiles_n;
+    const int lo = (int)((long)total * x >> 3), hi = (int)((long)total * (x + 1) >> 3);
+    const int p = lo + q;
+    if (p >= hi) return false;
+    const int per_group = a.tiles_m * a.n_group;
     const int full = a.tiles_n / a.n_group;
     int gi, r, w;
-    if (q < full * per_group) {
-        gi = q / per_group;
-        r = q - gi * per_group;
+    if (p < full * per_group) {
+        gi = p / per_group;
+        r = p - gi * per_group;
         w = a.n_group;
     } else {
         gi = full;
-        r = q - full * per_group;
+        r = p - full * per_group;
         w = a.tiles_n - full * a.n_group;
-        if (w <= 0) return false;
     }
     const int ti = r / w;
-    if (ti >= tml) return false;
-    tm = ti * 8 + x;
+    tm = ti;
     tn = gi * a.n_group + (r - ti * w);
     return true;
 }
@@ -107,12 +116,80 @@ __device__ __forceinline__ bool tile_of(const Big& a, int x, int q, int& tm, int
 // leave as 16-byte row-contiguous pieces, 8 lanes per 128-byte line (a direct store of the accumulator layout
 // touches 32 lines per instruction and measured 24 us per tile).  bf16 output: one pass over 32 x 64; f32 output: two
 // passes over 32 x 32.  Bias / activation run before the transpose, positional rows / residual after it.
-template <typename OutT, int ACT>
-__device__ __forceinline__ void store_chunk(const Big& a, const f32x16_t& acc0, const f32x16_t& acc1, int mrow0, int ncol0,
-                                            unsigned char* scratch, int lane) {
+//
+// Everything the 64 lanes share is kept on the scalar unit (round 3): the chunk's first row / column are wave-uniform,
+// so the output segment is ONE scalar lookup (a per-lane index made hipcc fetch the OutSeg with global loads and wait
+// vmcnt(0) -- draining the 64 KiB of LDS-DMA the main loop keeps in flight, four times per tile), the bias comes through
+// scalar loads for the same reason, and the (clip, frame) split of a row is one division per chunk instead of one
+// 35-instruction sequence per row.
+typedef const __attribute__((address_space(4))) float cfloat_t;
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+
+// What the four chunks of a wave's tile share, computed once per tile: the 64 output columns of a wave lie in one segment
+// (seg_width % 64 == 0), so segment, head and column of this lane's 16-byte piece are fixed for the tile.
+template <typename OutT> struct EpiTile {
+    OutT* pcol;   // segment base + head offset + column of this lane's piece (per lane)
+    long sb, st;  // element strides of (clip, frame) in the segment (wave-uniform)
+    int n;        // first column of this lane's piece in pass 0 (f32 output: pass 1 is 32 columns further)
+};
+template <typename OutT>
+__device__ __forceinline__ EpiTile<OutT> epi_tile(const Big& a, int ncol0, int lane) {
+    constexpr bool BF = sizeof(OutT) == 2;
+    EpiTile<OutT> e;
+    int s = 0, nbase = ncol0 < a.N ? ncol0 : 0;
+    if (a.nseg > 1) {
+        s = nbase / a.seg_width;
+        nbase -= s * a.seg_width;
+    }
+    const OutSeg sg = a.seg[s];  // wave-uniform index: scalar loads (a per-lane index made this a vmcnt(0) global load)
+    const int c16 = lane & 7;
+    const int nn = nbase + (BF ? c16 * 8 : c16 * 4);
+    int hh, dd;
+    if (sg.D == 64) {
+        hh = nn >> 6;
+        dd = nn & 63;
+    } else {
+        hh = nn / sg.D;
+        dd = nn - hh * sg.D;
+    }
+    e.pcol = (OutT*)sg.ptr + (long)hh * sg.sh + dd;
+    e.sb = sg.sb;
+    e.st = sg.st;
+    e.n = ncol0 + (BF ? c16 * 8 : c16 * 4);
+    return e;
+}
+
+template <typename OutT, int ACT, bool PLAIN>
+__device__ __forceinline__ void store_chunk(const Big& a, const EpiTile<OutT>& e, const f32x16_t& acc0, const f32x16_t& acc1,
+                                            int mrow0, int ncol0, unsigned char* scratch, int lane) {
     const int half = lane >> 5, l31 = lane & 31;
     constexpr bool BF = sizeof(OutT) == 2;
     constexpr int PASSES = BF ? 1 : 2;
+    if (mrow0 >= a.M || ncol0 >= a.N) return;  // wave-uniform: nothing of this chunk is inside the matrix
+    // LDS traffic of the epilogue goes through inline asm: for a C++ access hipcc waits vmcnt(0) first (a pending LDS-DMA is
+    // a pending LDS write to it) and drains the prefetch pipeline the next tile is about to need
+    const unsigned sbase = (unsigned)(size_t)(lds_void_t*)scratch;
+    // (clip, frame) of the chunk's first row: one wave-uniform division per chunk; the lane's four rows (lane / 8 + 8 i)
+    // follow by additions (rowT == 1 or rowT >= 32, checked by the launcher: at most one wrap per step)
+    int b0 = mrow0, t0 = 0;
+    if (a.rowT > 1) {
+        b0 = mrow0 / a.rowT;
+        t0 = mrow0 - b0 * a.rowT;
+    }
+    const int r = lane >> 3;
+    int bl = b0, tl = t0 + r;
+    if (a.rowT > 1) {
+        if (tl >= a.rowT) {
+            tl -= a.rowT;
+            ++bl;
+        }
+    } else {
+        bl = b0 + r;
+        tl = 0;
+    }
+    const long step8 = a.rowT > 1 ? 8 * e.st : 8 * e.sb;        // eight rows further inside a clip
+    const long wrap = a.rowT > 1 ? e.sb - (long)a.rowT * e.st : 0;  // ... and across a clip boundary
+    const long off0 = (long)bl * e.sb + (long)tl * e.st;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         // ---- write: row l31 of the chunk
@@ -122,89 +199,112 @@ __device__ __forceinline__ void store_chunk(const Big& a, const f32x16_t& acc0, 
             const f32x16_t& acc = nh == 0 ? acc0 : acc1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = ncol0 + nh * 32 + 8 * q + 4 * half;
                 float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-                if (a.bias) {
-                    const float4 bv = *(const float4*)(a.bias + (n < a.N ? n : 0));
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (!PLAIN && a.bias) {  // 8 consecutive columns through the scalar cache; this lane's half of them
+                    const int n0 = ncol0 + nh * 32 + 8 * q;
+                    const f32x8_t bv = *(const __attribute__((address_space(4))) f32x8_t*)(cfloat_t*)(a.bias + (n0 + 8 <= a.N ? n0 : 0));
+                    v.x += half ? bv[4] : bv[0];
+                    v.y += half ? bv[5] : bv[1];
+                    v.z += half ? bv[6] : bv[2];
+                    v.w += half ? bv[7] : bv[3];
                 }
                 v.x = act256<ACT>(v.x); v.y = act256<ACT>(v.y); v.z = act256<ACT>(v.z); v.w = act256<ACT>(v.w);
                 if (BF) {
                     const int c16 = nh * 4 + q;  // 16-byte chunk of the 128-byte row; this lane's half of it
-                    *(uint2*)(scratch + l31 * 128 + ((c16 ^ (l31 & 7)) << 4) + half * 8) =
-                        make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                    u32x2_t pk;
+                    pk[0] = pack_bf16x2(v.x, v.y);
+                    pk[1] = pack_bf16x2(v.z, v.w);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(sbase + (unsigned)(l31 * 128 + ((c16 ^ (l31 & 7)) << 4) + half * 8)), "v"(pk) : "memory");
                 } else {
                     const int c16 = 2 * q + half;
-                    *(float4*)(scratch + l31 * 128 + ((c16 ^ (l31 & 7)) << 4)) = v;
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(sbase + (unsigned)(l31 * 128 + ((c16 ^ (l31 & 7)) << 4))), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
                 }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave reads it back: no barrier needed
         // ---- read back row-contiguous: 8 lanes per row, 4 row groups
         const int c16 = lane & 7;
-        const int n = BF ? ncol0 + c16 * 8 : ncol0 + ps * 32 + c16 * 4;
-        int s = 0, nn = n < a.N ? n : 0;
-        if (a.nseg > 1) {
-            s = nn / a.seg_width;
-            nn -= s * a.seg_width;
-        }
-        const OutSeg sg = a.seg[s];
-        const int hh = nn / sg.D, dd = nn - hh * sg.D;
+        const int n = e.n + (BF ? 0 : ps * 32);
+        OutT* const pcol = e.pcol + (BF ? 0 : ps * 32);
+        u32x4_t raw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = (lane >> 3) + 8 * i;
-            const uint4 raw = *(const uint4*)(scratch + row * 128 + ((c16 ^ (row & 7)) << 4));
-            const int m = mrow0 + row;
-            if (m >= a.M || n >= a.N) continue;
-            int b = m, t = 0;
-            if (a.rowT > 1) {
-                b = m / a.rowT;
-                t = m - b * a.rowT;
-            }
-            OutT* p = (OutT*)sg.ptr + (long)b * sg.sb + (long)t * sg.st + (long)hh * sg.sh + dd;
-            if (BF) {
-                uint4 o = raw;
-                if (a.rowadd_mode || a.residual) {  // rare for bf16 destinations: unpack, add, repack
-                    float f[8];
-                    const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+            const int row = r + 8 * i;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(raw[i]) : "v"(sbase + (unsigned)(row * 128 + ((c16 ^ (row & 7)) << 4))) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        long off = off0;
+        int b = bl, t = tl;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f[2 * e] = __builtin_bit_cast(float, w4[e] << 16);
-                        f[2 * e + 1] = __builtin_bit_cast(float, w4[e] & 0xffff0000u);
+        for (int i = 0; i < 4; ++i) {
+            const int m = mrow0 + r + 8 * i;
+            if (i > 0) {
+                off += step8;
+                if (a.rowT > 1) {
+                    t += 8;
+                    if (t >= a.rowT) {
+                        t -= a.rowT;
+                        ++b;
+                        off += wrap;
+                    }
+                } else {
+                    b += 8;
+                }
+            }
+            if (m >= a.M || n >= a.N || (a.abl & 1)) continue;
+            OutT* p = pcol + off;
+            if (BF) {
+                uint4 o = __builtin_bit_cast(uint4, raw[i]);
+                if (!PLAIN && (a.rowadd_mode || a.residual)) {  // rare for bf16 destinations: unpack, add, repack
+                    float f[8];
+                    const uint32_t w4[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        f[2 * k] = __builtin_bit_cast(float, w4[k] << 16);
+                        f[2 * k + 1] = __builtin_bit_cast(float, w4[k] & 0xffff0000u);
                     }
                     if (a.rowadd_mode) {
                         const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b / a.rowadd_div + a.rowadd_off : a.rowadd_off);
                         const float* pr = a.rowadd + (size_t)ri * a.ld_rowadd + n;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] += pr[e] * a.rowadd_scale;
+                        for (int k = 0; k < 8; ++k) f[k] += pr[k] * a.rowadd_scale;
                     }
                     if (a.residual) {
                         const float* pr = a.residual + (size_t)m * a.ldr + n;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] += pr[e];
+                        for (int k = 0; k < 8; ++k) f[k] += pr[k];
                     }
                     o = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
                 }
                 *(uint4*)p = o;
             } else {
-                float4 v = __builtin_bit_cast(float4, raw);
-                if (a.rowadd_mode) {
+                float4 v = __builtin_bit_cast(float4, raw[i]);
+                if (!PLAIN && a.rowadd_mode) {
                     const int ri = a.rowadd_mode == 1 ? t : (a.rowadd_mode == 2 ? b / a.rowadd_div + a.rowadd_off : a.rowadd_off);
                     const float4 q4 = *(const float4*)(a.rowadd + (size_t)ri * a.ld_rowadd + n);
                     v.x += q4.x * a.rowadd_scale; v.y += q4.y * a.rowadd_scale; v.z += q4.z * a.rowadd_scale; v.w += q4.w * a.rowadd_scale;
                 }
-                if (a.residual) {
+                if (!PLAIN && a.residual) {
                     const float4 q4 = *(const float4*)(a.residual + (size_t)m * a.ldr + n);
                     v.x += q4.x; v.y += q4.y; v.z += q4.z; v.w += q4.w;
                 }
                 *(float4*)p = v;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pass / chunk overwrites
     }
 }
 
-template <typename OutT, int ACT>
+// VAR = where the two LDS-DMA pieces of a phase's half-tile re-staging are issued (tools/g256_var.py measures them):
+//   0  both in the load segment (round 2)
+//   1  both inside the wave's own MFMA segment of the PREVIOUS phase (same landing distance, no DMA in the load segment)
+//   2  first piece in the load segment, second after the fourth MFMA of the same phase
+//   3  both inside the MFMA segment of the same phase (after the 2nd and the 6th MFMA)
+// A load segment that carries two DMA issues next to 4-12 ds_read_b128 is longer than the partner's 8-MFMA segment (the
+// texture addresser takes 8 wave instructions from the four loading waves at once); among bare MFMAs an issue is cheap.
+// PROF: s_memtime stamps at the three points of a phase where lgkmcnt(0) holds anyway (MFMA segment start / end, after the
+// closing barrier); block 0, waves 0 and 4 write 4 x 3 interval sums + the k-tile count to a.prof.
+template <typename OutT, int ACT, bool PLAIN, int VAR, bool PROF>
 __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -222,6 +322,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
     if (ntiles == 0) return;
     const int nkt = a.nkt;
     const long total = (long)ntiles * nkt;  // k-tiles this block computes
+    // De-phase the blocks.  Persistent blocks of equal work run in lock step, so all 256 reach their epilogue together:
+    // a 32 MB burst of stores (every CU's 128 KiB tile) that the memory side takes ~15k cycles to absorb while no CU
+    // computes, then silence on the write path for a whole tile.  A start delay spread over one tile time turns that
+    // into a steady stream under the other CUs' MFMA work.  Blocks with a spare tile slot (fewer tiles than the busiest
+    // block) take the delay for free; the busiest blocks take desync_full (0 unless no block has slack).
+    {
+        const unsigned span = ntiles < a.nt_max ? a.desync_slack : a.desync_full;
+        if (span) {
+            const unsigned frac = ((blockIdx.x * 0x9E3779B1u) >> 16) & 0xffffu;  // well-spread over the blocks of every XCD
+            const unsigned long long wait = ((unsigned long long)span * frac) >> 16;
+            unsigned long long t0, t1;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+            do {
+                __builtin_amdgcn_s_sleep(32);
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+            } while (t1 - t0 < wait);
+        }
+    }
 
     // ---- DMA addressing: wave w moves local rows [16w, 16w + 16) of every half-tile as two 8-row pieces.  The W
     // half-tiles hold PERMUTED columns: local row lr of column half nh is column (lr / 32) * 64 + nh * 32 + lr % 32 of
@@ -263,15 +381,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
             c.a0 += 64; c.a1 += 64; c.b0 += 64; c.b1 += 64;
         }
     };
-    auto stage_a = [&](const Cur& c, int buf) {
+    // piece 0 / 1 of a half-tile's re-staging (PC = -1: both)
+    auto stage_a = [&](const Cur& c, int buf, int pc) {
         unsigned char* dst = smem + buf * kBuf + c.hA * kHalf + wave * 2048;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(a.A + c.a0), (lds_void_t*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(a.A + c.a1), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        if (pc != 1) __builtin_amdgcn_global_load_lds((glb_void_t*)(a.A + c.a0), (lds_void_t*)dst, 16, 0, 0);
+        if (pc != 0) __builtin_amdgcn_global_load_lds((glb_void_t*)(a.A + c.a1), (lds_void_t*)(dst + 1024), 16, 0, 0);
     };
-    auto stage_b = [&](const Cur& c, int buf) {
+    auto stage_b = [&](const Cur& c, int buf, int pc) {
         unsigned char* dst = smem + buf * kBuf + (2 + c.hB) * kHalf + wave * 2048;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(a.W + c.b0), (lds_void_t*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(a.W + c.b1), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        if (pc != 1) __builtin_amdgcn_global_load_lds((glb_void_t*)(a.W + c.b0), (lds_void_t*)dst, 16, 0, 0);
+        if (pc != 0) __builtin_amdgcn_global_load_lds((glb_void_t*)(a.W + c.b1), (lds_void_t*)(dst + 1024), 16, 0, 0);
     };
 
     // ---- fragment addressing (local row inside a half-tile; the swizzle term depends on l31 only)
@@ -302,18 +421,66 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
     Cur c1{j, 0, 1, 1, 0u, 0u, 0u, 0u};  // halves (A1h, B1h): runs one k-tile ahead
     bind_tile(c2);
     bind_tile(c1);
-    stage_a(c2, 0);
-    stage_b(c2, 0);
-    stage_b(c1, 0);
-    stage_a(c1, 0);
+    stage_a(c2, 0, -1);
+    stage_b(c2, 0, -1);
+    stage_b(c1, 0, -1);
+    stage_a(c1, 0, -1);
     advance(c2);  // -> k-tile 1
     advance(c1);  // -> k-tile 1
-    stage_a(c2, 1);
-    stage_b(c2, 1);
+    stage_a(c2, 1, -1);
+    stage_b(c2, 1, -1);
     advance(c2);  // -> k-tile 2
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (VAR == 1) {  // phase 1's re-staging is issued one phase early in this form
+        stage_b(c1, 1, -1);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
     raw_barrier();
     if (wr == 1) raw_barrier();  // waves 4-7 run half a phase behind
+
+    unsigned long long psum[17];
+    unsigned long long tprev = 0;
+    if (PROF) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) psum[i] = 0;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+    }
+#define G256_STAMP(SLOT)                                                                    \
+    do {                                                                                    \
+        if (PROF) {                                                                         \
+            unsigned long long tn_;                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_)::"memory");     \
+            psum[SLOT] += tn_ - tprev;                                                      \
+            tprev = tn_;                                                                    \
+        }                                                                                   \
+    } while (0)
+#define G256_WAIT_LOADSEG()                                                   \
+    do {                                                                      \
+        if (PROF && (a.abl & 8)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (VAR == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");        \
+        else if (VAR == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 \
+    } while (0)
+// one MFMA segment: quadrant accumulators ACC[0..1] += FB[ks] x fa[rb][ks]; H1 / H2 / H3 run after the 2nd / 4th / 6th MFMA
+#define G256_MFMA_SEG(ACC, FB, H1, H2, H3)                                                                              \
+    do {                                                                                                                \
+        if (kPrio) __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
+            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                                            \
+                ACC[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FB[ks]),                 \
+                                                                  __builtin_bit_cast(bf16x8_t, fa[rb][ks]), ACC[rb], 0, 0, 0); \
+            if (VAR != 0) {                                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                if (ks == 0) { H1; }                                                                                    \
+                if (ks == 1) { H2; }                                                                                    \
+                if (ks == 2) { H3; }                                                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+            }                                                                                                           \
+        }                                                                                                               \
+        if (kPrio) __builtin_amdgcn_s_setprio(0);                                                                       \
+    } while (0)
+#define G256_NOP ((void)0)
 
     u32x4_t fa[2][4], fb0[4], fb1[4];
     unsigned bo = 0;  // byte offset of the k-tile buffer being computed
@@ -322,44 +489,50 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
         // ================= phase 1: quadrant (0,0) -- read A(row half 0) and W(col half 0); stage B1h of g + 1
         {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ds_read128<0>(fb0[ks], baddr[ks] + bo);
+            for (int ks = 0; ks < 4; ++ks)
+                if (!(PROF && (a.abl & 4))) ds_read128<0>(fb0[ks], baddr[ks] + bo);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                if (PROF && (a.abl & 16)) continue;
                 ds_read128<0>(fa[0][ks], aaddr[ks] + bo);
                 ds_read128<4096>(fa[1][ks], aaddr[ks] + bo);
             }
         }
-        stage_b(c1, buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (VAR == 0) stage_b(c1, buf ^ 1, -1);
+        if (VAR == 2) stage_b(c1, buf ^ 1, 0);
+        if (PROF && (a.abl & 8)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G256_STAMP(13); }
+        G256_WAIT_LOADSEG();
         raw_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kPrio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                acc[0][0][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb0[ks]),
-                                                                       __builtin_bit_cast(bf16x8_t, fa[rb][ks]), acc[0][0][rb], 0, 0, 0);
-        if (kPrio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        G256_STAMP(0);
+        if (VAR == 1) G256_MFMA_SEG(acc[0][0], fb0, stage_a(c1, buf ^ 1, 0), G256_NOP, stage_a(c1, buf ^ 1, 1));
+        else if (VAR == 2) G256_MFMA_SEG(acc[0][0], fb0, G256_NOP, stage_b(c1, buf ^ 1, 1), G256_NOP);
+        else if (VAR == 3) G256_MFMA_SEG(acc[0][0], fb0, stage_b(c1, buf ^ 1, 0), G256_NOP, stage_b(c1, buf ^ 1, 1));
+        else G256_MFMA_SEG(acc[0][0], fb0, G256_NOP, G256_NOP, G256_NOP);
+        G256_STAMP(1);
         raw_barrier();
+        G256_STAMP(2);
         // ================= phase 2: quadrant (0,1) -- read W(col half 1); stage A1h of g + 1
         {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ds_read128<kHalf>(fb1[ks], baddr[ks] + bo);
         }
-        stage_a(c1, buf ^ 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (VAR == 0) stage_a(c1, buf ^ 1, -1);
+        if (VAR == 2) stage_a(c1, buf ^ 1, 0);
+        if (PROF && (a.abl & 8)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G256_STAMP(14); }
+        G256_WAIT_LOADSEG();
         raw_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kPrio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                acc[0][1][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb1[ks]),
-                                                                       __builtin_bit_cast(bf16x8_t, fa[rb][ks]), acc[0][1][rb], 0, 0, 0);
-        if (kPrio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        G256_STAMP(3);
+        if (VAR == 1) G256_MFMA_SEG(acc[0][1], fb1, stage_a(c2, buf, 0), G256_NOP, stage_a(c2, buf, 1));
+        else if (VAR == 2) G256_MFMA_SEG(acc[0][1], fb1, G256_NOP, stage_a(c1, buf ^ 1, 1), G256_NOP);
+        else if (VAR == 3) G256_MFMA_SEG(acc[0][1], fb1, stage_a(c1, buf ^ 1, 0), G256_NOP, stage_a(c1, buf ^ 1, 1));
+        else G256_MFMA_SEG(acc[0][1], fb1, G256_NOP, G256_NOP, G256_NOP);
+        G256_STAMP(4);
         raw_barrier();
+        G256_STAMP(5);
         advance(c1);
         // ================= phase 3: quadrant (1,1) -- read A(row half 1); stage A0h of g + 2
         {
@@ -369,44 +542,55 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
                 ds_read128<kHalf + 4096>(fa[1][ks], aaddr[ks] + bo);
             }
         }
-        stage_a(c2, buf);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (VAR == 0) stage_a(c2, buf, -1);
+        if (VAR == 2) stage_a(c2, buf, 0);
+        if (PROF && (a.abl & 8)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G256_STAMP(15); }
+        G256_WAIT_LOADSEG();
         raw_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kPrio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                acc[1][1][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb1[ks]),
-                                                                       __builtin_bit_cast(bf16x8_t, fa[rb][ks]), acc[1][1][rb], 0, 0, 0);
-        if (kPrio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        G256_STAMP(6);
+        if (VAR == 1) G256_MFMA_SEG(acc[1][1], fb1, stage_b(c2, buf, 0), G256_NOP, stage_b(c2, buf, 1));
+        else if (VAR == 2) G256_MFMA_SEG(acc[1][1], fb1, G256_NOP, stage_a(c2, buf, 1), G256_NOP);
+        else if (VAR == 3) G256_MFMA_SEG(acc[1][1], fb1, stage_a(c2, buf, 0), G256_NOP, stage_a(c2, buf, 1));
+        else G256_MFMA_SEG(acc[1][1], fb1, G256_NOP, G256_NOP, G256_NOP);
+        G256_STAMP(7);
         raw_barrier();
+        G256_STAMP(8);
         // ================= phase 4: quadrant (1,0) -- everything is in registers; stage B0h of g + 2
-        stage_b(c2, buf);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (VAR == 0) stage_b(c2, buf, -1);
+        if (VAR == 2) stage_b(c2, buf, 0);
+        if (PROF && (a.abl & 8)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G256_STAMP(16); }
+        G256_WAIT_LOADSEG();
         raw_barrier();
-        if (kPrio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                acc[1][0][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb0[ks]),
-                                                                       __builtin_bit_cast(bf16x8_t, fa[rb][ks]), acc[1][0][rb], 0, 0, 0);
-        if (kPrio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        G256_STAMP(9);
+        if (VAR == 1) {  // c1 already points one k-tile further (advanced after phase 2): next phase 1's B1h into THIS buffer
+            G256_MFMA_SEG(acc[1][0], fb0, stage_b(c1, buf, 0), G256_NOP, stage_b(c1, buf, 1));
+        } else if (VAR == 2) G256_MFMA_SEG(acc[1][0], fb0, G256_NOP, stage_b(c2, buf, 1), G256_NOP);
+        else if (VAR == 3) G256_MFMA_SEG(acc[1][0], fb0, stage_b(c2, buf, 0), G256_NOP, stage_b(c2, buf, 1));
+        else G256_MFMA_SEG(acc[1][0], fb0, G256_NOP, G256_NOP, G256_NOP);
+        G256_STAMP(10);
         raw_barrier();
+        G256_STAMP(11);
         advance(c2);
         bo ^= (unsigned)kBuf;
 
         // ================= end of an output tile: store, clear, move on (no barriers in here)
         if (++cu_kt == nkt) {
             unsigned char* scratch = smem + kLds + wave * 4096;
+            // Both wave groups store at the same time: group 0 lets group 1 finish its last MFMA segment first (one extra
+            // barrier here), group 1 pays its extra barrier after the stores -- the half-phase stagger is the same afterwards.
+            // Without the pair the stagger barriers serialise the two epilogues (group 1 waits for group 0's stores at its
+            // closing barrier, then group 0 waits for group 1's).
+            if (kOverlapEpi && wr == 0) raw_barrier();
+            const EpiTile<OutT> et = epi_tile<OutT>(a, cu_n0 + wc * 64, lane);
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
-                    store_chunk<OutT, ACT>(a, acc[mh][0][rb], acc[mh][1][rb], cu_m0 + mh * 128 + wr * 64 + rb * 32,
-                                           cu_n0 + wc * 64, scratch, lane);
+                    store_chunk<OutT, ACT, PLAIN>(a, et, acc[mh][0][rb], acc[mh][1][rb], cu_m0 + mh * 128 + wr * 64 + rb * 32,
+                                                  cu_n0 + wc * 64, scratch, lane);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         acc[mh][0][rb][r] = 0.f;
@@ -420,10 +604,232 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
                 cu_m0 = tm * 256;
                 cu_n0 = tn * 256;
             }
+            if (kOverlapEpi && wr == 1) raw_barrier();
+            if (PROF) {  // own epilogue in its own slot
+                unsigned long long tn_;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_)::"memory");
+                psum[12] += tn_ - tprev;
+                tprev = tn_;
+            }
         }
     }
     if (wr == 0) raw_barrier();  // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dummy stagings past the end must land before the LDS is released
+    if (PROF && a.prof && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) {
+        unsigned long long* o = a.prof + (wave >> 2) * 32;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) o[i] = psum[i];
+        o[17] = (unsigned long long)total;
+    }
+#undef G256_STAMP
+#undef G256_WAIT_LOADSEG
+#undef G256_MFMA_SEG
+#undef G256_NOP
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two phases per k-tile (round 3).  The four-phase loop above pays two barrier rendezvous per 8 MFMAs of a wave, and an
+// LDS-DMA issue inside an MFMA segment blocks that wave for ~60 cycles (8 pieces per wave and k-tile = +47 % on its 1024
+// matrix cycles), while a load segment as short as a 256-cycle MFMA segment has no room for them either (four waves'
+// pieces queue in the texture addresser at ~25 cycles each).  Here a phase is HALF a k-tile -- both column halves of one
+// row half, 16 MFMAs = 512 cycles per wave -- and the load segment next to it has the room:
+//   phase A: read W(col half 0), W(col half 1), A(row half 0)  [16 ds_read_b128], issue 4 pieces;  quadrants (0,0), (0,1)
+//   phase B: read A(row half 1)                                 [ 8 ds_read_b128], issue 4 pieces;  quadrants (1,1), (1,0)
+// Staging: phase A's load segment re-stages B1h and A1h of k-tile g + 1 into the other buffer (B1h first:
+// it is needed one phase earlier), phase B's re-stages A0h and B0h of k-tile g + 2 into this buffer -- each half-tile one
+// interval after its last reader retired (every load segment ends with lgkmcnt(0) BEFORE its barrier, so a half-tile read
+// in one interval may be overwritten from the next), each issued >= 2 intervals before the counted vmcnt that retires it
+// and read one phase after that wait: vmcnt(8) in phase A (A1h of this k-tile landed), vmcnt(6) in phase B ({A0h B0h B1h}
+// of the next k-tile landed).  (With the pieces inside the MFMA segments instead -- 6 in phase B, 2 in phase A -- this loop
+// measured 40.4 % of the bf16 peak on the K/V projection against 39.2 % for the four-phase loop on the same box.)  Waves 4-7
+// still run half a phase behind waves 0-3; epilogue and tile walk as above.
+template <typename OutT, int ACT, bool PLAIN>
+__global__ __launch_bounds__(512) void gemm256p2_kernel(const Big a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, nb = gridDim.x >> 3;
+    int ntiles = 0;
+    {
+        int tm, tn;
+        for (int q = j; tile_of(a, x, q, tm, tn); q += nb) ++ntiles;
+    }
+    if (ntiles == 0) return;
+    const int nkt = a.nkt;
+    const long total = (long)ntiles * nkt;
+
+    const int r0 = 16 * wave + (lane >> 3), r1 = r0 + 8;
+    const int dc0 = ((lane & 7) ^ ((r0 >> 1) & 7)) * 8, dc1 = ((lane & 7) ^ ((r1 >> 1) & 7)) * 8;
+    const int wcol0 = (r0 >> 5) * 64 + (r0 & 31), wcol1 = (r1 >> 5) * 64 + (r1 & 31);
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+    // cursor X: A(row half 0) + W(col half 0), two k-tiles ahead; cursor Y: A(row half 1) + W(col half 1), one k-tile ahead
+    struct Cur {
+        int q, kt, h;
+        unsigned a0, a1, b0, b1;
+    };
+    auto bind = [&](Cur& c) {
+        int tm, tn;
+        if (!tile_of(a, x, c.q, tm, tn)) return false;
+        const int mo = tm * 256 + c.h * 128, no = tn * 256 + c.h * 32;
+        int ra = mo + r0, rb = mo + r1, n0 = no + wcol0, n1 = no + wcol1;
+        ra = ra < a.M ? ra : a.M - 1;
+        rb = rb < a.M ? rb : a.M - 1;
+        n0 = n0 < a.N ? n0 : a.N - 1;
+        n1 = n1 < a.N ? n1 : a.N - 1;
+        c.a0 = (unsigned)ra * (unsigned)a.lda + dc0;
+        c.a1 = (unsigned)rb * (unsigned)a.lda + dc1;
+        c.b0 = (unsigned)n0 * (unsigned)a.ldw + dc0;
+        c.b1 = (unsigned)n1 * (unsigned)a.ldw + dc1;
+        return true;
+    };
+    auto advance = [&](Cur& c) {
+        if (++c.kt == nkt) {
+            c.kt = 0;
+            c.q += nb;
+            if (!bind(c)) {
+                const unsigned back = (unsigned)(nkt - 1) * 64;
+                c.a0 -= back; c.a1 -= back; c.b0 -= back; c.b1 -= back;
+            }
+        } else {
+            c.a0 += 64; c.a1 += 64; c.b0 += 64; c.b1 += 64;
+        }
+    };
+    // one 1 KiB LDS-DMA piece: 8 rows x 128 B of A or W -> half-tile `slot` (0 A0h, 1 A1h, 2 B0h, 3 B1h) of buffer `buf`
+    auto piece = [&](const bf16* base, unsigned off, int buf, int slot, int second) {
+        unsigned char* dst = smem + buf * kBuf + slot * kHalf + wave * 2048 + second * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off), (lds_void_t*)dst, 16, 0, 0);
+    };
+
+    const unsigned sw = (l31 >> 1) & 7;
+    unsigned aaddr[4], baddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned ko = ((unsigned)(2 * ks + half) ^ sw) << 4;
+        aaddr[ks] = lds0 + (wr * 64 + l31) * 128 + ko;
+        baddr[ks] = lds0 + 2 * kHalf + (wc * 32 + l31) * 128 + ko;
+    }
+    f32x16_t acc[2][2][2];  // [row half][col half][row block]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) (&acc[0][0][0])[i][r] = 0.f;
+
+    int cu_q = j, cu_kt = 0, cu_m0 = 0, cu_n0 = 0;
+    {
+        int tm, tn;
+        tile_of(a, x, cu_q, tm, tn);
+        cu_m0 = tm * 256;
+        cu_n0 = tn * 256;
+    }
+    // ---- prologue, in the steady-state issue order: {A0h B0h}(0), {B1h A1h}(0), {A0h B0h}(1)
+    Cur cx{j, 0, 0, 0u, 0u, 0u, 0u};
+    Cur cy{j, 0, 1, 0u, 0u, 0u, 0u};
+    bind(cx);
+    bind(cy);
+    piece(a.A, cx.a0, 0, 0, 0); piece(a.A, cx.a1, 0, 0, 1);
+    piece(a.W, cx.b0, 0, 2, 0); piece(a.W, cx.b1, 0, 2, 1);
+    piece(a.W, cy.b0, 0, 3, 0); piece(a.W, cy.b1, 0, 3, 1);
+    piece(a.A, cy.a0, 0, 1, 0); piece(a.A, cy.a1, 0, 1, 1);
+    advance(cx);  // -> k-tile 1
+    advance(cy);  // -> k-tile 1
+    piece(a.A, cx.a0, 1, 0, 0); piece(a.A, cx.a1, 1, 0, 1);
+    piece(a.W, cx.b0, 1, 2, 0); piece(a.W, cx.b1, 1, 2, 1);
+    advance(cx);  // -> k-tile 2
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // {A0h B0h B1h}(0) landed
+    raw_barrier();
+    if (wr == 1) raw_barrier();  // waves 4-7 run half a phase behind
+
+#define P2_MFMA(ACC, FB, KS, RB)                                                                                          \
+    ACC[RB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FB[KS]), __builtin_bit_cast(bf16x8_t, fa[RB][KS]), \
+                                                      ACC[RB], 0, 0, 0)
+// 16 MFMAs, nothing else: for every k-step the two row blocks of quadrant X, then of quadrant Y
+#define P2_SEG(ACCX, FBX, ACCY, FBY)                         \
+    do {                                                     \
+        if (kPrio) __builtin_amdgcn_s_setprio(1);            \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {   \
+            P2_MFMA(ACCX, FBX, ks, 0);                       \
+            P2_MFMA(ACCX, FBX, ks, 1);                       \
+            P2_MFMA(ACCY, FBY, ks, 0);                       \
+            P2_MFMA(ACCY, FBY, ks, 1);                       \
+        }                                                    \
+        if (kPrio) __builtin_amdgcn_s_setprio(0);            \
+    } while (0)
+
+    u32x4_t fa[2][4], fb0[4], fb1[4];
+    unsigned bo = 0;
+    for (long g = 0; g < total; ++g) {
+        const int buf = (int)(bo != 0);
+        // ================= phase A: quadrants (0,0), (0,1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ds_read128<0>(fb0[ks], baddr[ks] + bo);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            ds_read128<0>(fa[0][ks], aaddr[ks] + bo);
+            ds_read128<4096>(fa[1][ks], aaddr[ks] + bo);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ds_read128<kHalf>(fb1[ks], baddr[ks] + bo);
+        // {B1h A1h} of k-tile g + 1 -> the other buffer
+        piece(a.W, cy.b0, buf ^ 1, 3, 0); piece(a.W, cy.b1, buf ^ 1, 3, 1);
+        piece(a.A, cy.a0, buf ^ 1, 1, 0); piece(a.A, cy.a1, buf ^ 1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A1h of this k-tile has landed (read next phase)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads retired BEFORE the barrier: their half-tiles are free after it
+        raw_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        P2_SEG(acc[0][0], fb0, acc[0][1], fb1);
+        raw_barrier();
+        advance(cy);
+        // ================= phase B: quadrants (1,1), (1,0)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            ds_read128<kHalf>(fa[0][ks], aaddr[ks] + bo);
+            ds_read128<kHalf + 4096>(fa[1][ks], aaddr[ks] + bo);
+        }
+        // {A0h B0h} of k-tile g + 2 -> this buffer
+        piece(a.A, cx.a0, buf, 0, 0); piece(a.A, cx.a1, buf, 0, 1);
+        piece(a.W, cx.b0, buf, 2, 0); piece(a.W, cx.b1, buf, 2, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // {A0h B0h B1h} of the next k-tile have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        P2_SEG(acc[1][1], fb1, acc[1][0], fb0);
+        raw_barrier();
+        advance(cx);
+        bo ^= (unsigned)kBuf;
+
+        if (++cu_kt == nkt) {
+            unsigned char* scratch = smem + kLds + wave * 4096;
+            if (kOverlapEpi && wr == 0) raw_barrier();
+            const EpiTile<OutT> et = epi_tile<OutT>(a, cu_n0 + wc * 64, lane);
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    store_chunk<OutT, ACT, PLAIN>(a, et, acc[mh][0][rb], acc[mh][1][rb], cu_m0 + mh * 128 + wr * 64 + rb * 32,
+                                                  cu_n0 + wc * 64, scratch, lane);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc[mh][0][rb][r] = 0.f;
+                        acc[mh][1][rb][r] = 0.f;
+                    }
+                }
+            cu_kt = 0;
+            cu_q += nb;
+            int tm, tn;
+            if (tile_of(a, x, cu_q, tm, tn)) {
+                cu_m0 = tm * 256;
+                cu_n0 = tn * 256;
+            }
+            if (kOverlapEpi && wr == 1) raw_barrier();
+        }
+    }
+    if (wr == 0) raw_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef P2_MFMA
+#undef P2_SEG
 }
 
 }  // namespace
@@ -442,7 +848,8 @@ bool gemm256_eligible(const GemmArgs& g) {
     if (g.bias && ((uintptr_t)g.bias % 16)) return false;
     if (g.residual && (g.ldr % 4 || (uintptr_t)g.residual % 16)) return false;
     if (g.rowadd_mode && (g.ld_rowadd % 4 || (uintptr_t)g.rowadd % 16)) return false;
-    if (g.nseg > 1 && g.seg_width % 4) return false;
+    if (g.nseg > 1 && g.seg_width % 64) return false;  // a wave's 64-column chunk lies inside one segment
+    if (g.rowT > 1 && g.rowT < 32) return false;         // the epilogue steps 8 rows at a time with at most one clip wrap
     const int es = g.out_dtype == DIMX_BF16 ? 2 : 4;
     for (int i = 0; i < g.nseg; ++i) {
         const OutSeg& s = g.seg[i];
@@ -495,23 +902,101 @@ static int launch_big(const GemmArgs& g, const OutSeg* segs, int nseg, int seg_w
     }
     const int grid = cus / 8 * 8;
     DIMX_REQUIRE(grid >= 8, DIMX_ERR_ARG, "gemm256: device with %d CUs", cus);
-#define G256(OT, AC)                                                                                              \
-    do {                                                                                                          \
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<OT, AC>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal); \
-        hipLaunchKernelGGL((gemm256_kernel<OT, AC>), dim3(grid), dim3(512), kLdsTotal, s, a);                     \
+    {
+        // start-delay spans (see the kernel): one tile time ~ nkt x 2900 shader cycles (measured: 2.5 us per k-tile at
+        // ~1.8 GHz with the epilogue bursts, ~1.6 us without).  Blocks with a spare slot: a full tile time.  When every
+        // block has the same number of tiles nobody has slack: a quarter tile over all blocks still pays from ~8 tiles up.
+        const int tt = a.tiles_m * a.tiles_n, nbx = grid / 8;
+        int nt_max = 0, nt_min = 1 << 30;
+        for (int x8 = 0; x8 < 8; ++x8) {
+            const int cnt = (int)((long)tt * (x8 + 1) / 8) - (int)((long)tt * x8 / 8);
+            const int hi = ceil_div(cnt, nbx), lo = cnt / nbx;
+            nt_max = hi > nt_max ? hi : nt_max;
+            nt_min = lo < nt_min ? lo : nt_min;
+        }
+        a.nt_max = nt_max;
+        static const char* de = getenv("DIMX_G256_DESYNC");  // "slack_permille,full_permille"
+        int ps = 0, pf = 0;  // measured (round 3): any start delay costs more than it returns -- the epilogue is bound by the CU's own store path, not by a chip-wide write burst
+        if (de) {
+            ps = atoi(de);
+            const char* c = strchr(de, ',');
+            pf = c ? atoi(c + 1) : 0;
+        }
+        const double tile_cycles = (double)a.nkt * 2900.0;
+        a.desync_slack = (unsigned)(tile_cycles * ps / 1000.0);
+        a.desync_full = (unsigned)(tile_cycles * pf / 1000.0);
+        static const int abl_env = getenv("DIMX_G256_ABL") ? atoi(getenv("DIMX_G256_ABL")) : 0;
+        a.abl = abl_env;
+    }
+    // tuning (tools/g256_var.py): DMA placement variant and the in-kernel interval profile, bf16 / no-activation instantiation only
+    static const int var_env = getenv("DIMX_G256_VAR") ? atoi(getenv("DIMX_G256_VAR")) : kDefaultVar;
+    static const bool prof_env = getenv("DIMX_G256_PROF") != nullptr;
+    static unsigned long long* prof_buf = nullptr;
+    const bool plain = !g.bias && !g.residual && !g.rowadd_mode;  // epilogue without bias / positional rows / residual
+    const bool tunable = g.out_dtype == DIMX_BF16 && g.act == ACT_NONE && plain;
+    const int var = tunable ? var_env : kDefaultVar;
+    const bool prof = tunable && prof_env;
+    if (prof && !prof_buf) DIMX_HIP(hipMalloc((void**)&prof_buf, 64 * sizeof(unsigned long long)));
+    a.prof = prof ? prof_buf : nullptr;
+#define G256_(OT, AC, PL, VR, PF)                                                                                           \
+    do {                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<OT, AC, PL, VR, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal); \
+        hipLaunchKernelGGL((gemm256_kernel<OT, AC, PL, VR, PF>), dim3(grid), dim3(512), kLdsTotal, s, a);                   \
     } while (0)
-#define G256_ACT(OT)                                                 \
-    do {                                                             \
-        switch (g.act) {                                             \
-            case ACT_LEAKY: G256(OT, ACT_LEAKY); break;              \
-            case ACT_GELU_TANH: G256(OT, ACT_GELU_TANH); break;      \
-            case ACT_GELU_ERF: G256(OT, ACT_GELU_ERF); break;        \
-            default: G256(OT, ACT_NONE); break;                      \
-        }                                                            \
+#define G256(OT, AC, VR, PF)                                                   \
+    do {                                                                       \
+        if (plain) G256_(OT, AC, true, VR, PF); else G256_(OT, AC, false, VR, PF); \
     } while (0)
-    if (g.out_dtype == DIMX_BF16) G256_ACT(bf16); else G256_ACT(float);
+#define G256_ACT(OT)                                                                  \
+    do {                                                                              \
+        switch (g.act) {                                                              \
+            case ACT_LEAKY: G256(OT, ACT_LEAKY, kDefaultVar, false); break;           \
+            case ACT_GELU_TANH: G256(OT, ACT_GELU_TANH, kDefaultVar, false); break;   \
+            case ACT_GELU_ERF: G256(OT, ACT_GELU_ERF, kDefaultVar, false); break;     \
+            default: G256(OT, ACT_NONE, kDefaultVar, false); break;                   \
+        }                                                                             \
+    } while (0)
+#define G256P2_(OT, AC, PL)                                                                                             \
+    do {                                                                                                                \
+        (void)hipFuncSetAttribute((const void*)gemm256p2_kernel<OT, AC, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal); \
+        hipLaunchKernelGGL((gemm256p2_kernel<OT, AC, PL>), dim3(grid), dim3(512), kLdsTotal, s, a);                     \
+    } while (0)
+    if (tunable && var == 5 && !prof) {
+        G256P2_(bf16, ACT_NONE, true);
+    } else if (tunable && (var != kDefaultVar || prof)) {
+        switch (var * 2 + (prof ? 1 : 0)) {
+            case 0: G256_(bf16, ACT_NONE, true, 0, false); break;
+            case 1: G256_(bf16, ACT_NONE, true, 0, true); break;
+            case 2: G256_(bf16, ACT_NONE, true, 1, false); break;
+            case 3: G256_(bf16, ACT_NONE, true, 1, true); break;
+            case 4: G256_(bf16, ACT_NONE, true, 2, false); break;
+            case 5: G256_(bf16, ACT_NONE, true, 2, true); break;
+            case 6: G256_(bf16, ACT_NONE, true, 3, false); break;
+            case 7: G256_(bf16, ACT_NONE, true, 3, true); break;
+            default: DIMX_REQUIRE(false, DIMX_ERR_ARG, "gemm256: DIMX_G256_VAR=%d", var);
+        }
+    } else if (g.out_dtype == DIMX_BF16) {
+        G256_ACT(bf16);
+    } else {
+        G256_ACT(float);
+    }
 #undef G256_ACT
 #undef G256
+#undef G256_
+#undef G256P2_
+    if (prof) {  // tuning only: synchronous read-back of block 0's interval sums (waves 0 and 4)
+        unsigned long long hst[64];
+        DIMX_HIP(hipStreamSynchronize(s));
+        DIMX_HIP(hipMemcpy(hst, prof_buf, sizeof(hst), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 2; ++w) {
+            const double n = (double)hst[w * 32 + 17];
+            fprintf(stderr, "g256prof var %d wave %d ktiles %.0f :", var, w * 4, n);
+            for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", (double)hst[w * 32 + i] / (n > 0 ? n : 1));
+            fprintf(stderr, " | reads done");
+            for (int i = 13; i < 17; ++i) fprintf(stderr, " %.0f", (double)hst[w * 32 + i] / (n > 0 ? n : 1));
+            fprintf(stderr, " | epilogue per tile %.0f\n", (double)hst[w * 32 + 12] / (n > 0 ? n / a.nkt : 1));
+        }
+    }
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -1057,17 +1057,6 @@ static int check_common(dimx_handle h, int B, int T, void* ws, size_t ws_bytes, 
     const size_t need_bytes = workspace_bytes(h, B, T, S);
     DIMX_REQUIRE(ws_bytes >= need_bytes, DIMX_ERR_WORKSPACE, "workspace %zu < required %zu", ws_bytes, need_bytes);
     DIMX_HIP(hipSetDevice(h->device));
-    if (h->chain_err_host && h->chain_err_ev && hipEventQuery(h->chain_err_ev) == hipSuccess && *h->chain_err_host) {
-        const unsigned e = *h->chain_err_host;
-        *h->chain_err_host = 0;
-        (void)hipMemset(h->chain_err_dev, 0, 64);
-        h->use_chain = 0;  // fall back to the one-kernel-per-op step from now on
-        DIMX_REQUIRE(false, DIMX_ERR_STATE,
-                     "the previous generate call's XCD-local chain kernels reported %s%s: its tokens are not trustworthy "
-                     "(chain path disabled for this handle; set DIMX_NO_CHAIN=1 to avoid it from the start)"
-                     ,
-                     (e & 1) ? "two blocks on one (XCD, CU slot) " : "", (e & 2) ? "a group-barrier timeout" : "");
-    }
     DIMX_TRY(ensure_packed(h, need));
     return DIMX_OK;
 }
@@ -1619,6 +1608,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         c.seen = c.counters + 8 * 16;
         c.step = s.step;
         c.err = h->chain_err_dev;
+        c.fault = h->chain_fault_inject > 0 ? 1 : 0;
         return launch_chain(c, st);
     };
     int pending = 0;  // slabs of the previous residual projection not yet folded into x
@@ -1717,9 +1707,9 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
 
 extern "C" {
 
-int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T, int n_samples,
-                  float temperature, int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens, float* logits_out,
-                  void* ws, size_t ws_bytes, void* stream) {
+static int generate_impl(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T, int n_samples,
+                         float temperature, int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens,
+                         float* logits_out, void* ws, size_t ws_bytes, void* stream, bool* chain_used) {
     const int S = n_samples < 1 ? 1 : n_samples;
     DIMX_REQUIRE(S == 1 || S == 2 || S == 4 || S == 5 || S == 8 || S == 10, DIMX_ERR_ARG,
                  "generate: n_samples %d not in {1,2,4,5,8,10}", n_samples);
@@ -1794,7 +1784,7 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
                                   exp_noise, seed, tokens, logits_out, gs[g], false, S));
     } else {
         // greedy vs sampling is decided from the device-side parameters; only shapes and pointers key the graph
-        GraphKey key{ws, B, T, top_k, 0.f, exp_noise, 0, start, ctx_mask, tokens, logits_out, G * 100 + S + (h->use_chain ? 1000 : 0)};
+        GraphKey key{ws, B, T, top_k, 0.f, exp_noise, 0, start, ctx_mask, tokens, logits_out, G * 100 + S + (h->use_chain ? 1000 : 0) + (h->chain_fault_inject > 0 ? 2000 : 0)};
         if (!(h->graph_valid && h->graph_key == key)) {
             h->graph_valid = false;
             if (!h->cap_stream) DIMX_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -1853,10 +1843,48 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
             DIMX_HIP(hipStreamWaitEvent(st, h->ev_join[g], 0));
         }
     }
-    if (h->chain_err_dev) {  // looked at by the next call on this handle (check_common), never waited for here
+    *chain_used = G == 1 && gen_use_chain(h, lo[1] - lo[0], S, 0);
+    if (*chain_used) {
         DIMX_HIP(hipMemcpyAsync(h->chain_err_host, h->chain_err_dev, 4, hipMemcpyDeviceToHost, st));
         DIMX_HIP(hipEventRecord(h->chain_err_ev, st));
     }
+    return DIMX_OK;
+}
+
+// The XCD-local chain kernels need their 256 blocks co-resident, one per CU, on the XCD whose rows they own; another
+// process, handle or stream on the same GPU can break that.  They detect it (claim stamps, bounded barriers) but cannot
+// repair it, so the call that used them checks their flags before it returns: it waits for its own generation (the caller
+// is about to read the tokens anyway) and, on a fault, regenerates the same batch on the one-kernel-per-op step and keeps
+// the chain path off for this handle.  Round 2 reported the fault one call late.
+int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, int B, int T, int n_samples,
+                  float temperature, int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens, float* logits_out,
+                  void* ws, size_t ws_bytes, void* stream) {
+    bool chain_used = false;
+    DIMX_TRY(generate_impl(h, start, ctx_mask, B, T, n_samples, temperature, top_k, exp_noise, seed, tokens, logits_out, ws,
+                           ws_bytes, stream, &chain_used));
+    if (h->chain_fault_inject > 0) --h->chain_fault_inject;
+    if (!chain_used) return DIMX_OK;
+    DIMX_HIP(hipEventSynchronize(h->chain_err_ev));
+    const unsigned e = *h->chain_err_host;
+    if (!e) return DIMX_OK;
+    *h->chain_err_host = 0;
+    DIMX_HIP(hipMemsetAsync(h->chain_err_dev, 0, 64, (hipStream_t)stream));
+    h->use_chain = 0;
+    h->graph_valid = false;
+    ++h->chain_faults;
+    fprintf(stderr, "dimx: the XCD-local chain kernels reported %s%s; this batch is regenerated on the one-kernel-per-op "
+                    "step and the chain path stays off for this handle (DIMX_NO_CHAIN=1 avoids it from the start)\n",
+            (e & 1) ? "two blocks on one (XCD, CU slot) " : "", (e & 2) ? "a group-barrier timeout" : "");
+    return generate_impl(h, start, ctx_mask, B, T, n_samples, temperature, top_k, exp_noise, seed, tokens, logits_out, ws,
+                         ws_bytes, stream, &chain_used);
+}
+
+int dimx_chain_faults(dimx_handle h) { return h ? h->chain_faults : 0; }
+
+int dimx_debug_chain_fault(dimx_handle h, int n_calls) {
+    DIMX_REQUIRE(h && n_calls >= 0, DIMX_ERR_ARG, "debug_chain_fault: bad argument");
+    h->chain_fault_inject = n_calls;
+    h->graph_valid = false;
     return DIMX_OK;
 }
 

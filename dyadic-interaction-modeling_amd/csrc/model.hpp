@@ -159,6 +159,8 @@ struct dimx_ctx {
     unsigned* chain_err_dev = nullptr;  // bit 0: two blocks claimed one (XCD, CU slot), bit 1: a group barrier timed out
     unsigned* chain_err_host = nullptr; // pinned copy, refreshed at the end of every generate call
     hipEvent_t chain_err_ev = nullptr;
+    int chain_faults = 0;               // generate calls whose chain kernels reported a fault and that were re-run without them
+    int chain_fault_inject = 0;         // test hook: that many of the next generate calls launch the chain kernels with fault = 1
     // sampler generator window of a sharded batch (dimx_set_shard): this handle generates clips
     // [shard_row_off, shard_row_off + B) of shard_rows_total (0 = the call's own B)
     int shard_row_off = 0, shard_rows_total = 0;

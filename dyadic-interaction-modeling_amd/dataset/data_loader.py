@@ -95,16 +95,29 @@ def pad_collate(batch):
     return xx_pad, yy_pad, x_lens, (torch.LongTensor(speaker_ids), torch.LongTensor(listener_ids)), list(zz)
 
 
-def _loader(ds, batch_size, shuffle):
-    return data.DataLoader(dataset=ds, batch_size=batch_size, shuffle=shuffle, num_workers=0, collate_fn=pad_collate,
-                           pin_memory=torch.cuda.is_available())
+def _loader(ds, batch_size, shuffle, rank=0, world=1, seed=0):
+    """world > 1: every rank iterates its own 1/world of the (shuffled) set through a DistributedSampler -- same number
+    of batches on every rank (the sampler pads by wrapping around), so a collective per batch never waits for a rank that
+    has run out (without it every rank read the whole set and the effective batch was world x too large)."""
+    sampler = None
+    if world > 1:
+        sampler = data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed,
+                                                      drop_last=False)
+        shuffle = False
+    return data.DataLoader(dataset=ds, batch_size=batch_size, shuffle=shuffle, sampler=sampler, num_workers=0,
+                           collate_fn=pad_collate, pin_memory=torch.cuda.is_available())
 
 
 def get_vico_dataloaders(batch_size, data_path="../data/vico_processed_30fps", meta_data_path="../data/RLD_data.csv",
-                         synthetic=None):
+                         synthetic=None, rank=None, world=None, seed=0):
     """reference :461-478 -> {'train', 'valid', 'all'} loaders.  ``synthetic`` (a dict of SyntheticDyadDataset
     kwargs) asks for synthetic clips of the same format; without it the ViCo files must exist -- like the reference,
-    which fails on a missing data directory -- so metrics on random clips can never pass for ViCo results."""
+    which fails on a missing data directory -- so metrics on random clips can never pass for ViCo results.
+    ``rank`` / ``world`` (default: the initialised process group) shard every loader across the ranks of a multi-GPU job;
+    call ``loader.sampler.set_epoch(e)`` per epoch for a fresh shuffle."""
+    if world is None:
+        from .. import dist as ddist
+        rank, world = ddist.rank(), ddist.world_size()
     if synthetic is None:
         if not (os.path.isdir(data_path) and os.path.isfile(meta_data_path)):
             raise FileNotFoundError("ViCo data not found (%s, %s); pass synthetic={...} to get synthetic clips"
@@ -114,5 +127,5 @@ def get_vico_dataloaders(batch_size, data_path="../data/vico_processed_30fps", m
         kw = dict(synthetic or {})
         train = SyntheticDyadDataset(**kw)
         val = SyntheticDyadDataset(**{**kw, "seed": kw.get("seed", 20260928) + 1})
-    return {"train": _loader(train, batch_size, True), "valid": _loader(val, batch_size, False),
-            "all": _loader(data.ConcatDataset([train, val]), batch_size, True)}
+    return {"train": _loader(train, batch_size, True, rank, world, seed), "valid": _loader(val, batch_size, False, rank, world, seed),
+            "all": _loader(data.ConcatDataset([train, val]), batch_size, True, rank, world, seed)}

@@ -242,6 +242,15 @@ class Engine:
                                        wsb, self._s()), "dimx_generate")
         return (tokens, lg) if return_logits else tokens
 
+    def chain_faults(self):
+        """generate() calls of this handle whose XCD-local chain kernels reported a placement / barrier fault; each was
+        regenerated on the one-kernel-per-op step before generate() returned (0 = never happened)."""
+        return int(self.lib.dimx_chain_faults(self.h))
+
+    def debug_chain_fault(self, n_calls=1):
+        """test hook: the next n_calls generate() calls run their chain kernels on a non-bijective placement."""
+        L.check(self.lib.dimx_debug_chain_fault(self.h, int(n_calls)), "dimx_debug_chain_fault")
+
 
 # ---------------------------------------------------------------------- kernel-level wrappers (tests)
 def _pad_k(w, mult):

@@ -71,6 +71,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_uint64,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dimx_chain_faults": (c_int, [c_void_p]),
+    "dimx_debug_chain_fault": (c_int, [c_void_p, c_int]),
     "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "dimx_op_gemm_headmajor": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -110,12 +112,19 @@ def load(build_if_missing=True):
             raise DimxError("libdimx_hip.so not found at %s (run python __graft_entry__.py build)" % LIB_PATH)
         from . import build as _build
         _build.build()
-    elif in_tree and build_if_missing:
-        # the in-tree library is rebuilt when a source or header is newer than it (mtime check, no-op otherwise), so
-        # the ctypes signatures below can never describe a stale binary; a box without hipcc keeps the shipped .so
+    elif in_tree:
+        # The in-tree library must have been built from the sources next to it (content hash, build.stale()): the ctypes
+        # signatures below describe THESE sources.  Stale + hipcc present -> rebuild (one process at a time, build.py
+        # takes a file lock); stale without a compiler -> refuse: calling changed entry points through old signatures
+        # corrupts arguments silently.  DIMX_ALLOW_STALE_LIB=1 overrides (A/B runs against a saved build use DIMX_LIB).
         from . import build as _build
-        if _build.stale() and _build.have_hipcc():
-            _build.build()
+        if _build.stale():
+            if build_if_missing and _build.have_hipcc():
+                _build.build()
+            elif not os.environ.get("DIMX_ALLOW_STALE_LIB"):
+                raise DimxError("libdimx_hip.so at %s was not built from the sources next to it and %s; run "
+                                "python __graft_entry__.py build where hipcc exists"
+                                % (LIB_PATH, "hipcc is not available" if build_if_missing else "rebuilding was not requested"))
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         if not in_tree and not hasattr(lib, name):

@@ -33,11 +33,22 @@ def _masked_pairwise_loss(pred, target, m):
     return torch.where(m, d, zero).sum() / m.sum()
 
 
+def mark_prefix(mask):
+    """Declare that every row of ``mask`` is True on a prefix [0, len) and False after it (what the engine protocol builds
+    from ``src_len``, reference code/x_engine_pt.py:203-206).  compact_by_mask then has nothing to move and skips its
+    stable argsort + gather over [B,T,56]; the claim is the caller's (a Python attribute on the tensor, lost by any op
+    that creates a new tensor -- the safe direction)."""
+    mask.dimx_prefix = True
+    return mask
+
+
 def compact_by_mask(x, mask):
     """Left-align the valid frames of every clip (``v[i][mask[i]]`` of the reference, batched).
-    Returns (x_compact, lens int32); frames past a clip's length are zero.  A prefix mask (the engine protocol) keeps its
-    valid frames where they are."""
+    Returns (x_compact, lens int32).  A prefix mask (the engine protocol) keeps its valid frames where they are; frames past
+    a clip's length are zero unless the mask was declared a prefix mask (mark_prefix) -- the engine never reads them."""
     lens = mask.sum(1).to(torch.int32)
+    if getattr(mask, "dimx_prefix", False):
+        return x, lens
     T = mask.shape[1]
     prefix = torch.arange(T, device=mask.device)[None, :] < lens[:, None]
     if not x.is_cuda and torch.equal(prefix, mask):

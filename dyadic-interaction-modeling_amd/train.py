@@ -121,7 +121,12 @@ def all_reduce_grads(params, bucket_bytes=64 << 20):
     if world == 1:
         return 0
     import torch.distributed as dist
-    grads = [p.grad for p in params if p.grad is not None]
+    # every trainable parameter takes part on every rank, in the same order: a parameter without a gradient on this rank
+    # (unused in this batch) contributes zeros -- buckets built from "has a grad" could differ between ranks and hang
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
     n_coll, i = 0, 0
     while i < len(grads):
         j, size = i, 0
@@ -138,6 +143,43 @@ def all_reduce_grads(params, bucket_bytes=64 << 20):
         n_coll += 1
         i = j
     return n_coll
+
+
+def broadcast_parameters(params, src=0):
+    """Make every rank start from rank `src`'s parameters (flat buckets, like the gradients); without it the job relies on
+    bit-identical construction on every rank."""
+    if ddist.world_size() == 1:
+        return 0
+    import torch.distributed as dist
+    n = 0
+    with torch.no_grad():
+        i = 0
+        while i < len(params):
+            j, size = i, 0
+            while j < len(params) and (size == 0 or size + params[j].numel() * params[j].element_size() <= (64 << 20)):
+                size += params[j].numel() * params[j].element_size()
+                j += 1
+            flat = torch.cat([p.detach().reshape(-1) for p in params[i:j]])
+            dist.broadcast(flat, src)
+            o = 0
+            for p in params[i:j]:
+                p.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            n += 1
+            i = j
+    return n
+
+
+def assert_same_batch_count(n_batches, device=None):
+    """A collective per batch needs the same number of batches on every rank."""
+    if ddist.world_size() == 1:
+        return
+    import torch.distributed as dist
+    t = torch.tensor([n_batches, -n_batches], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[0]) != -int(t[1]):
+        raise RuntimeError("ranks see different batch counts (%d .. %d): shard the loader with a DistributedSampler "
+                           "(dimx.dataset.data_loader.get_vico_dataloaders does)" % (-int(t[1]), int(t[0])))
 
 
 def train_step(model, optimizer, v_speaker, v_listener, v_audio, mask, clip=1.0, kv_mask=None, scheduler=None):

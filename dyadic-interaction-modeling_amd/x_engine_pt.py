@@ -21,7 +21,8 @@ def _mask_from_lens(src, src_len, device):
     mask = torch.zeros((src.shape[0], src.shape[1]), dtype=torch.bool)
     for j in range(src.shape[0]):
         mask[j, :src_len[j]] = True
-    return mask.to(device)
+    from .seq2seq_pretrain import mark_prefix
+    return mark_prefix(mask.to(device))     # built as a prefix mask: SLMFT.forward_vq has nothing to compact
 
 
 def _prepare(batch, device):
@@ -171,11 +172,18 @@ def generate_sharded(model, v_speaker, v_listener, v_audio, mask, **forward_kw):
 def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, print_freq=2000, epoch=0, log=print):
     """reference code/x_engine_pt.py:9-60: one pass over the loader with zero_grad / forward(mode='train') / backward /
     clip / step.  For N > 1 processes the gradients are averaged over RCCL before clipping (dimx.train.all_reduce_grads);
-    every rank feeds its own loader shard.  Returns the mean loss of the epoch."""
+    every rank feeds its own loader shard (get_vico_dataloaders shards by rank through a DistributedSampler); the ranks must
+    see the same number of batches (checked) and start from rank 0's parameters (broadcast once).  Returns the mean loss."""
     from . import train as T
     model.train()
     T.set_trainable(model, True)
     params = [p for _, p in T.trainable_parameters(model)]
+    if ddist.world_size() > 1:
+        if hasattr(loader, "__len__"):
+            T.assert_same_batch_count(len(loader), device if torch.device(device).type == "cuda" else None)
+        if not getattr(model, "_dimx_params_broadcast", False):     # once per model: every rank starts from rank 0's weights
+            T.broadcast_parameters(params)
+            model._dimx_params_broadcast = True
     d = {k: 0.0 for k in ("l_ce_s", "l_ce_l", "l_cont_s", "l_cont_l", "nce", "c_acc")}
     losses, all_losses = [], []
     for i, batch in enumerate(loader):

@@ -195,6 +195,16 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
                   float temperature, int top_k, const float* exp_noise, uint64_t seed, int32_t* tokens,
                   float* logits_out, void* ws, size_t ws_bytes, void* stream);
 
+/* In the bf16 mode dimx_generate runs part of the decode step as XCD-local chain kernels (B <= 256, one sample per clip,
+ * 256-CU device) that rely on their 256 blocks being co-resident, one per CU.  They verify that and dimx_generate checks
+ * their flags BEFORE it returns: with the chain path active the call therefore waits for its own generation to finish
+ * (everything else stays asynchronous); on a fault it regenerates the same batch on the one-kernel-per-op step, keeps the
+ * chain path off for this handle and counts the event here (0 = never happened). */
+int dimx_chain_faults(dimx_handle h);
+/* Test hook: the next n_calls dimx_generate calls launch their chain kernels with a deliberately non-bijective
+ * (XCD, CU slot) placement (the blocks of every odd XCD claim the slots of its even neighbour). */
+int dimx_debug_chain_fault(dimx_handle h, int n_calls);
+
 /* ---- kernel-level entry points (unit parity tests) -------------------------------------- */
 
 /* C = epilogue(A[M,K] . W[N,K]^T).  A/W element type `in_dtype`, C element type `out_dtype`.

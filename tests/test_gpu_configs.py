@@ -53,7 +53,15 @@ def test_c2_forward_train_b1_t300_matches_oracle(model_f32, full_sd):
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3
     assert safe.float().mean() > 0.95
     assert torch.equal(tok.cpu()[safe], aux["logits"].argmax(-1)[safe])
-    if torch.equal(tok.cpu(), aux["logits"].argmax(-1)):        # same code sequence -> the decoded motion must agree
+    # decoded motion, unconditionally: the VQ decoder mixes all frames, so ONE flipped rounding-tie token would change
+    # every frame of `pred`; the comparison therefore decodes the ORACLE's code sequence on the GPU and holds that against
+    # the oracle's own decode (1e-4, the north-star tolerance) -- and the end-to-end `pred` too whenever no tie flipped
+    otok = aux["logits"].argmax(-1).to(torch.int32).to(v_s.device)
+    dec = model_f32.engine(v_s.device).vq_decode(1, otok, 0, 1)
+    err = (dec.cpu() - rpred).abs().max().item()
+    print("C2 decoded-motion max |gpu - oracle| = %.2e" % err)
+    assert err < 1e-4
+    if torch.equal(tok.cpu(), aux["logits"].argmax(-1)):
         assert (pred.cpu() - rpred).abs().max() < 1e-4
     assert abs(float(d["l_ce_l"]) - float(rd["l_ce_l"])) < 1e-3 * max(1.0, abs(float(rd["l_ce_l"])))
     assert abs(float(tot) - float(rt)) < 2e-3 * max(1.0, abs(float(rt)))
