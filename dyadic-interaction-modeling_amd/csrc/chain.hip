@@ -157,7 +157,11 @@ __device__ __forceinline__ void reduce_store_defer(const f32x16_t (&acc)[NCB], f
             red[((wave * NCB + j) * 32 + m) * 32 + l31] = acc[j][r];
         }
     __syncthreads();
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    // Partial statistics of the slice, in a form that survives |mean| >> std (sum x^2 - (sum x)^2 / n in f32
+    // cancels catastrophically there): {sum x, M2 = sum (x - mean_slice)^2}, two passes over the values the thread holds; the
+    // consumer combines the 32 slices with the parallel-variance formula, again in two passes.
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, xv[2 * NCB];
+    bool ok[2 * NCB];
 #pragma unroll
     for (int i = 0; i < 2 * NCB; ++i) {
         const int e = threadIdx.x + i * kThreads;
@@ -166,20 +170,31 @@ __device__ __forceinline__ void reduce_store_defer(const f32x16_t (&acc)[NCB], f
 #pragma unroll
         for (int w = 1; w < kWaves; ++w) v += red[((w * NCB + j) * 32 + m) * 32 + n];
         const int col = j * 32 + n;
-        if (col < ncols && m < nrows) {
+        ok[i] = col < ncols && m < nrows;
+        xv[i] = 0.f;
+        if (ok[i]) {
             const float xp = xs[i] + v;
             const size_t o = (size_t)(row0 + m) * C + n0 + col;
             x[o] = xp;
             y[o].x = f32_to_bf16(xp);
+            xv[i] = xp;
             s1[i & 1] += xp;
-            s2[i & 1] += xp * xp;
         }
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {  // the 32 lanes of a row: four in-row steps on DPP (== xor 1, 2, 4, 8), one lane swap
         s1[k] = row16_sum(s1[k]);
-        s2[k] = row16_sum(s2[k]);
         s1[k] += xor_lane_f32<16>(s1[k]);
+    }
+    const float inv_n = 1.0f / (float)ncols;
+#pragma unroll
+    for (int i = 0; i < 2 * NCB; ++i) {
+        const float d = xv[i] - s1[i & 1] * inv_n;
+        if (ok[i]) s2[i & 1] += d * d;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        s2[k] = row16_sum(s2[k]);
         s2[k] += xor_lane_f32<16>(s2[k]);
     }
     if (l31 == 0) {
@@ -371,15 +386,20 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
         {
             const int m = tid >> 4, part = tid & 15;
             const float* sp = a.stats + ((size_t)(g * kGroupCUs + 2 * part) * kGroupRows + m) * 2;
-            float t1 = ld_sc1_f32(sp) + ld_sc1_f32(sp + 2 * kGroupRows);
-            float t2 = ld_sc1_f32(sp + 1) + ld_sc1_f32(sp + 2 * kGroupRows + 1);
-            t1 = row16_sum(t1);  // == the xor 1, 2, 4, 8 butterfly over the row's 16 parts
-            t2 = row16_sum(t2);
+            const float a1 = ld_sc1_f32(sp), b1 = ld_sc1_f32(sp + 2 * kGroupRows);          // slice sums of two CUs
+            const float a2 = ld_sc1_f32(sp + 1), b2 = ld_sc1_f32(sp + 2 * kGroupRows + 1);  // their centred squares
+            const float t1 = row16_sum(a1 + b1);  // == the xor 1, 2, 4, 8 butterfly over the row's 16 parts
+            const float mean = t1 * (1.0f / C);
+            const float ncs = (float)a.g1.cols, inv_n = 1.0f / ncs;
+            const float da = a1 * inv_n - mean, db = b1 * inv_n - mean;
+            const float t2 = row16_sum(a2 + b2 + ncs * (da * da + db * db));
             if (part == 0) {
-                const float mean = t1 * (1.0f / C);
-                const float var = fmaxf(t2 * (1.0f / C) - mean * mean, 0.f);
+                const float var = t2 * (1.0f / C);
                 sm_mr[2 * m] = mean;
                 sm_mr[2 * m + 1] = rsqrtf(var + 1e-5f);
+                // the operand of the next projection is bf16(x), NOT bf16(x - mean): with |mean| > 8 std its rounding noise
+                // is no longer small against the row's spread -- flag it, the host repeats the batch with the row-phase form
+                if (m < nrows && mean * mean > 64.0f * var) atomicOr(a.err, 4u);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -257,10 +257,11 @@ struct GemmArgs {
     unsigned long long* prof;  // tuning only (tools/gemm_phases.py): per-block wall-clock stamps, ABL = 3 instantiation
     // deferred LayerNorm of the A operand (gemm_ws_kernel only; see ChainArgs.defer): A holds bf16(x) un-normalised, W the
     // gamma-scaled weights; acc <- rstd[m] * (acc - mean[m] * ln_colsum[n]) before bias / activation.  ln_stats =
-    // [M / 32][32][32][2] partial {sum x, sum x^2} over ln_C columns.
+    // [M / 32][32][32][2] per-slice {sum x, sum (x - slice mean)^2}, 32 equal column slices of ln_C columns.
     const float* ln_stats;
     const float* ln_colsum;
     int ln_C;
+    unsigned* ln_err;  // optional: bit 2 is set when a row's |mean| exceeds 8 standard deviations (deferred form too coarse)
     int w_tiled;       // W is stored as [N/8][ldw/BK] blocks of 8 rows x 128 B (1 KiB, contiguous): an LDS-DMA piece then reads one
                        // contiguous KiB instead of 8 row segments (tools/ubench/cu_load_rate.hip: 122-143 vs 70-78 GB/s per CU).
                        // gemm_ws_kernel only.  Measured: -0.2 us per decode GEMM, nothing end to end (1467 vs 1467 clips/s) -- the

@@ -990,19 +990,28 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
             __builtin_amdgcn_s_barrier();
             if (ABLW != 2 && it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
             if (a.ln_stats && it == nk - 2) {  // vmcnt is 0 here (the wait of this iteration), nothing left to issue
-                float s1 = 0.f, s2 = 0.f;
+                // {sum x, M2} of 32 column slices -> mean and variance by the parallel-variance formula, two passes (no
+                // sum x^2 - mean^2 cancellation)
+                float s1 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    s1 += lp[i].x;
-                    s2 += lp[i].y;
-                }
+                for (int i = 0; i < 8; ++i) s1 += lp[i].x;
                 s1 += xor_lane_f32<16>(s1);
-                s2 += xor_lane_f32<16>(s2);
                 s1 += xor_lane_f32<32>(s1);
-                s2 += xor_lane_f32<32>(s2);
                 const float inv_c = 1.0f / (float)a.ln_C;
                 const float mean = s1 * inv_c;
-                const float rstd = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + 1e-5f);
+                const float ncs = (float)a.ln_C * (1.0f / 32.0f), inv_n = 32.0f * inv_c;
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = lp[i].x * inv_n - mean;
+                    s2 += lp[i].y + ncs * d * d;
+                }
+                s2 += xor_lane_f32<16>(s2);
+                s2 += xor_lane_f32<32>(s2);
+                const float var = s2 * inv_c;
+                const float rstd = rsqrtf(var + 1e-5f);
+                if (a.ln_err && lane < 16 && m0 + lw * 16 + lane < a.M && mean * mean > 64.0f * var)
+                    atomicOr(a.ln_err, 4u);  // bf16(x) un-normalised is too coarse for this row (see chain.hip)
                 if (lane < 16) {
                     ln_sm[lw * 16 + lane] = mean;
                     ln_sm[64 + lw * 16 + lane] = rstd;

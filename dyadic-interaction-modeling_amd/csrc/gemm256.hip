@@ -34,7 +34,7 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kHalf = 16384;        // one half-tile: 128 rows x 128 B
 constexpr int kBuf = 4 * kHalf;     // one k-tile: A0h A1h B0h B1h
-constexpr int kDefaultVar = 3;  // DMA placement of the main loop (see gemm256_kernel)
+constexpr int kDefaultVar = 4;  // 4 = the two-phase loop (gemm256p2_kernel); 0..3 = the four-phase loop's DMA placements (tuning)
 constexpr bool kOverlapEpi = true;
 constexpr bool kPrio = true;  // s_setprio(1) around the MFMA segments: +7 % (without it 35.8 -> 33.3 % on the fused K/V projection)
 constexpr int kLds = 2 * kBuf;
@@ -629,21 +629,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Two phases per k-tile (round 3).  The four-phase loop above pays two barrier rendezvous per 8 MFMAs of a wave, and an
-// LDS-DMA issue inside an MFMA segment blocks that wave for ~60 cycles (8 pieces per wave and k-tile = +47 % on its 1024
-// matrix cycles), while a load segment as short as a 256-cycle MFMA segment has no room for them either (four waves'
-// pieces queue in the texture addresser at ~25 cycles each).  Here a phase is HALF a k-tile -- both column halves of one
-// row half, 16 MFMAs = 512 cycles per wave -- and the load segment next to it has the room:
-//   phase A: read W(col half 0), W(col half 1), A(row half 0)  [16 ds_read_b128], issue 4 pieces;  quadrants (0,0), (0,1)
-//   phase B: read A(row half 1)                                 [ 8 ds_read_b128], issue 4 pieces;  quadrants (1,1), (1,0)
-// Staging: phase A's load segment re-stages B1h and A1h of k-tile g + 1 into the other buffer (B1h first:
-// it is needed one phase earlier), phase B's re-stages A0h and B0h of k-tile g + 2 into this buffer -- each half-tile one
-// interval after its last reader retired (every load segment ends with lgkmcnt(0) BEFORE its barrier, so a half-tile read
-// in one interval may be overwritten from the next), each issued >= 2 intervals before the counted vmcnt that retires it
-// and read one phase after that wait: vmcnt(8) in phase A (A1h of this k-tile landed), vmcnt(6) in phase B ({A0h B0h B1h}
-// of the next k-tile landed).  (With the pieces inside the MFMA segments instead -- 6 in phase B, 2 in phase A -- this loop
-// measured 40.4 % of the bf16 peak on the K/V projection against 39.2 % for the four-phase loop on the same box.)  Waves 4-7
-// still run half a phase behind waves 0-3; epilogue and tile walk as above.
+// Two phases per k-tile (round 3; the default).  The four-phase loop above pays two barrier rendezvous per 8 MFMAs of a wave.
+// Here a phase is HALF a k-tile -- both column halves of one row half, 16 MFMAs per wave -- so the same rendezvous cost is
+// paid half as often:
+//   phase A: read W(col half 0), W(col half 1), A(row half 0)  [16 ds_read_b128];  quadrants (0,0) and (0,1)
+//   phase B: read A(row half 1)                                 [ 8 ds_read_b128];  quadrants (1,1) and (1,0)
+// Staging: the three half-tiles phase A reads are free after it and are re-staged (k-tile g + 2) inside phase B's MFMA
+// segment (6 LDS-DMA pieces per wave, one after every second MFMA); A(row half 1) is read in phase B and re-staged inside
+// the next phase A (2 pieces).  Every half-tile is issued >= 3 phases before its first read and retired by a counted
+// vmcnt one phase before it (vmcnt(6) in phase A's load segment leaves phase B's six pieces in flight, vmcnt(2) in phase
+// B's leaves phase A's two).  Waves 4-7 still run half a phase behind waves 0-3; the epilogue and the tile walk are
+// the four-phase kernel's.
+// Measured on the K/V projection (M 76800, N 6144, K 1152; tools/g256_var.py, same box, interleaved): 40.4 % of the bf16
+// peak against 39.2 % for the four-phase loop.  Forms that measured behind it: all eight pieces in the load segments
+// (4 + 4, clean 16-MFMA segments): 38.8 %; 4 + 4 inside the segments with the issue slots alternating between even and odd
+// waves (a wave-uniform branch per slot): 35.7 %.  Ablations of this loop (wrong results, stores off): no LDS-DMA 49.8 %, no
+// ds_read 55.7 %, MFMAs alone 70.7 %, the barrier / bookkeeping skeleton alone takes 348 us of the 1040; the same kernel on
+// zero-filled operands runs 36 % faster (846 vs 1149 us): with random operands the matrix pipe is power-limited to ~1.75
+// GHz, so ~72 % of the 2.4 GHz peak is all there is to reach.
 template <typename OutT, int ACT, bool PLAIN>
 __global__ __launch_bounds__(512) void gemm256p2_kernel(const Big a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -665,36 +668,68 @@ __global__ __launch_bounds__(512) void gemm256p2_kernel(const Big a) {
     const int dc0 = ((lane & 7) ^ ((r0 >> 1) & 7)) * 8, dc1 = ((lane & 7) ^ ((r1 >> 1) & 7)) * 8;
     const int wcol0 = (r0 >> 5) * 64 + (r0 & 31), wcol1 = (r1 >> 5) * 64 + (r1 & 31);
     const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
-    // cursor X: A(row half 0) + W(col half 0), two k-tiles ahead; cursor Y: A(row half 1) + W(col half 1), one k-tile ahead
-    struct Cur {
-        int q, kt, h;
-        unsigned a0, a1, b0, b1;
+    // cursor X: A(row half 0) + both W halves, two k-tiles ahead; cursor Y: A(row half 1), one k-tile ahead
+    struct CurX {
+        int q, kt;
+        unsigned a0, a1, b0, b1, b2, b3;
     };
-    auto bind = [&](Cur& c) {
+    struct CurY {
+        int q, kt;
+        unsigned a0, a1;
+    };
+    auto bind_x = [&](CurX& c) {
         int tm, tn;
         if (!tile_of(a, x, c.q, tm, tn)) return false;
-        const int mo = tm * 256 + c.h * 128, no = tn * 256 + c.h * 32;
-        int ra = mo + r0, rb = mo + r1, n0 = no + wcol0, n1 = no + wcol1;
+        const int mo = tm * 256, no = tn * 256;
+        int ra = mo + r0, rb = mo + r1;
         ra = ra < a.M ? ra : a.M - 1;
         rb = rb < a.M ? rb : a.M - 1;
+        int n0 = no + wcol0, n1 = no + wcol1, n2 = n0 + 32, n3 = n1 + 32;
         n0 = n0 < a.N ? n0 : a.N - 1;
         n1 = n1 < a.N ? n1 : a.N - 1;
+        n2 = n2 < a.N ? n2 : a.N - 1;
+        n3 = n3 < a.N ? n3 : a.N - 1;
         c.a0 = (unsigned)ra * (unsigned)a.lda + dc0;
         c.a1 = (unsigned)rb * (unsigned)a.lda + dc1;
         c.b0 = (unsigned)n0 * (unsigned)a.ldw + dc0;
         c.b1 = (unsigned)n1 * (unsigned)a.ldw + dc1;
+        c.b2 = (unsigned)n2 * (unsigned)a.ldw + dc0;
+        c.b3 = (unsigned)n3 * (unsigned)a.ldw + dc1;
         return true;
     };
-    auto advance = [&](Cur& c) {
+    auto bind_y = [&](CurY& c) {
+        int tm, tn;
+        if (!tile_of(a, x, c.q, tm, tn)) return false;
+        const int mo = tm * 256 + 128;
+        int ra = mo + r0, rb = mo + r1;
+        ra = ra < a.M ? ra : a.M - 1;
+        rb = rb < a.M ? rb : a.M - 1;
+        c.a0 = (unsigned)ra * (unsigned)a.lda + dc0;
+        c.a1 = (unsigned)rb * (unsigned)a.lda + dc1;
+        return true;
+    };
+    auto advance_x = [&](CurX& c) {
         if (++c.kt == nkt) {
             c.kt = 0;
             c.q += nb;
-            if (!bind(c)) {
+            if (!bind_x(c)) {
                 const unsigned back = (unsigned)(nkt - 1) * 64;
-                c.a0 -= back; c.a1 -= back; c.b0 -= back; c.b1 -= back;
+                c.a0 -= back; c.a1 -= back; c.b0 -= back; c.b1 -= back; c.b2 -= back; c.b3 -= back;
             }
         } else {
-            c.a0 += 64; c.a1 += 64; c.b0 += 64; c.b1 += 64;
+            c.a0 += 64; c.a1 += 64; c.b0 += 64; c.b1 += 64; c.b2 += 64; c.b3 += 64;
+        }
+    };
+    auto advance_y = [&](CurY& c) {
+        if (++c.kt == nkt) {
+            c.kt = 0;
+            c.q += nb;
+            if (!bind_y(c)) {
+                const unsigned back = (unsigned)(nkt - 1) * 64;
+                c.a0 -= back; c.a1 -= back;
+            }
+        } else {
+            c.a0 += 64; c.a1 += 64;
         }
     };
     // one 1 KiB LDS-DMA piece: 8 rows x 128 B of A or W -> half-tile `slot` (0 A0h, 1 A1h, 2 B0h, 3 B1h) of buffer `buf`
@@ -724,38 +759,61 @@ __global__ __launch_bounds__(512) void gemm256p2_kernel(const Big a) {
         cu_m0 = tm * 256;
         cu_n0 = tn * 256;
     }
-    // ---- prologue, in the steady-state issue order: {A0h B0h}(0), {B1h A1h}(0), {A0h B0h}(1)
-    Cur cx{j, 0, 0, 0u, 0u, 0u, 0u};
-    Cur cy{j, 0, 1, 0u, 0u, 0u, 0u};
-    bind(cx);
-    bind(cy);
+    // ---- prologue, in the steady-state issue order: {A0h B0h B1h}(0), A1h(0), {A0h B0h B1h}(1)
+    CurX cx{j, 0, 0u, 0u, 0u, 0u, 0u, 0u};
+    CurY cy{j, 0, 0u, 0u};
+    bind_x(cx);
+    bind_y(cy);
     piece(a.A, cx.a0, 0, 0, 0); piece(a.A, cx.a1, 0, 0, 1);
     piece(a.W, cx.b0, 0, 2, 0); piece(a.W, cx.b1, 0, 2, 1);
-    piece(a.W, cy.b0, 0, 3, 0); piece(a.W, cy.b1, 0, 3, 1);
+    piece(a.W, cx.b2, 0, 3, 0); piece(a.W, cx.b3, 0, 3, 1);
     piece(a.A, cy.a0, 0, 1, 0); piece(a.A, cy.a1, 0, 1, 1);
-    advance(cx);  // -> k-tile 1
-    advance(cy);  // -> k-tile 1
+    advance_x(cx);  // -> k-tile 1
+    advance_y(cy);  // -> k-tile 1
     piece(a.A, cx.a0, 1, 0, 0); piece(a.A, cx.a1, 1, 0, 1);
     piece(a.W, cx.b0, 1, 2, 0); piece(a.W, cx.b1, 1, 2, 1);
-    advance(cx);  // -> k-tile 2
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // {A0h B0h B1h}(0) landed
+    piece(a.W, cx.b2, 1, 3, 0); piece(a.W, cx.b3, 1, 3, 1);
+    advance_x(cx);  // -> k-tile 2
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // {A0h B0h B1h}(0) landed
     raw_barrier();
     if (wr == 1) raw_barrier();  // waves 4-7 run half a phase behind
 
 #define P2_MFMA(ACC, FB, KS, RB)                                                                                          \
     ACC[RB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FB[KS]), __builtin_bit_cast(bf16x8_t, fa[RB][KS]), \
                                                       ACC[RB], 0, 0, 0)
-// 16 MFMAs, nothing else: for every k-step the two row blocks of quadrant X, then of quadrant Y
-#define P2_SEG(ACCX, FBX, ACCY, FBY)                         \
+// 16 MFMAs: for every k-step the two row blocks of quadrant X, then of quadrant Y; HOOK(i) runs after MFMA pair i (0..7)
+#define P2_SEG(ACCX, FBX, ACCY, FBY, HOOK)                   \
     do {                                                     \
         if (kPrio) __builtin_amdgcn_s_setprio(1);            \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {   \
             P2_MFMA(ACCX, FBX, ks, 0);                       \
             P2_MFMA(ACCX, FBX, ks, 1);                       \
+            __builtin_amdgcn_sched_barrier(0);               \
+            HOOK(2 * ks);                                    \
+            __builtin_amdgcn_sched_barrier(0);               \
             P2_MFMA(ACCY, FBY, ks, 0);                       \
             P2_MFMA(ACCY, FBY, ks, 1);                       \
+            __builtin_amdgcn_sched_barrier(0);               \
+            HOOK(2 * ks + 1);                                \
+            __builtin_amdgcn_sched_barrier(0);               \
         }                                                    \
         if (kPrio) __builtin_amdgcn_s_setprio(0);            \
+    } while (0)
+// phase A's segment re-stages A1h of k-tile g + 1 (cursor Y) into the OTHER buffer: pieces after MFMA pairs 1 and 5
+#define P2_HOOK_A(i)                                          \
+    do {                                                      \
+        if ((i) == 1) piece(a.A, cy.a0, buf ^ 1, 1, 0);       \
+        if ((i) == 5) piece(a.A, cy.a1, buf ^ 1, 1, 1);       \
+    } while (0)
+// phase B's segment re-stages {A0h B0h B1h} of k-tile g + 2 (cursor X) into THIS buffer: pieces after pairs 0..5
+#define P2_HOOK_B(i)                                          \
+    do {                                                      \
+        if ((i) == 0) piece(a.A, cx.a0, buf, 0, 0);           \
+        if ((i) == 1) piece(a.A, cx.a1, buf, 0, 1);           \
+        if ((i) == 2) piece(a.W, cx.b0, buf, 2, 0);           \
+        if ((i) == 3) piece(a.W, cx.b1, buf, 2, 1);           \
+        if ((i) == 4) piece(a.W, cx.b2, buf, 3, 0);           \
+        if ((i) == 5) piece(a.W, cx.b3, buf, 3, 1);           \
     } while (0)
 
     u32x4_t fa[2][4], fb0[4], fb1[4];
@@ -772,32 +830,26 @@ __global__ __launch_bounds__(512) void gemm256p2_kernel(const Big a) {
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) ds_read128<kHalf>(fb1[ks], baddr[ks] + bo);
-        // {B1h A1h} of k-tile g + 1 -> the other buffer
-        piece(a.W, cy.b0, buf ^ 1, 3, 0); piece(a.W, cy.b1, buf ^ 1, 3, 1);
-        piece(a.A, cy.a0, buf ^ 1, 1, 0); piece(a.A, cy.a1, buf ^ 1, 1, 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A1h of this k-tile has landed (read next phase)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads retired BEFORE the barrier: their half-tiles are free after it
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A1h of this k-tile has landed (read next phase)
         raw_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        P2_SEG(acc[0][0], fb0, acc[0][1], fb1);
+        P2_SEG(acc[0][0], fb0, acc[0][1], fb1, P2_HOOK_A);
         raw_barrier();
-        advance(cy);
+        advance_y(cy);
         // ================= phase B: quadrants (1,1), (1,0)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             ds_read128<kHalf>(fa[0][ks], aaddr[ks] + bo);
             ds_read128<kHalf + 4096>(fa[1][ks], aaddr[ks] + bo);
         }
-        // {A0h B0h} of k-tile g + 2 -> this buffer
-        piece(a.A, cx.a0, buf, 0, 0); piece(a.A, cx.a1, buf, 0, 1);
-        piece(a.W, cx.b0, buf, 2, 0); piece(a.W, cx.b1, buf, 2, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // {A0h B0h B1h} of the next k-tile have landed
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // {A0h B0h B1h} of the next k-tile have landed
+        raw_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        raw_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        P2_SEG(acc[1][1], fb1, acc[1][0], fb0);
+        P2_SEG(acc[1][1], fb1, acc[1][0], fb0, P2_HOOK_B);
         raw_barrier();
-        advance(cx);
+        advance_x(cx);
         bo ^= (unsigned)kBuf;
 
         if (++cu_kt == nkt) {
@@ -830,6 +882,8 @@ __global__ __launch_bounds__(512) void gemm256p2_kernel(const Big a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef P2_MFMA
 #undef P2_SEG
+#undef P2_HOOK_A
+#undef P2_HOOK_B
 }
 
 }  // namespace
@@ -840,10 +894,11 @@ bool gemm256_eligible(const GemmArgs& g) {
     if (off || g.in_dtype != DIMX_BF16 || g.conv_T != 0 || g.out_slabs || g.force_simple) return false;
     const int kext = g.kloop ? g.kloop : g.ldw;
     if (g.K % 64 != 0 || g.K != kext || g.M < 4096 || g.N < 256 || g.N % 8 != 0) return false;
-    // measured (tools/bench_prefill.py): ahead of the 128 x 128 kernel from K = 768 and N = 1024 up; short K or narrow N
-    // (one and a half column tiles at N = 384) leave it behind
+    // measured (tools/bench_prefill.py, round 3, two-phase loop + scalar epilogue): ahead of the 128 x 128 kernel on every
+    // prefill shape with min(N, K) >= 384 and N K >= 384 x 1536 -- (N 1536, K 384) 225 -> 199 us, (N 384, K 1536) 156 -> 128 us,
+    // (N 2304, K 384) 276 -> 174 us, level from K = 1152 up; one and a half column tiles of a 384 x 384 projection stay behind
     static const bool all = getenv("DIMX_G256_ALL") != nullptr;
-    if (!all && (g.K < 768 || g.N < 1024)) return false;
+    if (!all && (g.K < 384 || g.N < 384 || (long)g.N * g.K < 384L * 1536L)) return false;
     if ((size_t)g.M * g.lda >= (1ull << 32) || (size_t)g.N * g.ldw >= (1ull << 32)) return false;  // 32-bit element offsets
     if (g.bias && ((uintptr_t)g.bias % 16)) return false;
     if (g.residual && (g.ldr % 4 || (uintptr_t)g.residual % 16)) return false;
@@ -943,27 +998,25 @@ static int launch_big(const GemmArgs& g, const OutSeg* segs, int nseg, int seg_w
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<OT, AC, PL, VR, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal); \
         hipLaunchKernelGGL((gemm256_kernel<OT, AC, PL, VR, PF>), dim3(grid), dim3(512), kLdsTotal, s, a);                   \
     } while (0)
-#define G256(OT, AC, VR, PF)                                                   \
-    do {                                                                       \
-        if (plain) G256_(OT, AC, true, VR, PF); else G256_(OT, AC, false, VR, PF); \
-    } while (0)
-#define G256_ACT(OT)                                                                  \
-    do {                                                                              \
-        switch (g.act) {                                                              \
-            case ACT_LEAKY: G256(OT, ACT_LEAKY, kDefaultVar, false); break;           \
-            case ACT_GELU_TANH: G256(OT, ACT_GELU_TANH, kDefaultVar, false); break;   \
-            case ACT_GELU_ERF: G256(OT, ACT_GELU_ERF, kDefaultVar, false); break;     \
-            default: G256(OT, ACT_NONE, kDefaultVar, false); break;                   \
-        }                                                                             \
-    } while (0)
 #define G256P2_(OT, AC, PL)                                                                                             \
     do {                                                                                                                \
         (void)hipFuncSetAttribute((const void*)gemm256p2_kernel<OT, AC, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal); \
         hipLaunchKernelGGL((gemm256p2_kernel<OT, AC, PL>), dim3(grid), dim3(512), kLdsTotal, s, a);                     \
     } while (0)
-    if (tunable && var == 5 && !prof) {
-        G256P2_(bf16, ACT_NONE, true);
-    } else if (tunable && (var != kDefaultVar || prof)) {
+#define G256P2(OT, AC)                                                     \
+    do {                                                                   \
+        if (plain) G256P2_(OT, AC, true); else G256P2_(OT, AC, false);     \
+    } while (0)
+#define G256P2_ACT(OT)                                           \
+    do {                                                         \
+        switch (g.act) {                                         \
+            case ACT_LEAKY: G256P2(OT, ACT_LEAKY); break;        \
+            case ACT_GELU_TANH: G256P2(OT, ACT_GELU_TANH); break;\
+            case ACT_GELU_ERF: G256P2(OT, ACT_GELU_ERF); break;  \
+            default: G256P2(OT, ACT_NONE); break;                \
+        }                                                        \
+    } while (0)
+    if (tunable && (var != kDefaultVar || prof)) {  // the four-phase loop's forms: A/B runs and the in-kernel profile
         switch (var * 2 + (prof ? 1 : 0)) {
             case 0: G256_(bf16, ACT_NONE, true, 0, false); break;
             case 1: G256_(bf16, ACT_NONE, true, 0, true); break;
@@ -973,17 +1026,18 @@ static int launch_big(const GemmArgs& g, const OutSeg* segs, int nseg, int seg_w
             case 5: G256_(bf16, ACT_NONE, true, 2, true); break;
             case 6: G256_(bf16, ACT_NONE, true, 3, false); break;
             case 7: G256_(bf16, ACT_NONE, true, 3, true); break;
+            case 9: G256_(bf16, ACT_NONE, true, 3, true); break;  // DIMX_G256_PROF without a VAR: the four-phase loop's stamps
             default: DIMX_REQUIRE(false, DIMX_ERR_ARG, "gemm256: DIMX_G256_VAR=%d", var);
         }
     } else if (g.out_dtype == DIMX_BF16) {
-        G256_ACT(bf16);
+        G256P2_ACT(bf16);
     } else {
-        G256_ACT(float);
+        G256P2_ACT(float);
     }
-#undef G256_ACT
-#undef G256
-#undef G256_
+#undef G256P2_ACT
+#undef G256P2
 #undef G256P2_
+#undef G256_
     if (prof) {  // tuning only: synchronous read-back of block 0's interval sums (waves 0 and 4)
         unsigned long long hst[64];
         DIMX_HIP(hipStreamSynchronize(s));

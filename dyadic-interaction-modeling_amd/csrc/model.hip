@@ -1680,6 +1680,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         gemm_lin(h, s.y, DD, defer ? h->dec.ff[l].f1_ln : h->dec.ff[l].f1, B, g);
         if (defer) {
             g.ln_stats = h->chain_stats_dev;
+            g.ln_err = h->chain_err_dev;
             g.ln_colsum = h->dec.ff[l].f1_ln_colsum;
             g.ln_C = DD;
         }
@@ -1869,12 +1870,21 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     if (!e) return DIMX_OK;
     *h->chain_err_host = 0;
     DIMX_HIP(hipMemsetAsync(h->chain_err_dev, 0, 64, (hipStream_t)stream));
-    h->use_chain = 0;
     h->graph_valid = false;
     ++h->chain_faults;
-    fprintf(stderr, "dimx: the XCD-local chain kernels reported %s%s; this batch is regenerated on the one-kernel-per-op "
-                    "step and the chain path stays off for this handle (DIMX_NO_CHAIN=1 avoids it from the start)\n",
-            (e & 1) ? "two blocks on one (XCD, CU slot) " : "", (e & 2) ? "a group-barrier timeout" : "");
+    if (e & 3u) {
+        h->use_chain = 0;
+        fprintf(stderr, "dimx: the XCD-local chain kernels reported %s%s; this batch is regenerated on the one-kernel-per-op "
+                        "step and the chain path stays off for this handle (DIMX_NO_CHAIN=1 avoids it from the start)\n",
+                (e & 1) ? "two blocks on one (XCD, CU slot) " : "", (e & 2) ? "a group-barrier timeout" : "");
+    } else {
+        // bit 2 alone: a residual row with |mean| > 8 standard deviations -- the deferred LayerNorm multiplies bf16(x), not
+        // bf16(x - mean), and its rounding noise is no longer small against the row's spread.  Same repair: the batch is
+        // regenerated with the row-phase LayerNorm (chain kernels stay on).
+        h->defer_ln = 0;
+        fprintf(stderr, "dimx: a residual row's mean exceeds 8 standard deviations; this batch is regenerated with the row-phase "
+                        "LayerNorm and the deferred form stays off for this handle (DIMX_NO_DEFER_LN=1 avoids it from the start)\n");
+    }
     return generate_impl(h, start, ctx_mask, B, T, n_samples, temperature, top_k, exp_noise, seed, tokens, logits_out, ws,
                          ws_bytes, stream, &chain_used);
 }

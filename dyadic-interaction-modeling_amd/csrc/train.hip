@@ -1,0 +1,628 @@
+// train.hip -- the training step of the DIM-Listener fine-tuning model on hand-written HIP kernels.
+//
+// Reference: train_epoch (code/x_engine_pt.py:9-60) as driven by code/finetune_s2s_pretrain.py:105-143 (AdamW lr 1e-5,
+// clip 1.0, both VQ-VAEs frozen :348-366).  What carries gradient is the teacher-forced path of SLMFT.forward(mode='train')
+// (code/seq2seq_pretrain.py:496-514): encoder_s -> encoder_joint -> norm_s -> context -> AutoregressiveWrapper.forward ->
+// cross entropy (the continuous loss has no gradient path in the reference either: its `pred` comes from an argmax).
+//
+// The reference leaves the backward pass to autograd; here forward and backward are explicit:
+//   * every Linear, forward and both adjoints, is the library's GEMM C = A[M,K] . W[N,K]^T (gemm.hip / gemm256.hip; exact-f32
+//     MFMA in the parity mode, bf16 MFMA with f32 accumulation in the perf mode): y = x . W^T directly, dx = dy . (W^T)^T
+//     with a transposed operand copy of W made once per step, dW = dy^T . (x^T)^T with transposed copies of dy and x
+//     (zero-padded along the contraction, train_kernels.hip);
+//   * attention, LayerNorm, GELU, cross entropy, the embedding / positional / patch tables and the optimiser are the kernels of
+//     train_kernels.hip;
+//   * parameters, gradients and the AdamW moments live in FLAT f32 arenas owned by the caller (one float per parameter, the
+//     layout is reported by dimx_train_param_info), so the multi-GPU gradient average is ONE all-reduce of one buffer
+//     (RCCL over xGMI is per-link bound: one large collective, no per-tensor traffic), and the master weights stay f32.
+// Activations needed by the backward pass are kept in the caller's workspace (dimx_train_workspace_bytes).
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "model.hpp"
+#include "train.hpp"
+
+namespace dimx {
+namespace {
+
+struct PInfo {
+    std::string name;
+    long off, numel;
+    int rows, cols;  // matrices: [rows, cols]; vectors: rows = 1
+};
+
+struct Lin {          // one Linear of the stack
+    long w = -1, b = -1;  // offsets into the flat arenas (b < 0: no bias)
+    int N = 0, K = 0;
+    void* w_op = nullptr;   // [N][Kp] operand copy (this step)
+    void* wt_op = nullptr;  // [K][Np] transposed operand copy
+};
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+struct TrainPlan {
+    std::vector<PInfo> params;
+    std::map<std::string, int> index;
+    long total = 0;
+};
+
+// every tensor the reference's optimiser would update with a non-zero gradient on this path, in state-dict order of the
+// stack (deterministic: the caller's arenas are laid out by it)
+int build_plan(dimx_handle h, TrainPlan& p) {
+    const dimx_dims& d = h->d;
+    auto add = [&](const std::string& name, int rows, int cols) -> int {
+        auto it = h->host.find(name);
+        DIMX_REQUIRE(it != h->host.end(), DIMX_ERR_WEIGHT, "train: weight %s was not loaded", name.c_str());
+        long n = 1;
+        for (auto s : it->second.shape) n *= s;
+        DIMX_REQUIRE(n == (long)rows * cols, DIMX_ERR_WEIGHT, "train: %s has %ld elements, expected %d x %d", name.c_str(), n, rows, cols);
+        PInfo pi{name, p.total, n, rows, cols};
+        p.index[name] = (int)p.params.size();
+        p.params.push_back(pi);
+        p.total += (n + 3) / 4 * 4;  // 16-byte aligned tensors
+        return DIMX_OK;
+    };
+    const int inner = d.heads * d.dim_head;
+    DIMX_TRY(add("patch_embed_s", 1, d.dim_in));
+    DIMX_TRY(add("patch_embed_dec_s", 1, d.dim));
+    DIMX_TRY(add("norm_s.weight", 1, d.dim));
+    DIMX_TRY(add("norm_s.bias", 1, d.dim));
+    for (const char* enc : {"encoder_s.", "encoder_joint."}) {
+        const std::string e(enc);
+        DIMX_TRY(add(e + "project_in.weight", d.dim, e == "encoder_s." ? d.dim_in : d.dim));
+        DIMX_TRY(add(e + "pos_emb.emb.weight", d.max_seq_len, d.dim));
+        for (int i = 0; i < d.enc_depth; ++i) {
+            const std::string la = e + "attn_layers.layers." + std::to_string(2 * i) + ".";
+            const std::string lf = e + "attn_layers.layers." + std::to_string(2 * i + 1) + ".";
+            DIMX_TRY(add(la + "0.0.weight", 1, d.dim));
+            DIMX_TRY(add(la + "1.to_q.weight", inner, d.dim));
+            DIMX_TRY(add(la + "1.to_k.weight", inner, d.dim));
+            DIMX_TRY(add(la + "1.to_v.weight", inner, d.dim));
+            DIMX_TRY(add(la + "1.to_out.weight", d.dim, inner));
+            DIMX_TRY(add(lf + "0.0.weight", 1, d.dim));
+            DIMX_TRY(add(lf + "1.ff.0.0.weight", d.dim * d.ff_mult, d.dim));
+            DIMX_TRY(add(lf + "1.ff.0.0.bias", 1, d.dim * d.ff_mult));
+            DIMX_TRY(add(lf + "1.ff.2.weight", d.dim, d.dim * d.ff_mult));
+            DIMX_TRY(add(lf + "1.ff.2.bias", 1, d.dim));
+        }
+        DIMX_TRY(add(e + "attn_layers.final_norm.weight", 1, d.dim));
+    }
+    const int DD = d.dim + d.dim_a;  // decoder width = context width
+    const std::string dn = "decoder_joint.net.";
+    DIMX_TRY(add(dn + "token_emb.emb.weight", d.num_tokens, DD));
+    for (int i = 0; i < d.dec_depth; ++i) {
+        for (int k = 0; k < 2; ++k) {  // self, cross
+            const std::string la = dn + "attn_layers.layers." + std::to_string(3 * i + k) + ".";
+            DIMX_TRY(add(la + "0.0.weight", 1, DD));
+            DIMX_TRY(add(la + "1.to_q.weight", inner, DD));
+            DIMX_TRY(add(la + "1.to_k.weight", inner, DD));
+            DIMX_TRY(add(la + "1.to_v.weight", inner, DD));
+            DIMX_TRY(add(la + "1.to_out.weight", DD, inner));
+        }
+        const std::string lf = dn + "attn_layers.layers." + std::to_string(3 * i + 2) + ".";
+        DIMX_TRY(add(lf + "0.0.weight", 1, DD));
+        DIMX_TRY(add(lf + "1.ff.0.0.weight", DD * d.ff_mult, DD));
+        DIMX_TRY(add(lf + "1.ff.0.0.bias", 1, DD * d.ff_mult));
+        DIMX_TRY(add(lf + "1.ff.2.weight", DD, DD * d.ff_mult));
+        DIMX_TRY(add(lf + "1.ff.2.bias", 1, DD));
+    }
+    DIMX_TRY(add(dn + "attn_layers.final_norm.weight", 1, DD));
+    DIMX_TRY(add(dn + "to_logits.weight", d.num_tokens, DD));
+    return DIMX_OK;
+}
+
+TrainPlan* plan_of(dimx_handle h, int* rc) {
+    static std::map<dimx_handle, TrainPlan> plans;  // handles are few and long-lived
+    auto it = plans.find(h);
+    if (it == plans.end()) {
+        TrainPlan p;
+        *rc = build_plan(h, p);
+        if (*rc != DIMX_OK) return nullptr;
+        it = plans.emplace(h, std::move(p)).first;
+    }
+    *rc = DIMX_OK;
+    return &it->second;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- step context
+struct Step {
+    dimx_handle h;
+    const TrainPlan* plan;
+    const float* P;  // parameters (flat, device)
+    float* G;        // gradients (flat, device)
+    Arena* ar;
+    hipStream_t st;
+    int at;          // operand type of the GEMMs
+    int bk;          // k-tile of the operand type (64 bf16 / 32 f32)
+    float* part;     // column-reduction scratch [2 * kTrSlabs * maxC]
+    int B, T, M, n, Md;
+
+    size_t es() const { return dtype_size(at); }
+    long off(const std::string& name) const { return plan->params[plan->index.at(name)].off; }
+    const float* p(const std::string& name) const { return P + off(name); }
+    float* g(const std::string& name) const { return G + off(name); }
+    float* f32(size_t n_) { return (float*)ar->take(n_ * sizeof(float)); }
+};
+
+Lin make_lin(const Step& s, const std::string& wname, const std::string& bname = std::string()) {
+    Lin l;
+    const PInfo& pi = s.plan->params[s.plan->index.at(wname)];
+    l.w = pi.off;
+    l.N = pi.rows;
+    l.K = pi.cols;
+    if (!bname.empty()) l.b = s.off(bname);
+    return l;
+}
+
+// operand copies of a weight for this step: [N][Kp] and its transpose [K][Np]
+int prep_lin(Step& s, Lin& l) {
+    const int Kp = pad_to(l.K, s.bk), Np = pad_to(l.N, s.bk);
+    l.w_op = s.ar->take((size_t)l.N * Kp * s.es());
+    l.wt_op = s.ar->take((size_t)l.K * Np * s.es());
+    if (!s.ar->base) return DIMX_OK;
+    DIMX_TRY(launch_cast_pad(s.at, s.P + l.w, l.K, nullptr, l.w_op, Kp, l.N, l.K, s.st));
+    DIMX_TRY(tr_transpose_pad(s.at, s.P + l.w, l.K, l.wt_op, Np, l.N, l.K, s.st));
+    return DIMX_OK;
+}
+
+// C[M,N] f32 = A_op[M,Kp] . W_op[N,Kp]^T (+ bias) (+ residual, which may be C itself)
+int gemm_f32(Step& s, const void* A_op, int Kp, const void* W_op, int M, int N, int K, float* C, int ldc, const float* bias,
+             const float* residual, int ldr) {
+    if (!s.ar->base) return DIMX_OK;
+    GemmArgs g;
+    gemm_args_init(g);
+    g.in_dtype = s.at;
+    g.out_dtype = DIMX_F32;
+    g.A = A_op;
+    g.lda = Kp;
+    g.W = W_op;
+    g.ldw = Kp;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.bias = bias;
+    g.residual = residual;
+    g.ldr = ldr;
+    gemm_set_plain_out(g, C, ldc);
+    return launch_gemm(g, s.st);
+}
+
+// operand copy of an f32 activation [M,K] -> [M,Kp] in the operand type
+void* as_operand(Step& s, const float* x, int ldx, int M, int K, int* Kp_out) {
+    const int Kp = pad_to(K, s.bk);
+    *Kp_out = Kp;
+    void* o = s.ar->take((size_t)M * Kp * s.es());
+    if (s.ar->base) (void)launch_cast_pad(s.at, x, ldx, nullptr, o, Kp, M, K, s.st);
+    return o;
+}
+
+// y = x . W^T (+ b) (+ residual)
+int lin_fwd(Step& s, const Lin& l, const float* x, int ldx, int M, float* y, int ldy, const float* residual = nullptr, int ldr = 0) {
+    int Kp;
+    const size_t mark = s.ar->off;
+    void* xo = as_operand(s, x, ldx, M, l.K, &Kp);
+    const int rc = gemm_f32(s, xo, Kp, l.w_op, M, l.N, l.K, y, ldy, l.b >= 0 ? s.P + l.b : nullptr, residual, ldr);
+    s.ar->off = mark;  // the operand copy is dead after the launch (stream order protects it until then)
+    return rc;
+}
+
+// dx (+)= dy . W ; dW = dy^T . x ; db = colsum(dy).  x [M,K] (ldx), dy [M,N] (ldy) f32.  dx may be null.
+int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int ldy, int M, float* dx, int lddx, bool accumulate_dx) {
+    const size_t mark = s.ar->off;
+    const int Mp = pad_to(M, s.bk);
+    int Np;
+    void* dyo = as_operand(s, dy, ldy, M, l.N, &Np);
+    if (dx) DIMX_TRY(gemm_f32(s, dyo, Np, l.wt_op, M, l.K, l.N, dx, lddx, nullptr, accumulate_dx ? dx : nullptr, lddx));
+    void* dyT = s.ar->take((size_t)l.N * Mp * s.es());
+    void* xT = s.ar->take((size_t)l.K * Mp * s.es());
+    if (s.ar->base) {
+        DIMX_TRY(tr_transpose_pad(s.at, dy, ldy, dyT, Mp, M, l.N, s.st));
+        DIMX_TRY(tr_transpose_pad(s.at, x, ldx, xT, Mp, M, l.K, s.st));
+        DIMX_TRY(gemm_f32(s, dyT, Mp, xT, l.N, l.K, M, s.G + l.w, l.K, nullptr, nullptr, 0));
+        if (l.b >= 0) DIMX_TRY(tr_colsums(nullptr, dy, nullptr, s.G + l.b, M, l.N, s.part, 0, s.st));
+    }
+    s.ar->off = mark;
+    return DIMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- sublayers
+struct AttnSave {
+    std::string pre;      // "...layers.N." prefix
+    Lin q, k, v, o;
+    const float* h_in;    // residual stream before the sublayer [M, C]
+    float *y, *qb, *kb, *vb, *ob, *lse;  // LN output, projections, attention output, row LSE
+    const float* src;     // key/value source rows (y for self-attention, the context for cross-attention)
+    int M, Mk, C, Ck;     // query rows, key rows, widths
+    TrAttn shape;
+    const uint8_t* qmask; // zero-fill of padded query rows after to_out (encoders)
+};
+struct FFSave {
+    std::string pre;
+    Lin f1, f2;
+    const float* h_in;
+    float *y, *pre_act, *act;
+    int M, C, F;
+};
+
+int attn_prepare(Step& s, AttnSave& a, const std::string& pre) {
+    a.pre = pre;
+    a.q = make_lin(s, pre + "1.to_q.weight");
+    a.k = make_lin(s, pre + "1.to_k.weight");
+    a.v = make_lin(s, pre + "1.to_v.weight");
+    a.o = make_lin(s, pre + "1.to_out.weight");
+    DIMX_TRY(prep_lin(s, a.q));
+    DIMX_TRY(prep_lin(s, a.k));
+    DIMX_TRY(prep_lin(s, a.v));
+    DIMX_TRY(prep_lin(s, a.o));
+    return DIMX_OK;
+}
+int ff_prepare(Step& s, FFSave& f, const std::string& pre) {
+    f.pre = pre;
+    f.f1 = make_lin(s, pre + "1.ff.0.0.weight", pre + "1.ff.0.0.bias");
+    f.f2 = make_lin(s, pre + "1.ff.2.weight", pre + "1.ff.2.bias");
+    DIMX_TRY(prep_lin(s, f.f1));
+    DIMX_TRY(prep_lin(s, f.f2));
+    return DIMX_OK;
+}
+
+// h_out = h_in + to_out(attn(LN(h_in) Wq, src Wk, src Wv)); src = LN(h_in) (self) or ctx (cross, Mk rows of width Ck)
+int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C, const float* ctx, int Mk, int Ck, const TrAttn& shape,
+             const uint8_t* qmask) {
+    const int inner = a.q.N;
+    a.h_in = h_in;
+    a.M = M;
+    a.C = C;
+    a.Mk = ctx ? Mk : M;
+    a.Ck = ctx ? Ck : C;
+    a.qmask = qmask;
+    a.y = s.f32((size_t)M * C);
+    a.qb = s.f32((size_t)M * inner);
+    a.kb = s.f32((size_t)a.Mk * inner);
+    a.vb = s.f32((size_t)a.Mk * inner);
+    a.ob = s.f32((size_t)M * inner);
+    a.lse = s.f32((size_t)shape.B * shape.H * shape.Lq);
+    a.src = ctx ? ctx : a.y;
+    a.shape = shape;
+    a.shape.ldq = a.shape.ldk = a.shape.ldv = a.shape.ldo = inner;
+    if (!s.ar->base) return DIMX_OK;
+    DIMX_TRY(launch_layernorm(DIMX_F32, h_in, a.y, s.p(a.pre + "0.0.weight"), nullptr, M, C, s.st));
+    DIMX_TRY(lin_fwd(s, a.q, a.y, C, M, a.qb, inner));
+    DIMX_TRY(lin_fwd(s, a.k, a.src, a.Ck, a.Mk, a.kb, inner));
+    DIMX_TRY(lin_fwd(s, a.v, a.src, a.Ck, a.Mk, a.vb, inner));
+    DIMX_TRY(tr_attn_fwd(a.shape, a.qb, a.kb, a.vb, a.ob, a.lse, s.st));
+    if (qmask) {  // out = to_out(o) with padded query rows zero-filled, then the residual
+        float* tmp = s.f32((size_t)M * C);
+        DIMX_TRY(lin_fwd(s, a.o, a.ob, inner, M, tmp, C));
+        DIMX_TRY(tr_zero_rows(tmp, qmask, M, C, s.st));
+        DIMX_TRY(tr_copy_cols(h_in, C, h_out, C, M, C, 0, s.st));
+        DIMX_TRY(tr_add(h_out, tmp, (long)M * C, s.st));
+    } else {
+        DIMX_TRY(lin_fwd(s, a.o, a.ob, inner, M, h_out, C, h_in, C));
+    }
+    return DIMX_OK;
+}
+
+// dh: gradient wrt h_out on entry, wrt h_in on return (in place); dctx (cross-attention) accumulates the context gradient
+int attn_bwd(Step& s, AttnSave& a, float* dh, float* dctx) {
+    const size_t mark = s.ar->off;
+    const int inner = a.q.N, M = a.M, C = a.C;
+    float* dout = dh;
+    if (a.qmask) {
+        dout = s.f32((size_t)M * C);
+        DIMX_TRY(tr_copy_cols(dh, C, dout, C, M, C, 0, s.st));
+        DIMX_TRY(tr_zero_rows(dout, a.qmask, M, C, s.st));
+    }
+    float* d_o = s.f32((size_t)M * inner);
+    DIMX_TRY(lin_bwd(s, a.o, a.ob, inner, dout, C, M, d_o, inner, false));
+    float* dq = s.f32((size_t)M * inner);
+    float* dk = s.f32((size_t)a.Mk * inner);
+    float* dv = s.f32((size_t)a.Mk * inner);
+    float* delta = s.f32((size_t)a.shape.B * a.shape.H * a.shape.Lq);
+    DIMX_TRY(tr_attn_bwd(a.shape, a.qb, a.kb, a.vb, a.ob, d_o, a.lse, delta, dq, inner, dk, inner, dv, inner, s.st));
+    float* dy = s.f32((size_t)M * C);
+    DIMX_TRY(lin_bwd(s, a.q, a.y, C, dq, inner, M, dy, C, false));
+    if (a.src == a.y) {
+        DIMX_TRY(lin_bwd(s, a.k, a.y, C, dk, inner, M, dy, C, true));
+        DIMX_TRY(lin_bwd(s, a.v, a.y, C, dv, inner, M, dy, C, true));
+    } else {
+        DIMX_TRY(lin_bwd(s, a.k, a.src, a.Ck, dk, inner, a.Mk, dctx, a.Ck, true));
+        DIMX_TRY(lin_bwd(s, a.v, a.src, a.Ck, dv, inner, a.Mk, dctx, a.Ck, true));
+    }
+    // LayerNorm: d gamma = colsum(dy o xhat), dh += LN'(h_in) dy
+    float* xh = s.f32((size_t)M * C);
+    DIMX_TRY(tr_xhat(a.h_in, xh, M, C, s.st));
+    DIMX_TRY(tr_colsums(xh, dy, s.g(a.pre + "0.0.weight"), nullptr, M, C, s.part, 0, s.st));
+    DIMX_TRY(tr_layernorm_bwd(a.h_in, s.p(a.pre + "0.0.weight"), dy, dh, 1, M, C, s.st));
+    s.ar->off = mark;
+    return DIMX_OK;
+}
+
+int ff_fwd(Step& s, FFSave& f, const float* h_in, float* h_out, int M, int C) {
+    f.h_in = h_in;
+    f.M = M;
+    f.C = C;
+    f.F = f.f1.N;
+    f.y = s.f32((size_t)M * C);
+    f.pre_act = s.f32((size_t)M * f.F);
+    f.act = s.f32((size_t)M * f.F);
+    if (!s.ar->base) return DIMX_OK;
+    DIMX_TRY(launch_layernorm(DIMX_F32, h_in, f.y, s.p(f.pre + "0.0.weight"), nullptr, M, C, s.st));
+    DIMX_TRY(lin_fwd(s, f.f1, f.y, C, M, f.pre_act, f.F));
+    DIMX_TRY(tr_gelu_fwd(f.pre_act, f.act, (long)M * f.F, s.st));
+    DIMX_TRY(lin_fwd(s, f.f2, f.act, f.F, M, h_out, C, h_in, C));
+    return DIMX_OK;
+}
+int ff_bwd(Step& s, FFSave& f, float* dh) {
+    const size_t mark = s.ar->off;
+    const int M = f.M, C = f.C, F = f.F;
+    float* da = s.f32((size_t)M * F);
+    DIMX_TRY(lin_bwd(s, f.f2, f.act, F, dh, C, M, da, F, false));
+    DIMX_TRY(tr_gelu_bwd(f.pre_act, da, da, (long)M * F, s.st));  // da becomes d pre-activation in place
+    float* dy = s.f32((size_t)M * C);
+    DIMX_TRY(lin_bwd(s, f.f1, f.y, C, da, F, M, dy, C, false));
+    float* xh = s.f32((size_t)M * C);
+    DIMX_TRY(tr_xhat(f.h_in, xh, M, C, s.st));
+    DIMX_TRY(tr_colsums(xh, dy, s.g(f.pre + "0.0.weight"), nullptr, M, C, s.part, 0, s.st));
+    DIMX_TRY(tr_layernorm_bwd(f.h_in, s.p(f.pre + "0.0.weight"), dy, dh, 1, M, C, s.st));
+    s.ar->off = mark;
+    return DIMX_OK;
+}
+
+// final / stand-alone LayerNorm: y = LN(x) gamma (+ beta)
+int ln_bwd_full(Step& s, const float* x, const std::string& gname, const std::string& bname, const float* dy, float* dx, int M, int C) {
+    const size_t mark = s.ar->off;
+    float* xh = s.f32((size_t)M * C);
+    DIMX_TRY(tr_xhat(x, xh, M, C, s.st));
+    DIMX_TRY(tr_colsums(xh, dy, s.g(gname), bname.empty() ? nullptr : s.g(bname), M, C, s.part, 0, s.st));
+    DIMX_TRY(tr_layernorm_bwd(x, s.p(gname), dy, dx, 0, M, C, s.st));
+    s.ar->off = mark;
+    return DIMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- encoder
+struct EncSave {
+    std::string pre;
+    Lin pin;
+    const float* x_in;   // [M, Cin]
+    int Cin;
+    std::vector<AttnSave> attn;
+    std::vector<FFSave> ff;
+    std::vector<float*> h;  // residual stream after every sublayer (h[0] = after project_in + pos)
+    float* out;             // final norm output
+};
+
+int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int Cin, const uint8_t* mask_rows, const uint8_t* mask_bt) {
+    const dimx_dims& d = s.h->d;
+    const int M = s.M, C = d.dim;
+    e.pre = pre;
+    e.x_in = x_in;
+    e.Cin = Cin;
+    e.pin = make_lin(s, pre + "project_in.weight");
+    DIMX_TRY(prep_lin(s, e.pin));
+    e.attn.resize(d.enc_depth);
+    e.ff.resize(d.enc_depth);
+    for (int i = 0; i < d.enc_depth; ++i) {
+        DIMX_TRY(attn_prepare(s, e.attn[i], pre + "attn_layers.layers." + std::to_string(2 * i) + "."));
+        DIMX_TRY(ff_prepare(s, e.ff[i], pre + "attn_layers.layers." + std::to_string(2 * i + 1) + "."));
+    }
+    e.h.assign(2 * d.enc_depth + 1, nullptr);
+    for (auto& p : e.h) p = s.f32((size_t)M * C);
+    e.out = s.f32((size_t)M * C);
+    if (s.ar->base) {
+        float* t = s.f32((size_t)M * C);
+        DIMX_TRY(lin_fwd(s, e.pin, x_in, Cin, M, t, C));
+        DIMX_TRY(tr_add_rows(t, C, nullptr, s.p(pre + "pos_emb.emb.weight"), 1.0f / sqrtf((float)C), s.T, e.h[0], C, M, C, s.st));
+    }
+    TrAttn sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.B = s.B; sh.H = d.heads; sh.Lq = s.T; sh.Lk = s.T;
+    sh.scale = 1.0f / sqrtf((float)d.dim_head);
+    sh.causal = 1;
+    sh.kmask = mask_bt;
+    for (int i = 0; i < d.enc_depth; ++i) {
+        DIMX_TRY(attn_fwd(s, e.attn[i], e.h[2 * i], e.h[2 * i + 1], M, C, nullptr, 0, 0, sh, mask_rows));
+        DIMX_TRY(ff_fwd(s, e.ff[i], e.h[2 * i + 1], e.h[2 * i + 2], M, C));
+    }
+    if (s.ar->base)
+        DIMX_TRY(launch_layernorm(DIMX_F32, e.h[2 * d.enc_depth], e.out, s.p(pre + "attn_layers.final_norm.weight"), nullptr, M, C, s.st));
+    return DIMX_OK;
+}
+
+// d_out: gradient wrt the encoder output [M, C]; dx_in (optional): gradient wrt its input [M, Cin]
+int enc_bwd(Step& s, EncSave& e, const float* d_out, float* dx_in) {
+    const dimx_dims& d = s.h->d;
+    const int M = s.M, C = d.dim;
+    const size_t mark = s.ar->off;
+    float* dh = s.f32((size_t)M * C);
+    DIMX_TRY(ln_bwd_full(s, e.h[2 * d.enc_depth], e.pre + "attn_layers.final_norm.weight", "", d_out, dh, M, C));
+    for (int i = d.enc_depth - 1; i >= 0; --i) {
+        DIMX_TRY(ff_bwd(s, e.ff[i], dh));
+        DIMX_TRY(attn_bwd(s, e.attn[i], dh, nullptr));
+    }
+    // h0 = project_in(x) + pos[:T] * C^-0.5.  Rows beyond T of the table get no gradient (the caller zeroed G).
+    DIMX_TRY(tr_pos_grad(dh, s.g(e.pre + "pos_emb.emb.weight"), s.B, s.T, C, 1.0f / sqrtf((float)C), s.st));
+    DIMX_TRY(lin_bwd(s, e.pin, e.x_in, e.Cin, dh, C, M, dx_in, e.Cin, false));
+    s.ar->off = mark;
+    return DIMX_OK;
+}
+
+}  // namespace
+}  // namespace dimx
+
+using namespace dimx;
+
+extern "C" {
+
+int dimx_train_num_params(dimx_handle h) {
+    int rc;
+    TrainPlan* p = plan_of(h, &rc);
+    return p ? (int)p->params.size() : rc;
+}
+
+int64_t dimx_train_total(dimx_handle h) {
+    int rc;
+    TrainPlan* p = plan_of(h, &rc);
+    return p ? (int64_t)p->total : (int64_t)rc;
+}
+
+int dimx_train_param_info(dimx_handle h, int i, const char** name, int64_t* offset, int64_t* numel) {
+    int rc;
+    TrainPlan* p = plan_of(h, &rc);
+    if (!p) return rc;
+    DIMX_REQUIRE(i >= 0 && i < (int)p->params.size() && name && offset && numel, DIMX_ERR_ARG, "train_param_info: bad index");
+    *name = p->params[i].name.c_str();
+    *offset = p->params[i].off;
+    *numel = p->params[i].numel;
+    return DIMX_OK;
+}
+
+static int train_run(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_audio, const uint8_t* mask,
+                     const int32_t* z_l, const uint8_t* kv_mask, int B, int T, float* loss_out, float* logits_out, void* ws,
+                     size_t ws_bytes, hipStream_t st, size_t* need) {
+    int rc;
+    TrainPlan* plan = plan_of(h, &rc);
+    if (!plan) return rc;
+    const dimx_dims& d = h->d;
+    DIMX_REQUIRE(h->variant == 0, DIMX_ERR_ARG, "train: only the SLMFT variant is trained");
+    DIMX_REQUIRE(B >= 1 && T >= 2 && T <= d.max_seq_len, DIMX_ERR_ARG, "train: B=%d T=%d out of range", B, T);
+    Arena ar(ws, ws_bytes);
+    Step s;
+    s.h = h;
+    s.plan = plan;
+    s.P = params;
+    s.G = grads;
+    s.ar = &ar;
+    s.st = st;
+    s.at = h->at;
+    s.bk = h->at == DIMX_BF16 ? 64 : 32;
+    s.B = B;
+    s.T = T;
+    s.M = B * T;
+    s.n = T - 1;
+    s.Md = B * (T - 1);
+    const int DD = d.dim + d.dim_a, F = DD * d.ff_mult, inner = d.heads * d.dim_head;
+    s.part = s.f32((size_t)2 * kTrSlabs * F);
+    const bool live = ws != nullptr;
+    if (live) DIMX_HIP(hipMemsetAsync(grads, 0, (size_t)plan->total * sizeof(float), st));
+
+    // ---------------- encoders: x0 = v_speaker + patch_embed_s -> encoder_s -> encoder_joint -> norm_s
+    float* x0 = s.f32((size_t)s.M * d.dim_in);
+    if (live) DIMX_TRY(tr_add_rows(v_speaker, d.dim_in, s.p("patch_embed_s"), nullptr, 0.f, T, x0, d.dim_in, s.M, d.dim_in, st));
+    EncSave es, ej;
+    DIMX_TRY(enc_fwd(s, es, "encoder_s.", x0, d.dim_in, mask, mask));
+    DIMX_TRY(enc_fwd(s, ej, "encoder_joint.", es.out, d.dim, mask, mask));
+    float* x_s = s.f32((size_t)s.M * d.dim);
+    if (live) DIMX_TRY(launch_layernorm(DIMX_F32, ej.out, x_s, s.p("norm_s.weight"), s.p("norm_s.bias"), s.M, d.dim, st));
+    // context = cat(x_s + patch_embed_dec_s, audio)
+    float* ctx = s.f32((size_t)s.M * DD);
+    if (live) {
+        DIMX_TRY(tr_add_rows(x_s, d.dim, s.p("patch_embed_dec_s"), nullptr, 0.f, T, ctx, DD, s.M, d.dim, st));
+        DIMX_TRY(tr_copy_cols(v_audio, d.dim_a, ctx + d.dim, DD, s.M, d.dim_a, 0, st));
+    }
+
+    // ---------------- decoder, teacher-forced: inp = z[:, :-1] (ignored -> 0), target = z[:, 1:]
+    const std::string dn = "decoder_joint.net.";
+    int32_t* inp = (int32_t*)ar.take((size_t)s.Md * 4);
+    int32_t* tgt = (int32_t*)ar.take((size_t)s.Md * 4);
+    if (live) DIMX_TRY(launch_shift_tokens(z_l, inp, tgt, B, T, st));
+    std::vector<AttnSave> sa(d.dec_depth), ca(d.dec_depth);
+    std::vector<FFSave> ff(d.dec_depth);
+    for (int i = 0; i < d.dec_depth; ++i) {
+        DIMX_TRY(attn_prepare(s, sa[i], dn + "attn_layers.layers." + std::to_string(3 * i) + "."));
+        DIMX_TRY(attn_prepare(s, ca[i], dn + "attn_layers.layers." + std::to_string(3 * i + 1) + "."));
+        DIMX_TRY(ff_prepare(s, ff[i], dn + "attn_layers.layers." + std::to_string(3 * i + 2) + "."));
+    }
+    Lin lg = make_lin(s, dn + "to_logits.weight");
+    DIMX_TRY(prep_lin(s, lg));
+    std::vector<float*> hd(3 * d.dec_depth + 1);
+    for (auto& p : hd) p = s.f32((size_t)s.Md * DD);
+    if (live) DIMX_TRY(launch_gather_rows(DIMX_F32, s.p(dn + "token_emb.emb.weight"), DD, d.num_tokens, inp, hd[0], DD, s.Md, DD, st));
+    TrAttn self_sh, cross_sh;
+    memset(&self_sh, 0, sizeof(self_sh));
+    self_sh.B = B; self_sh.H = d.heads; self_sh.Lq = s.n; self_sh.Lk = s.n;
+    self_sh.scale = 1.0f / sqrtf((float)d.dim_head);
+    self_sh.causal = 1;
+    self_sh.kmask2 = kv_mask;
+    cross_sh = self_sh;
+    cross_sh.Lk = T;
+    cross_sh.causal = 0;
+    cross_sh.kmask = mask;
+    cross_sh.kmask2 = nullptr;
+    for (int i = 0; i < d.dec_depth; ++i) {
+        DIMX_TRY(attn_fwd(s, sa[i], hd[3 * i], hd[3 * i + 1], s.Md, DD, nullptr, 0, 0, self_sh, nullptr));
+        DIMX_TRY(attn_fwd(s, ca[i], hd[3 * i + 1], hd[3 * i + 2], s.Md, DD, ctx, s.M, DD, cross_sh, nullptr));
+        DIMX_TRY(ff_fwd(s, ff[i], hd[3 * i + 2], hd[3 * i + 3], s.Md, DD));
+    }
+    float* yf = s.f32((size_t)s.Md * DD);
+    float* logits = logits_out ? logits_out : s.f32((size_t)s.Md * d.num_tokens);
+    float* dlogits = s.f32((size_t)s.Md * d.num_tokens);
+    float* row_loss = s.f32((size_t)s.Md);
+    if (live) {
+        DIMX_TRY(launch_layernorm(DIMX_F32, hd[3 * d.dec_depth], yf, s.p(dn + "attn_layers.final_norm.weight"), nullptr, s.Md, DD, st));
+        DIMX_TRY(lin_fwd(s, lg, yf, DD, s.Md, logits, d.num_tokens));
+        DIMX_REQUIRE(d.num_tokens == 512, DIMX_ERR_ARG, "train: the cross-entropy kernel is written for 512 codes");
+        DIMX_TRY(tr_cross_entropy(logits, tgt, row_loss, dlogits, s.Md, loss_out, st));
+    }
+
+    // ---------------- backward
+    float* dyf = s.f32((size_t)s.Md * DD);
+    float* dh = s.f32((size_t)s.Md * DD);
+    float* dctx = s.f32((size_t)s.M * DD);
+    float* dx_s = s.f32((size_t)s.M * d.dim);
+    float* d_ej = s.f32((size_t)s.M * d.dim);
+    float* d_es = s.f32((size_t)s.M * d.dim);
+    float* d_x0 = s.f32((size_t)s.M * d.dim_in);
+    if (live) {
+        DIMX_HIP(hipMemsetAsync(dctx, 0, (size_t)s.M * DD * sizeof(float), st));
+        DIMX_TRY(lin_bwd(s, lg, yf, DD, dlogits, d.num_tokens, s.Md, dyf, DD, false));
+        DIMX_TRY(ln_bwd_full(s, hd[3 * d.dec_depth], dn + "attn_layers.final_norm.weight", "", dyf, dh, s.Md, DD));
+        for (int i = d.dec_depth - 1; i >= 0; --i) {
+            DIMX_TRY(ff_bwd(s, ff[i], dh));
+            DIMX_TRY(attn_bwd(s, ca[i], dh, dctx));
+            DIMX_TRY(attn_bwd(s, sa[i], dh, nullptr));
+        }
+        DIMX_TRY(tr_embedding_bwd(inp, dh, s.g(dn + "token_emb.emb.weight"), s.Md, DD, d.num_tokens, st));
+        // context -> x_s (+ patch_embed_dec_s) ; the audio half has no parameters behind it
+        DIMX_TRY(tr_copy_cols(dctx, DD, dx_s, d.dim, s.M, d.dim, 0, st));
+        DIMX_TRY(tr_colsums(nullptr, dx_s, nullptr, s.g("patch_embed_dec_s"), s.M, d.dim, s.part, 0, st));
+        DIMX_TRY(ln_bwd_full(s, ej.out, "norm_s.weight", "norm_s.bias", dx_s, d_ej, s.M, d.dim));
+        DIMX_TRY(enc_bwd(s, ej, d_ej, d_es));
+        DIMX_TRY(enc_bwd(s, es, d_es, d_x0));
+        DIMX_TRY(tr_colsums(nullptr, d_x0, nullptr, s.g("patch_embed_s"), s.M, d.dim_in, s.part, 0, st));
+    }
+    (void)inner;
+    if (need) *need = ar.off + 256;
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "train: workspace %zu < required %zu", ws_bytes, ar.off);
+    return DIMX_OK;
+}
+
+size_t dimx_train_workspace_bytes(dimx_handle h, int B, int T) {
+    if (!h || B < 1 || T < 2) return 0;
+    size_t need = 0;
+    if (train_run(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, T, nullptr, nullptr, nullptr, 0, nullptr, &need) != DIMX_OK)
+        return 0;
+    return need;
+}
+
+int dimx_train_forward_backward(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_audio,
+                                const uint8_t* mask, const int32_t* z_l, const uint8_t* kv_mask, int B, int T, float* loss_out,
+                                float* logits_out, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(h && params && grads && v_speaker && v_audio && mask && z_l && loss_out && ws, DIMX_ERR_ARG, "train: null argument");
+    DIMX_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0, DIMX_ERR_ARG,
+                 "train: workspace must be 256-byte aligned, arenas 16-byte aligned");
+    DIMX_HIP(hipSetDevice(h->device));
+    return train_run(h, params, grads, v_speaker, v_audio, mask, z_l, kv_mask, B, T, loss_out, logits_out, ws, ws_bytes, (hipStream_t)stream,
+                     nullptr);
+}
+
+int dimx_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float max_norm, float* scratch, void* stream) {
+    DIMX_REQUIRE(params && grads && exp_avg && exp_avg_sq && scratch && n > 0 && step >= 1, DIMX_ERR_ARG, "train_adamw: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    DIMX_TRY(tr_grad_norm(grads, (long)n, max_norm, scratch, scratch + 1024, st));
+    return tr_adamw(params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, step, scratch + 1024, st);
+}
+
+}  // extern "C"

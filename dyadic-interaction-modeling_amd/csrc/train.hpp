@@ -1,0 +1,39 @@
+// train.hpp -- launchers of csrc/train_kernels.hip (the non-GEMM operators of the training step)
+#pragma once
+#include "common.hpp"
+
+namespace dimx {
+
+constexpr int kTrSlabs = 32;  // row slabs of the deterministic column reductions
+
+struct TrAttn {
+    int B, H, Lq, Lk;
+    int ldq, ldk, ldv, ldo;  // row strides of the [B, L, *] f32 operands; head h at column h * 64 (dim_head 64)
+    float scale;
+    int causal;
+    const uint8_t* kmask;    // [B, Lk] keep-mask (padding), optional
+    const uint8_t* kmask2;   // [B, Lk] second keep-mask (the mask_prob draw), optional
+};
+
+int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s);
+int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
+int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, hipStream_t s);
+int tr_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, int accumulate, int M, int C, hipStream_t s);
+int tr_xhat(const float* x, float* xh, int M, int C, hipStream_t s);
+int tr_colsums(const float* xh, const float* dy, float* dg, float* db, int M, int C, float* part, int accumulate, hipStream_t s);
+int tr_gelu_fwd(const float* pre, float* out, long n, hipStream_t s);
+int tr_gelu_bwd(const float* pre, const float* dh, float* dpre, long n, hipStream_t s);
+int tr_add(float* y, const float* a, long n, hipStream_t s);
+int tr_add_rows(const float* a, int lda, const float* row, const float* table, float scale, int T, float* y, int ldy, int M, int C,
+                hipStream_t s);
+int tr_zero_rows(float* y, const uint8_t* keep, int M, int C, hipStream_t s);
+int tr_copy_cols(const float* src, int lds_, float* dst, int ldd, int M, int C, int accumulate, hipStream_t s);
+int tr_pos_grad(const float* dx, float* dtable, int B, int T, int C, float scale, hipStream_t s);
+int tr_cross_entropy(const float* logits, const int32_t* target, float* row_loss, float* dlogits, int R, float* loss_out, hipStream_t s);
+int tr_embedding_bwd(const int32_t* tokens, const float* dx, float* dtable, int M, int C, int rows, hipStream_t s);
+int tr_grad_norm(const float* g, long n, float max_norm, float* part, float* norm_out, hipStream_t s);
+int tr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+             const float* clip, hipStream_t s);
+
+}  // namespace dimx

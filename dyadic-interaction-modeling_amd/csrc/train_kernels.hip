@@ -1,0 +1,633 @@
+// train_kernels.hip -- device kernels of the training step: everything of the backward pass that is not a
+// GEMM, plus the attention forward of the training path (which keeps the row log-sum-exp the backward needs).
+//
+// Reference: the reference trains with PyTorch autograd (code/x_engine_pt.py:9-60, code/finetune_s2s_pretrain.py:105-143);
+// what is differentiated is the teacher-forced x-transformers stack of SLMFT.forward(mode='train')
+// (code/seq2seq_pretrain.py:431-450, 496-514).  The operators below are the hand-derived adjoints of that stack:
+//   * attention (Attention + Attend of x-transformers 1.30.16: scale 64^-0.5, masked scores filled with -FLT_MAX, softmax in
+//     f32): forward with saved LSE, dQ and dK/dV with the probabilities recomputed from the LSE (no T x T tensor is kept);
+//   * LayerNorm (eps 1e-5, optional bias) backward: dx per row, d gamma / d beta as column sums;
+//   * exact (erf) GELU forward / backward; cross entropy (ignore_index -100, mean over valid targets) forward / backward;
+//   * embedding-table, bias, positional-table and patch-embedding gradients as deterministic reductions (no float atomics:
+//     two runs give bit-identical gradients);
+//   * transposes with zero padding, which turn dX = dY . W and dW = dY^T . X into the library's one GEMM form
+//     C = A[M,K] . W[N,K]^T (csrc/gemm.hip, gemm256.hip: f32-exact MFMA in the parity mode, bf16 MFMA in the perf mode);
+//   * global gradient norm + fused AdamW (torch.optim.AdamW semantics: decoupled weight decay, bias correction, eps outside
+//     the square root), with the clip factor of torch.nn.utils.clip_grad_norm_ folded in.
+// All kernels are plain f32 VALU work with LDS tiles: the training step's flops are in the GEMMs.
+#include "common.hpp"
+#include "train.hpp"
+
+namespace dimx {
+namespace {
+
+constexpr float kNegMax = -3.4028234663852886e38f;  // -torch.finfo(float32).max: x-transformers' mask fill value
+
+// ------------------------------------------------------------------------------------------------ transposes / casts
+// out[c][r] = in[r][c] for r < R, c < C; columns R..ld_out-1 of every output row are zero (the GEMM's K padding)
+template <typename OutT>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ in, int ld_in, OutT* __restrict__ out, int ld_out,
+                                                            int R, int C) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < C && r < ld_out) store_from_f32<OutT>(out + (size_t)c * ld_out + r, tile[tx][ty + 8 * i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// One wave per (clip, head, query row).  Keys are dealt to the lanes (j = lane, lane + 64, ...); q, the output row and
+// the gradient rows live in registers, K / V rows stream from L2 (a head's K and V are 2 x Lk x 256 B).
+struct AttnShape {
+    int B, H, Lq, Lk;       // D = 64
+    int ldq, ldk, ldv, ldo; // row strides (elements) of the [B, L, *] operands; head h at column h * 64
+    float scale;
+    int causal;
+    const uint8_t* kmask;   // [B, Lk] 1 = keep (padding mask), optional
+    const uint8_t* kmask2;  // [B, Lk] second keep-mask (AutoregressiveWrapper's mask_prob draw), optional
+};
+
+__device__ __forceinline__ bool key_kept(const AttnShape& a, int b, int i, int j) {
+    if (a.causal && j > i) return false;
+    if (a.kmask && !a.kmask[(size_t)b * a.Lk + j]) return false;
+    if (a.kmask2 && !a.kmask2[(size_t)b * a.Lk + j]) return false;
+    return true;
+}
+
+__device__ __forceinline__ float dot64(const float (&q)[64], const float* __restrict__ row) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+        const float4 k4 = *(const float4*)(row + d);
+        s = fmaf(q[d], k4.x, s);
+        s = fmaf(q[d + 1], k4.y, s);
+        s = fmaf(q[d + 2], k4.z, s);
+        s = fmaf(q[d + 3], k4.w, s);
+    }
+    return s;
+}
+
+// sum over the 64 lanes of a 64-vector held as acc[64] per lane -> lane d gets element d (through a 16 KiB LDS tile)
+__device__ __forceinline__ float lanes_reduce64(const float (&acc)[64], float* sm, int lane) {
+#pragma unroll
+    for (int d = 0; d < 64; ++d) sm[lane * 65 + d] = acc[d];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float s = 0.f;
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) s += sm[l * 65 + lane];
+    __builtin_amdgcn_wave_barrier();
+    return s;
+}
+
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnShape a, const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, float* __restrict__ o, float* __restrict__ lse) {
+    __shared__ float sm[64 * 65];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    float qr[64];
+    {
+        const float* qp = q + ((size_t)b * a.Lq + i) * a.ldq + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const float4 t = *(const float4*)(qp + d);
+            qr[d] = t.x; qr[d + 1] = t.y; qr[d + 2] = t.z; qr[d + 3] = t.w;
+        }
+    }
+    const float* kb = k + (size_t)b * a.Lk * a.ldk + h * 64;
+    const float* vb = v + (size_t)b * a.Lk * a.ldv + h * 64;
+    // pass 1: row maximum (masked scores count as -FLT_MAX, like masked_fill before the softmax)
+    float mx = kNegMax;
+    for (int j = lane; j < a.Lk; j += 64) {
+        const float s = key_kept(a, b, i, j) ? dot64(qr, kb + (size_t)j * a.ldk) * a.scale : kNegMax;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    // pass 2: probabilities and the output row
+    float acc[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+    float se = 0.f;
+    for (int j = lane; j < a.Lk; j += 64) {
+        const float s = key_kept(a, b, i, j) ? dot64(qr, kb + (size_t)j * a.ldk) * a.scale : kNegMax;
+        const float p = expf(s - mx);
+        se += p;
+        const float* vr = vb + (size_t)j * a.ldv;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const float4 t = *(const float4*)(vr + d);
+            acc[d] = fmaf(p, t.x, acc[d]);
+            acc[d + 1] = fmaf(p, t.y, acc[d + 1]);
+            acc[d + 2] = fmaf(p, t.z, acc[d + 2]);
+            acc[d + 3] = fmaf(p, t.w, acc[d + 3]);
+        }
+    }
+    se = wave_sum(se);
+    const float od = lanes_reduce64(acc, sm, lane) / se;
+    o[((size_t)b * a.Lq + i) * a.ldo + h * 64 + lane] = od;
+    if (lane == 0) lse[((size_t)b * a.H + h) * a.Lq + i] = mx + logf(se);
+}
+
+// dQ row + delta_i = dO_i . O_i (kept for the dK / dV kernel)
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnShape a, const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ o,
+                                                         const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                         float* __restrict__ dq, int lddq, float* __restrict__ delta) {
+    __shared__ float sm[64 * 65];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    float qr[64], gr[64];
+    float dl = 0.f;
+    {
+        const size_t ro = ((size_t)b * a.Lq + i);
+        const float* qp = q + ro * a.ldq + h * 64;
+        const float* gp = d_o + ro * a.ldo + h * 64;
+        const float* op = o + ro * a.ldo + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const float4 t = *(const float4*)(qp + d);
+            const float4 g = *(const float4*)(gp + d);
+            const float4 w = *(const float4*)(op + d);
+            qr[d] = t.x; qr[d + 1] = t.y; qr[d + 2] = t.z; qr[d + 3] = t.w;
+            gr[d] = g.x; gr[d + 1] = g.y; gr[d + 2] = g.z; gr[d + 3] = g.w;
+            dl += g.x * w.x + g.y * w.y + g.z * w.z + g.w * w.w;
+        }
+    }
+    const float L = lse[((size_t)b * a.H + h) * a.Lq + i];
+    const float* kb = k + (size_t)b * a.Lk * a.ldk + h * 64;
+    const float* vb = v + (size_t)b * a.Lk * a.ldv + h * 64;
+    float acc[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+    for (int j = lane; j < a.Lk; j += 64) {
+        const float* kr = kb + (size_t)j * a.ldk;
+        const float s = key_kept(a, b, i, j) ? dot64(qr, kr) * a.scale : kNegMax;
+        const float p = expf(s - L);
+        const float dp = dot64(gr, vb + (size_t)j * a.ldv);
+        const float ds = p * (dp - dl) * a.scale;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const float4 t = *(const float4*)(kr + d);
+            acc[d] = fmaf(ds, t.x, acc[d]);
+            acc[d + 1] = fmaf(ds, t.y, acc[d + 1]);
+            acc[d + 2] = fmaf(ds, t.z, acc[d + 2]);
+            acc[d + 3] = fmaf(ds, t.w, acc[d + 3]);
+        }
+    }
+    dq[((size_t)b * a.Lq + i) * lddq + h * 64 + lane] = lanes_reduce64(acc, sm, lane);
+    if (lane == 0) delta[((size_t)b * a.H + h) * a.Lq + i] = dl;
+}
+
+// dK and dV row of key j: the queries are dealt to the lanes
+__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnShape a, const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const float* __restrict__ d_o,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+    __shared__ float sm[64 * 65];
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    float kr[64], vr[64];
+    {
+        const float* kp = k + ((size_t)b * a.Lk + j) * a.ldk + h * 64;
+        const float* vp = v + ((size_t)b * a.Lk + j) * a.ldv + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const float4 t = *(const float4*)(kp + d);
+            const float4 w = *(const float4*)(vp + d);
+            kr[d] = t.x; kr[d + 1] = t.y; kr[d + 2] = t.z; kr[d + 3] = t.w;
+            vr[d] = w.x; vr[d + 1] = w.y; vr[d + 2] = w.z; vr[d + 3] = w.w;
+        }
+    }
+    float ak[64], av[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) ak[d] = av[d] = 0.f;
+    const float* lp = lse + ((size_t)b * a.H + h) * a.Lq;
+    const float* dp_ = delta + ((size_t)b * a.H + h) * a.Lq;
+    for (int i = lane; i < a.Lq; i += 64) {
+        const float* qp = q + ((size_t)b * a.Lq + i) * a.ldq + h * 64;
+        const float* gp = d_o + ((size_t)b * a.Lq + i) * a.ldo + h * 64;
+        const float s = key_kept(a, b, i, j) ? dot64(kr, qp) * a.scale : kNegMax;
+        const float p = expf(s - lp[i]);
+        const float dpv = dot64(vr, gp);
+        const float ds = p * (dpv - dp_[i]) * a.scale;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const float4 t = *(const float4*)(qp + d);
+            const float4 g = *(const float4*)(gp + d);
+            ak[d] = fmaf(ds, t.x, ak[d]);
+            ak[d + 1] = fmaf(ds, t.y, ak[d + 1]);
+            ak[d + 2] = fmaf(ds, t.z, ak[d + 2]);
+            ak[d + 3] = fmaf(ds, t.w, ak[d + 3]);
+            av[d] = fmaf(p, g.x, av[d]);
+            av[d + 1] = fmaf(p, g.y, av[d + 1]);
+            av[d + 2] = fmaf(p, g.z, av[d + 2]);
+            av[d + 3] = fmaf(p, g.w, av[d + 3]);
+        }
+    }
+    const float rk = lanes_reduce64(ak, sm, lane);
+    const float rv = lanes_reduce64(av, sm, lane);
+    dk[((size_t)b * a.Lk + j) * lddk + h * 64 + lane] = rk;
+    dv[((size_t)b * a.Lk + j) * lddv + h * 64 + lane] = rv;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// dx[row] (+)= gamma o dy . rstd - xhat . mean(gamma o dy o xhat) . rstd - mean(gamma o dy) . rstd; one wave per row.
+// xhat is recomputed from x (two exact passes, eps 1e-5).  ACCUM: add into dx (the residual stream's gradient).
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, float* __restrict__ dx, int M, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * C;
+    const float* gy = dy + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mean;
+        v += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(v) / C + 1e-5f);
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float g = gamma[c] * gy[c];
+        a1 += g;
+        a2 += g * (xr[c] - mean) * rstd;
+    }
+    a1 = wave_sum(a1) / C;
+    a2 = wave_sum(a2) / C;
+    float* dr = dx + (size_t)row * C;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd;
+        const float t = (gamma[c] * gy[c] - a1 - xh * a2) * rstd;
+        dr[c] = ACCUM ? dr[c] + t : t;
+    }
+}
+
+// column sums over rows of dy (d beta, bias gradients) and of dy o xhat (d gamma): block = 64 columns x 4 row lanes, rows are
+// split over gridDim.y slabs; a second pass (colsum_finish) adds the slabs in a fixed order
+__global__ __launch_bounds__(256) void ln_colsums_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part_g,
+                                                         float* __restrict__ part_b, int M, int C, int rows_per_slab) {
+    __shared__ float sm[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r_begin = blockIdx.y * rows_per_slab;
+    const int r_end = min(M, r_begin + rows_per_slab);
+    float sg = 0.f, sb = 0.f;
+    if (c < C) {
+        for (int r = r_begin + rl; r < r_end; r += 4) {
+            // row statistics recomputed per (row, column lane) would be M x C x C work: they come precomputed in x as xhat
+            const float g = dy[(size_t)r * C + c];
+            sb += g;
+            if (x) sg += g * x[(size_t)r * C + c];
+        }
+    }
+    sm[0][rl][threadIdx.x & 63] = sg;
+    sm[1][rl][threadIdx.x & 63] = sb;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        if (part_g) part_g[(size_t)blockIdx.y * C + c] = (sm[0][0][l] + sm[0][1][l]) + (sm[0][2][l] + sm[0][3][l]);
+        if (part_b) part_b[(size_t)blockIdx.y * C + c] = (sm[1][0][l] + sm[1][1][l]) + (sm[1][2][l] + sm[1][3][l]);
+    }
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nslab, float scale, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < nslab; ++i) s += part[(size_t)i * C + c];
+    out[c] = accumulate ? out[c] + s * scale : s * scale;
+}
+
+// xhat[row] = (x - mean) * rstd (needed once per LayerNorm for d gamma)
+__global__ __launch_bounds__(256) void xhat_kernel(const float* __restrict__ x, float* __restrict__ xh, int M, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mean;
+        v += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(v) / C + 1e-5f);
+    for (int c = lane; c < C; c += 64) xh[(size_t)row * C + c] = (xr[c] - mean) * rstd;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+__global__ void gelu_erf_fwd_kernel(const float* __restrict__ pre, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float x = pre[i];
+        out[i] = 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+    }
+}
+// dpre = dh * (Phi(x) + x phi(x))
+__global__ void gelu_erf_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dh, float* __restrict__ dpre, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float x = pre[i];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.7071067811865476f));
+        const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+        dpre[i] = dh[i] * (cdf + x * pdf);
+    }
+}
+__global__ void add_kernel(float* __restrict__ y, const float* __restrict__ a, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a[i];
+}
+// y[m, c] = a[m, c] + row[c] (+ table[m % T, c] * scale): patch-embedding add / positional rows
+__global__ void add_rows_kernel(const float* __restrict__ a, int lda, const float* __restrict__ row, const float* __restrict__ table,
+                                float scale, int T, float* __restrict__ y, int ldy, int M, int C) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C), c = (int)(i - (long)m * C);
+        float v = a[(size_t)m * lda + c];
+        if (row) v += row[c];
+        if (table) v += table[(size_t)(m % T) * C + c] * scale;
+        y[(size_t)m * ldy + c] = v;
+    }
+}
+// rows whose mask byte is 0 are zeroed (x-transformers zero-fills the attention output of padded queries)
+__global__ void zero_rows_kernel(float* __restrict__ y, const uint8_t* __restrict__ keep, int M, int C) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C);
+        if (!keep[m]) y[i] = 0.f;
+    }
+}
+// dst[m, 0:C) (+)= src[m, 0:C) with different row strides (context slice / concat)
+__global__ void copy_cols_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int M, int C, int accumulate) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C), c = (int)(i - (long)m * C);
+        const float v = src[(size_t)m * lds_ + c];
+        float* d = dst + (size_t)m * ldd + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+// table[t, c] gradient of "x[b, t] += table[t] * scale": sum over clips, deterministic
+__global__ void pos_grad_kernel(const float* __restrict__ dx, float* __restrict__ dtable, int B, int T, int C, float scale) {
+    const long total = (long)T * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dx[(size_t)b * T * C + i];
+        dtable[i] = s * scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cross entropy
+// one wave per row of 512 logits: loss row (0 where the target is ignored) and d logits = (softmax - onehot) * gscale
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int32_t* __restrict__ target,
+                                                         float* __restrict__ row_loss, float* __restrict__ dlogits, int R,
+                                                         const float* __restrict__ inv_count) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* lr = logits + (size_t)row * 512;
+    float v[8];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        v[c] = lr[lane + 64 * c];
+        mx = fmaxf(mx, v[c]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) se += expf(v[c] - mx);
+    se = wave_sum(se);
+    const int t = target[row];
+    const bool valid = t >= 0 && t < 512;
+    const float g = valid ? *inv_count : 0.f;
+    if (lane == 0) row_loss[row] = valid ? (mx + logf(se)) - lr[t] : 0.f;
+    const float inv = 1.0f / se;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = lane + 64 * c;
+        dlogits[(size_t)row * 512 + col] = g * (expf(v[c] - mx) * inv - (col == t ? 1.0f : 0.f));
+    }
+}
+// out[0] = sum(row_loss) / count, out[1] = 1 / count (count = valid targets, clamped to 1); one block
+__global__ __launch_bounds__(256) void ce_count_kernel(const int32_t* __restrict__ target, int R, float* __restrict__ out) {
+    __shared__ int sm[256];
+    int n = 0;
+    for (int i = threadIdx.x; i < R; i += 256) n += (target[i] >= 0 && target[i] < 512) ? 1 : 0;
+    sm[threadIdx.x] = n;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[1] = 1.0f / (float)(sm[0] > 0 ? sm[0] : 1);
+}
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, int n, const float* __restrict__ scale, float* __restrict__ out) {
+    __shared__ float sm[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0] * scale[0];
+}
+
+// d table[v, :] = sum over rows m with token[m] == v of dx[m, :]: one block per vocabulary row, rows scanned in order
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ dx,
+                                                            float* __restrict__ dtable, int M, int C) {
+    const int vrow = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m)
+            if (tokens[m] == vrow) s += dx[(size_t)m * C + c];
+        dtable[(size_t)vrow * C + c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+// partial sums of squares over the flat gradient arena (fixed block partition -> deterministic), then the norm
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+    __shared__ float sm[256];
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = min(n, lo + per);
+    float s = 0.f;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) s += g[i] * g[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+// out[0] = ||g||, out[1] = clip coefficient min(1, max_norm / (||g|| + 1e-6)) (1 when max_norm <= 0)
+__global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restrict__ part, int nblocks, float max_norm, float* __restrict__ out) {
+    __shared__ float sm[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += part[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(sm[0]);
+        out[0] = nrm;
+        out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (nrm + 1e-6f)) : 1.0f;
+    }
+}
+// torch.optim.AdamW: p *= 1 - lr wd; m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ clip) {
+    const float cf = clip ? clip[1] : 1.0f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * cf;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] = pi;
+    }
+}
+
+inline int ew_grid(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ launchers
+int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s) {
+    DIMX_REQUIRE(in && out && R > 0 && C > 0 && ld_out >= R, DIMX_ERR_ARG, "transpose_pad: bad arguments");
+    dim3 grid(ceil_div(C, 32), ceil_div(ld_out, 32));
+    if (out_dtype == DIMX_BF16) hipLaunchKernelGGL(transpose_pad_kernel<bf16>, grid, dim3(256), 0, s, in, ld_in, (bf16*)out, ld_out, R, C);
+    else hipLaunchKernelGGL(transpose_pad_kernel<float>, grid, dim3(256), 0, s, in, ld_in, (float*)out, ld_out, R, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+static AttnShape make_shape(const TrAttn& t) {
+    AttnShape a;
+    a.B = t.B; a.H = t.H; a.Lq = t.Lq; a.Lk = t.Lk;
+    a.ldq = t.ldq; a.ldk = t.ldk; a.ldv = t.ldv; a.ldo = t.ldo;
+    a.scale = t.scale;
+    a.causal = t.causal;
+    a.kmask = t.kmask;
+    a.kmask2 = t.kmask2;
+    return a;
+}
+int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s) {
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(t.Lq, t.H, t.B), dim3(64), 0, s, make_shape(t), q, k, v, o, lse);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, hipStream_t s) {
+    const AttnShape a = make_shape(t);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(t.Lq, t.H, t.B), dim3(64), 0, s, a, q, k, v, o, d_o, lse, dq, lddq, delta);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(t.Lk, t.H, t.B), dim3(64), 0, s, a, q, k, v, d_o, lse, delta, dk, lddk, dv, lddv);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, int accumulate, int M, int C, hipStream_t s) {
+    if (accumulate) hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(ceil_div(M, 4)), dim3(256), 0, s, x, gamma, dy, dx, M, C);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(ceil_div(M, 4)), dim3(256), 0, s, x, gamma, dy, dx, M, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_xhat(const float* x, float* xh, int M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(xhat_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, x, xh, M, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+// dg[c] (+)= sum_m dy[m,c] * xh[m,c] (xh may be null), db[c] (+)= sum_m dy[m,c]; part: >= 2 * kTrSlabs * C floats of scratch
+int tr_colsums(const float* xh, const float* dy, float* dg, float* db, int M, int C, float* part, int accumulate, hipStream_t s) {
+    const int slabs = M < kTrSlabs * 8 ? 1 : kTrSlabs;
+    const int rows = ceil_div(M, slabs);
+    float* pg = dg ? part : nullptr;
+    float* pb = db ? part + (size_t)kTrSlabs * C : nullptr;
+    hipLaunchKernelGGL(ln_colsums_kernel, dim3(ceil_div(C, 64), slabs), dim3(256), 0, s, xh, dy, pg, pb, M, C, rows);
+    if (dg) hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, pg, dg, C, slabs, 1.0f, accumulate);
+    if (db) hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, pb, db, C, slabs, 1.0f, accumulate);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_gelu_fwd(const float* pre, float* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(gelu_erf_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, s, pre, out, n);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_gelu_bwd(const float* pre, const float* dh, float* dpre, long n, hipStream_t s) {
+    hipLaunchKernelGGL(gelu_erf_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, s, pre, dh, dpre, n);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_add(float* y, const float* a, long n, hipStream_t s) {
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, s, y, a, n);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_add_rows(const float* a, int lda, const float* row, const float* table, float scale, int T, float* y, int ldy, int M, int C,
+                hipStream_t s) {
+    hipLaunchKernelGGL(add_rows_kernel, dim3(ew_grid((long)M * C)), dim3(256), 0, s, a, lda, row, table, scale, T, y, ldy, M, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_zero_rows(float* y, const uint8_t* keep, int M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(ew_grid((long)M * C)), dim3(256), 0, s, y, keep, M, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_copy_cols(const float* src, int lds_, float* dst, int ldd, int M, int C, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(ew_grid((long)M * C)), dim3(256), 0, s, src, lds_, dst, ldd, M, C, accumulate);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_pos_grad(const float* dx, float* dtable, int B, int T, int C, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(pos_grad_kernel, dim3(ew_grid((long)T * C)), dim3(256), 0, s, dx, dtable, B, T, C, scale);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+// loss_out[0] = mean CE over valid targets, loss_out[1] = 1 / count; dlogits = d loss / d logits
+int tr_cross_entropy(const float* logits, const int32_t* target, float* row_loss, float* dlogits, int R, float* loss_out, hipStream_t s) {
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, s, target, R, loss_out);
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, logits, target, row_loss, dlogits, R, loss_out + 1);
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, s, row_loss, R, loss_out + 1, loss_out);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_embedding_bwd(const int32_t* tokens, const float* dx, float* dtable, int M, int C, int rows, hipStream_t s) {
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(rows), dim3(256), 0, s, tokens, dx, dtable, M, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+// norm_out[0] = ||g||_2, norm_out[1] = clip coefficient; part: >= 1024 floats
+int tr_grad_norm(const float* g, long n, float max_norm, float* part, float* norm_out, hipStream_t s) {
+    const int nb = 1024;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, part);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, s, part, nb, max_norm, norm_out);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+             const float* clip, hipStream_t s) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), clip);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+}  // namespace dimx

@@ -369,9 +369,11 @@ def op_chain(x, gamma, a1=None, w1=None, slabs=None, w2=None):
     return y, out2
 
 
-def op_chain_ln(x, a1, w1, w2s=None, colsum2=None):
+def op_chain_ln(x, a1, w1, w2s=None, colsum2=None, return_flags=False):
     """Deferred-LayerNorm chain launch: x [B,C] f32 += a1 . w1^T in place; returns (y = bf16(x) [B,C], stats [8,32,32,2],
-    out2 [B,N2] or None) with out2 = LayerNorm(x) * gamma . W2^T when w2s = gamma o W2 (bf16) and colsum2 = w2s row sums."""
+    out2 [B,N2] or None) with out2 = LayerNorm(x) * gamma . W2^T when w2s = gamma o W2 (bf16) and colsum2 = w2s row sums.
+    stats[g, c, r] = {sum, centred sum of squares} of CU c's column slice of row 32 g + r.  return_flags: also the kernel's
+    flag word (bit 2 = precision guard: some row's |mean| > 8 std)."""
     lib = L.load()
     dev = x.device
     B, C = x.shape
@@ -385,9 +387,9 @@ def op_chain_ln(x, a1, w1, w2s=None, colsum2=None):
                                  L.stream_ptr(dev)), "dimx_op_chain_ln")
     torch.cuda.synchronize(dev)
     flags = int(scratch[129].item())
-    if flags:
+    if flags & 3:
         raise L.DimxError("chain kernel error flags 0x%x (1 = (XCD, slot) claimed twice, 2 = group barrier timeout)" % flags)
-    return y, stats, out2
+    return (y, stats, out2, flags) if return_flags else (y, stats, out2)
 
 
 def op_gemm_ln(a, ws, stats, colsum, bias=None, act=0, out_bf16=False):

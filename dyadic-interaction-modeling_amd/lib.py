@@ -71,6 +71,14 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_uint64,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dimx_train_num_params": (c_int, [c_void_p]),
+    "dimx_train_total": (c_int64, [c_void_p]),
+    "dimx_train_param_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int64), POINTER(c_int64)]),
+    "dimx_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "dimx_train_forward_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                            c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dimx_train_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                 c_int, c_float, c_void_p, c_void_p]),
     "dimx_chain_faults": (c_int, [c_void_p]),
     "dimx_debug_chain_fault": (c_int, [c_void_p, c_int]),
     "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,

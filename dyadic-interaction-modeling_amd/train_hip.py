@@ -1,0 +1,141 @@
+"""Training step of the DIM-Listener fine-tuning model on hand-written HIP kernels.
+
+Reference: ``train_epoch`` (code/x_engine_pt.py:9-60) as driven by code/finetune_s2s_pretrain.py:105-143 -- AdamW
+(lr 1e-5), gradient clipping at 1.0, both VQ-VAEs frozen.  The reference differentiates ``SLMFT.forward(mode='train')``
+with autograd; here the forward AND the backward pass of the teacher-forced stack run in libdimx_hip.so
+(csrc/train.hip, csrc/train_kernels.hip): every Linear and both of its adjoints on the library's MFMA GEMM, attention /
+LayerNorm / GELU / cross-entropy adjoints as HIP kernels, fused clip + AdamW.  ``dimx.train`` (the PyTorch-autograd
+restatement of round 2) stays as the CHECKER of this path (tests/test_gpu_train_hip.py) and as the CPU fallback-free
+reference of the gradient math; it is no longer what ``x_engine_pt.train_epoch`` runs on a GPU.
+
+State: parameters, gradients and the two AdamW moments are four flat f32 device tensors laid out by the library
+(``dimx_train_param_info``); the module's ``nn.Parameter``s are written back by ``sync_to_model()`` (end of an epoch,
+before evaluation or ``state_dict()``).  Multi-GPU: one process per GPU, replicated weights, per-rank batch shard, and
+ONE all-reduce of the flat gradient tensor per step over RCCL (xGMI rings are per-link bound: one 0.4 GB collective
+instead of one per tensor)."""
+import ctypes
+
+import torch
+
+from . import dist as ddist
+from . import lib as L
+
+
+class HipTrainer:
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clip=1.0, device=None):
+        """AdamW defaults are torch.optim.AdamW's (the reference passes only lr, code/finetune_s2s_pretrain.py:119)."""
+        self.model = model
+        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        if self.device.type != "cuda":
+            raise L.DimxError("HipTrainer needs the module on a ROCm GPU (model.to('cuda:0')); there is no CPU path")
+        self.lr, self.betas, self.eps, self.weight_decay, self.clip = lr, betas, eps, weight_decay, clip
+        self.lib = L.load()
+        self.eng = model.engine(self.device)
+        h = self.eng.h
+        n = self.lib.dimx_train_num_params(h)
+        if n <= 0:
+            L.check(n, "dimx_train_num_params")
+        self.total = int(self.lib.dimx_train_total(h))
+        self.layout = []
+        for i in range(n):
+            name, off, numel = ctypes.c_char_p(), ctypes.c_int64(), ctypes.c_int64()
+            L.check(self.lib.dimx_train_param_info(h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(numel)), "train_param_info")
+            self.layout.append((name.value.decode(), int(off.value), int(numel.value)))
+        kw = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.total, **kw)
+        self.grads = torch.zeros(self.total, **kw)
+        self.exp_avg = torch.zeros(self.total, **kw)
+        self.exp_avg_sq = torch.zeros(self.total, **kw)
+        self._scratch = torch.zeros(1026, **kw)
+        self._loss = torch.zeros(2, **kw)
+        self._ws, self._ws_bytes = None, 0
+        self.step_count = 0
+        self.load_from_model()
+        if ddist.world_size() > 1:                      # every rank starts from rank 0's parameters
+            import torch.distributed as dist
+            dist.broadcast(self.params, 0)
+
+    # ------------------------------------------------------------------ arena <-> module
+    def _named(self):
+        return dict(self.model.named_parameters())
+
+    def load_from_model(self):
+        named = self._named()
+        with torch.no_grad():
+            for name, off, numel in self.layout:
+                self.params[off:off + numel].copy_(named[name].detach().reshape(-1).to(self.device, torch.float32))
+
+    def sync_to_model(self):
+        """write the trained parameters back into the nn.Module (its engine re-packs them before its next launch)."""
+        named = self._named()
+        with torch.no_grad():
+            for name, off, numel in self.layout:
+                p = named[name]
+                p.copy_(self.params[off:off + numel].view_as(p))
+
+    def view(self, arena, name):
+        for n, off, numel in self.layout:
+            if n == name:
+                return arena[off:off + numel].view(self._named()[name].shape)
+        raise KeyError(name)
+
+    def grad(self, name):
+        return self.view(self.grads, name)
+
+    # ------------------------------------------------------------------ one step
+    def _workspace(self, B, T):
+        need = int(self.lib.dimx_train_workspace_bytes(self.eng.h, B, T))
+        if need == 0:
+            raise L.DimxError("dimx_train_workspace_bytes(B=%d, T=%d) = 0: %s" % (B, T, (self.lib.dimx_last_error() or b"").decode()))
+        if need > self._ws_bytes:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        base = self._ws.data_ptr()
+        return ctypes.c_void_p((base + 255) // 256 * 256), self._ws.numel() - 256
+
+    def forward_backward(self, v_speaker, v_listener, v_audio, mask, kv_mask=None, z_l=None, return_logits=False):
+        """loss (0-dim device tensor, mean cross entropy over the valid listener codes) and the gradients in ``self.grads``.
+        kv_mask: keep-mask [B,T-1] of the mask_prob draw; None draws one like the reference, False disables it."""
+        mask = mask.bool()
+        B, T = mask.shape
+        if z_l is None:
+            with torch.no_grad():
+                _, z_l = self.model.forward_vq(v_speaker, v_listener, mask, with_speaker=False)
+        if kv_mask is None:
+            kv_mask = self.model.draw_kv_mask(B, T, self.device)
+        elif kv_mask is False:
+            kv_mask = None
+        v_s = v_speaker.to(self.device, torch.float32).contiguous()
+        v_a = v_audio.to(self.device, torch.float32).contiguous()
+        m8 = mask.to(self.device, torch.uint8).contiguous()
+        z32 = z_l.to(self.device, torch.int32).contiguous()
+        kv8 = kv_mask.to(self.device, torch.uint8).contiguous() if kv_mask is not None else None
+        logits = torch.empty(B, T - 1, 512, dtype=torch.float32, device=self.device) if return_logits else None
+        ws, wsb = self._workspace(B, T)
+        L.check(self.lib.dimx_train_forward_backward(self.eng.h, L.ptr(self.params), L.ptr(self.grads), L.ptr(v_s), L.ptr(v_a),
+                                                     L.ptr(m8), L.ptr(z32), L.ptr(kv8), B, T, L.ptr(self._loss), L.ptr(logits), ws,
+                                                     wsb, L.stream_ptr(self.device)), "dimx_train_forward_backward")
+        loss = self._loss[0].clone()
+        return (loss, logits) if return_logits else loss
+
+    def all_reduce_grads(self):
+        world = ddist.world_size()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads)
+            self.grads.div_(world)
+
+    def step(self):
+        """clip (torch.nn.utils.clip_grad_norm_ semantics) + AdamW; returns the gradient norm before clipping (device scalar)."""
+        self.step_count += 1
+        L.check(self.lib.dimx_train_adamw(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                          self.total, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                          float(self.weight_decay), self.step_count, float(self.clip or 0.0), L.ptr(self._scratch),
+                                          L.stream_ptr(self.device)), "dimx_train_adamw")
+        return self._scratch[1024]
+
+    def train_step(self, v_speaker, v_listener, v_audio, mask, kv_mask=None, z_l=None):
+        loss = self.forward_backward(v_speaker, v_listener, v_audio, mask, kv_mask=kv_mask, z_l=z_l)
+        self.all_reduce_grads()
+        self.step()
+        return loss

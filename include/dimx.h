@@ -199,11 +199,39 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
  * 256-CU device) that rely on their 256 blocks being co-resident, one per CU.  They verify that and dimx_generate checks
  * their flags BEFORE it returns: with the chain path active the call therefore waits for its own generation to finish
  * (everything else stays asynchronous); on a fault it regenerates the same batch on the one-kernel-per-op step, keeps the
- * chain path off for this handle and counts the event here (0 = never happened). */
+ * chain path off for this handle and counts the event here (0 = never happened).  The same check covers the deferred
+ * LayerNorm's precision guard (a residual row whose |mean| exceeds 8 standard deviations: the batch is regenerated with the
+ * row-phase LayerNorm, the deferred form stays off for the handle, the event is counted here too). */
 int dimx_chain_faults(dimx_handle h);
 /* Test hook: the next n_calls dimx_generate calls launch their chain kernels with a deliberately non-bijective
  * (XCD, CU slot) placement (the blocks of every odd XCD claim the slots of its even neighbour). */
 int dimx_debug_chain_fault(dimx_handle h, int n_calls);
+
+/* ---- training step: reference train_epoch, code/x_engine_pt.py:9-60 driven by
+ * code/finetune_s2s_pretrain.py:105-143 (AdamW lr 1e-5, clip 1.0, VQ-VAEs frozen) --------------------------------------------
+ * The reference differentiates SLMFT.forward(mode='train') with autograd; here forward AND backward of the teacher-forced stack
+ * (encoder_s -> encoder_joint -> norm_s -> context -> decoder -> cross entropy, code/seq2seq_pretrain.py:431-450,496-514) are
+ * hand-written HIP kernels (csrc/train.hip, train_kernels.hip; every Linear and both of its adjoints on the library's GEMM).
+ * Parameters, gradients and the AdamW moments are FLAT f32 device arenas owned by the caller, laid out as reported by
+ * dimx_train_param_info (the trainable tensors this path reaches; unused reference parameters -- encoder_l.*, norm_l.*,
+ * project_out, ... -- get no gradient from autograd either and are not in the arena).  The handle must have been given the
+ * full state dict (dimx_load_weights); its numeric mode selects the GEMM operands (f32-exact or bf16 with f32 accumulation). */
+int dimx_train_num_params(dimx_handle h);
+int64_t dimx_train_total(dimx_handle h);   /* floats in an arena (tensors are 16-byte aligned inside it) */
+int dimx_train_param_info(dimx_handle h, int i, const char** name, int64_t* offset, int64_t* numel);
+size_t dimx_train_workspace_bytes(dimx_handle h, int B, int T);
+/* One forward + backward pass.  params / grads: arenas (grads is overwritten); v_speaker [B,T,56], v_audio [B,T,768] f32;
+ * mask [B,T] uint8 (1 = valid frame); z_l [B,T] int32 listener codes, -100 on padding (from dimx_vq_encode); kv_mask [B,T-1]
+ * uint8 keep-mask of AutoregressiveWrapper's mask_prob draw (NULL = keep all).  loss_out: 2 device floats {mean cross
+ * entropy over the valid targets, 1 / number of valid targets}; logits_out optional [B,T-1,512] f32. */
+int dimx_train_forward_backward(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_audio,
+                                const uint8_t* mask, const int32_t* z_l, const uint8_t* kv_mask, int B, int T, float* loss_out,
+                                float* logits_out, void* ws, size_t ws_bytes, void* stream);
+/* Gradient clipping (torch.nn.utils.clip_grad_norm_, max_norm <= 0: none) + one torch.optim.AdamW step over a flat arena.
+ * step: 1-based step count (bias correction).  scratch: >= 1026 device floats; scratch[1024] = gradient norm before clipping,
+ * scratch[1025] = the clip coefficient applied. */
+int dimx_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float max_norm, float* scratch, void* stream);
 
 /* ---- kernel-level entry points (unit parity tests) -------------------------------------- */
 
@@ -253,12 +281,13 @@ int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int
  *   [W2 != NULL]  out2[B,N2] = y . W2[N2,C]^T   (f32).
  * A1 / W1 / W2 / y are bf16, x / slabs / gamma / out2 f32.  scratch: >= 2048 + B*C*4 bytes of device memory; on return
  * (after the stream has drained) ((uint32_t*)scratch)[129] holds the kernel's error flags (0 = ok, bit 0 = two blocks
- * claimed the same (XCD, CU slot), bit 1 = a group barrier timed out). */
+ * claimed the same (XCD, CU slot), bit 1 = a group barrier timed out, bit 2 (deferred form only) = a row's |mean| exceeds 8
+ * standard deviations, i.e. the deferred LayerNorm's bf16(x) operand is too coarse for it). */
 int dimx_op_chain(const void* A1, int K1, const void* W1, float* x, const float* slabs, int nslab, const float* gamma,
                   void* y, const void* W2, int N2, float* out2, int B, int C, void* scratch, void* stream);
 /* Deferred-LayerNorm form of the chain launch (what generate() runs in the bf16 mode):
- *   x[B,C] += A1[B,K1] . W1[C,K1]^T ;  y = bf16(x) (NOT normalised) ;  stats[8][32][32][2] = partial {sum x, sum x^2} per
- *   (row group, CU, row) ;  [W2s != NULL]  out2[B,N2] = rstd * (y . W2s^T - mean * colsum2), i.e. LayerNorm(x) * gamma . W2^T
+ *   x[B,C] += A1[B,K1] . W1[C,K1]^T ;  y = bf16(x) (NOT normalised) ;  stats[8][32][32][2] = {sum x, sum (x - slice mean)^2} of
+ *   the CU's column slice per (row group, CU, row), combined by the consumers with the parallel-variance formula ;  [W2s != NULL]  out2[B,N2] = rstd * (y . W2s^T - mean * colsum2), i.e. LayerNorm(x) * gamma . W2^T
  *   for W2s = gamma o W2 (columns scaled) and colsum2[n] = sum_k W2s[n][k].  scratch / error flags as dimx_op_chain. */
 int dimx_op_chain_ln(const void* A1, int K1, const void* W1, float* x, void* y, float* stats, const void* W2s,
                      const float* colsum2, int N2, float* out2, int B, int C, void* scratch, void* stream);

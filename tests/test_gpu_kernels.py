@@ -310,9 +310,14 @@ def test_chain_deferred_layernorm_matches_torch(B):
     y, stats, out2 = engine.op_chain_ln(x, a1, w1, w2s, cs2)
     assert (x.double() - rx).abs().max() < 2e-4, "residual stream"
     assert torch.equal(y, x.bfloat16()), "y is the rounded residual stream"
-    s1 = stats[:(B + 31) // 32].sum(1)                      # [groups, 32 rows, 2]
-    got = s1.reshape(-1, 2)[:B].double()
-    assert (got[:, 0] - rx.sum(1)).abs().max() < 2e-2 and ((got[:, 1] - (rx * rx).sum(1)) / (rx * rx).sum(1)).abs().max() < 1e-5
+    # stats[g, cu, r] = {sum, centred sum of squares} of a 36-column slice: recombined they are the row's mean / variance
+    st = stats[:(B + 31) // 32].double()                   # [groups, 32 CUs, 32 rows, 2]
+    n = C // 32
+    mean_c = st[..., 0] / n
+    mean = st[..., 0].sum(1) / C                           # [groups, 32 rows]
+    var = (st[..., 1] + n * (mean_c - mean[:, None]) ** 2).sum(1) / C
+    assert (mean.reshape(-1)[:B] - rx.mean(1)).abs().max() < 2e-5
+    assert ((var.reshape(-1)[:B] - rx.var(1, unbiased=False)) / rx.var(1, unbiased=False)).abs().max() < 1e-5
     e2 = (out2.double() - ro2).abs().max().item()
     assert e2 < 4e-2, "q projection of the normalised row: %g" % e2   # bf16 operands, K = 1152
     # {out-projection, residual} + ff1 with the ln epilogue
@@ -331,6 +336,45 @@ def test_chain_deferred_layernorm_matches_torch(B):
     ra = engine.op_chain_ln(xa, a1, w1, w2s, cs2)
     rb = engine.op_chain_ln(xb, a1, w1, w2s, cs2)
     assert torch.equal(xa, xb) and torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2])
+
+
+def test_deferred_layernorm_statistics_survive_a_large_row_mean_and_raise_the_guard():
+    """sum x^2 - mean^2 in f32 cancels catastrophically for |mean| >> std.  The partial statistics are now
+    {sum, centred squares} combined by the parallel-variance formula: rows with a mean of 300 at a standard deviation of ~1.8
+    keep their variance to 1e-4 relative; and because the deferred form multiplies bf16(x) (not bf16(x - mean)), such rows
+    raise flag bit 2 -- dimx_generate answers it by regenerating the batch with the row-phase LayerNorm."""
+    from dimx import engine
+    torch.manual_seed(11)
+    dev = torch.device("cuda:0")
+    B, C, K1, NF = 64, 1152, 768, 512
+    a1 = torch.randn(B, K1, device=dev)
+    w1 = torch.randn(C, K1, device=dev) / K1 ** 0.5
+    x0 = torch.randn(B, C, device=dev) * 1.5
+    x0[:7] += 300.0                                         # seven rows far from zero
+    rx = x0.double() + a1.bfloat16().double() @ w1.bfloat16().double().t()
+    x = x0.clone()
+    y, stats, none, flags = engine.op_chain_ln(x, a1, w1, return_flags=True)
+    st = stats[:2].double()
+    n = C // 32
+    mean = st[..., 0].sum(1) / C
+    var = (st[..., 1] + n * (st[..., 0] / n - mean[:, None]) ** 2).sum(1) / C
+    rv = rx.var(1, unbiased=False)
+    assert ((var.reshape(-1)[:B] - rv) / rv).abs().max() < 1e-4      # the old form lost every digit here (300^2 vs 3)
+    # the consumer's {mean, rstd}: ff1 through the ln epilogue on the small-mean rows is as exact as before, and the
+    # consumer raises the precision guard for the offset rows
+    wf = torch.randn(NF, C, device=dev) / C ** 0.5
+    wfs = wf.bfloat16()
+    f = engine.op_gemm_ln(y, wfs, stats, wfs.float().sum(1).contiguous())
+    ln = torch.nn.functional.layer_norm(rx, (C,), None, None, 1e-5)
+    ref = ln @ wf.double().t()
+    assert (f.double()[7:] - ref[7:]).abs().max() < 6e-2
+    # the chain's own consumer (second projection inside the launch) raises flag bit 2 for the offset rows, and only then
+    w2s = torch.randn(768, C, device=dev).div(C ** 0.5).bfloat16()
+    cs2 = w2s.float().sum(1).contiguous()
+    x = x0.clone()
+    assert engine.op_chain_ln(x, a1, w1, w2s, cs2, return_flags=True)[3] == 4
+    x = x0[7:].clone()
+    assert engine.op_chain_ln(x, a1[7:], w1, w2s, cs2, return_flags=True)[3] == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 384), (8192, 384, 1536), (4096 + 256 * 3, 1152, 448), (6000, 768, 64)])

@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
-LOGIT_TOL = 1e-3   # tightened to the measured level below once measured (see test_decode_tf_matches_oracle)
+LOGIT_TOL = 1e-4   # SURVEY Appendix C; measured on MI355X (round 3): 3.6e-6 .. 3.7e-6 at T = 24 .. 300
 
 
 @pytest.fixture(scope="module")
@@ -63,8 +63,8 @@ def test_decode_tf_matches_oracle(eng, full_sd, B, T, lens, use_kv):
     logits = logits.cpu()
     err = (logits - ref).abs().max().item()
     print("teacher-forced logits max |gpu - oracle| = %.2e (B=%d T=%d)" % (err, B, T))
-    # measured on MI355X (round 3): 4e-5 .. 2.2e-4 (f32 MFMA, other summation order than the CPU's blocked GEMMs over a
-    # 1152-wide residual stream of O(10) values); SURVEY Appendix C asks for 1e-4 -- asserted just above the measured level
+    # measured on MI355X (round 3): 3.6e-6 .. 3.7e-6 (f32 MFMA, other summation order than the CPU's blocked GEMMs);
+    # SURVEY Appendix C asks for 1e-4, asserted as such (round 2 had 1e-3 here)
     assert err < LOGIT_TOL, "logit err %g" % err
     # argmax identical where the top-2 margin is comfortable
     top2 = ref.topk(2, -1).values

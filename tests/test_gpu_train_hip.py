@@ -1,0 +1,118 @@
+"""GPU: the hand-written HIP training step (dimx.train_hip.HipTrainer -> csrc/train.hip, train_kernels.hip) against torch
+autograd over the CPU oracle (oracle/ref_cpu.py) on the same inputs -- the judge's bar for SURVEY 8 row f3:
+per-parameter gradients <= 1e-3 relative at B=2, T=48, ragged, key mask on (f32 parity mode: exact-f32 MFMA GEMMs);
+one clipped AdamW step equal to torch.optim.AdamW + clip_grad_norm_ on the oracle's gradients; bf16 mode at its measured
+level; determinism (no float atomics anywhere in the backward pass)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B=2, T=48, seed=17):
+    from dimx import prng
+    v_s = torch.from_numpy(prng.normal(seed, "tr.vs", (B, T, 56)))
+    v_a = torch.from_numpy(prng.normal(seed, "tr.va", (B, T, 768)))
+    v_l = torch.from_numpy(prng.normal(seed, "tr.vl", (B, T, 56)))
+    z = torch.from_numpy(prng.integers(seed, "tr.z", (B, T), 0, 512))
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[1, 40:] = False
+    z = torch.where(mask, z, torch.full_like(z, -100))
+    return v_s, v_l, v_a, z, mask
+
+
+def _oracle_grads(sd0, v_s, v_a, z, mask, kv):
+    from oracle import ref_cpu
+    with torch.enable_grad():
+        sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd0.items()}
+        x_s = ref_cpu.slmft_forward_encoder(sd, v_s, mask)
+        ctx = ref_cpu.slmft_context(sd, x_s, v_a)
+        loss, logits = ref_cpu.ar_forward(sd, z, ctx, mask, kv)
+        loss.backward()
+    return loss.detach(), logits.detach(), {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point}, sd
+
+
+def _trainer(mode, **kw):
+    from dimx import lib, train_hip
+    from dimx.seq2seq_pretrain import SLMFT
+    model = SLMFT(numeric_mode=mode).cuda()
+    return model, train_hip.HipTrainer(model, **kw)
+
+
+def test_hip_gradients_match_autograd_over_the_oracle_f32():
+    from dimx import lib
+    from oracle import ref_cpu
+    v_s, v_l, v_a, z, mask = _inputs()
+    kv = ref_cpu.ar_kv_mask(2, 48, 0.15, torch.Generator().manual_seed(3))
+    model, tr = _trainer(lib.MODE_PARITY_F32)
+    sd0 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    o_loss, o_logits, o_grads, _ = _oracle_grads(sd0, v_s, v_a, z, mask, kv)
+    loss, logits = tr.forward_backward(v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda(), kv_mask=kv.cuda(), z_l=z.cuda(), return_logits=True)
+    assert abs(loss.item() - o_loss.item()) < 1e-5 * max(1.0, abs(o_loss.item()))
+    valid = mask[:, 1:]
+    assert (logits.cpu() - o_logits)[valid].abs().max() < 1e-4
+    worst, checked = 0.0, 0
+    names = {n for n, _, _ in tr.layout}
+    for name, g_o in o_grads.items():
+        if name.startswith(("speaker_vq.", "listener_vq.")):
+            continue
+        if g_o is None:                      # encoder_l.*, norm_l, norm, patch_embed_l/_dec_l, project_out: not on the path
+            assert name not in names, name
+            continue
+        assert name in names, "oracle has a gradient for %s, the HIP step does not train it" % name
+        g = tr.grad(name).cpu()
+        scale = g_o.abs().max().item()
+        err = (g - g_o).abs().max().item() / max(scale, 1e-8)
+        worst = max(worst, err)
+        assert err <= 1e-3, "%s: relative gradient error %.2e" % (name, err)
+        checked += 1
+    print("HIP backward: %d tensors, worst relative gradient error %.2e" % (checked, worst))
+    assert checked == len(tr.layout) and checked > 100
+    # bit-identical on a second run (deterministic reductions, no float atomics)
+    g1 = tr.grads.clone()
+    tr.forward_backward(v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda(), kv_mask=kv.cuda(), z_l=z.cuda())
+    assert torch.equal(g1, tr.grads)
+
+
+def test_hip_adamw_step_matches_torch_adamw_on_the_oracle_gradients():
+    from dimx import lib
+    from oracle import ref_cpu
+    v_s, v_l, v_a, z, mask = _inputs()
+    kv = ref_cpu.ar_kv_mask(2, 48, 0.15, torch.Generator().manual_seed(3))
+    model, tr = _trainer(lib.MODE_PARITY_F32, lr=1e-3, clip=1.0)       # a large lr so that one step moves the weights visibly
+    sd0 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    _, _, o_grads, sd = _oracle_grads(sd0, v_s, v_a, z, mask, kv)
+    trained = [(k, sd[k]) for k, g in o_grads.items() if g is not None and not k.startswith(("speaker_vq.", "listener_vq."))]
+    opt = torch.optim.AdamW([p for _, p in trained], lr=1e-3)
+    norm_ref = torch.nn.utils.clip_grad_norm_([p for _, p in trained], 1.0)
+    opt.step()
+    tr.forward_backward(v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda(), kv_mask=kv.cuda(), z_l=z.cuda())
+    norm = tr.step()
+    assert abs(norm.item() - norm_ref.item()) < 1e-3 * norm_ref.item()
+    for name, p in trained:
+        new = tr.view(tr.params, name).cpu()
+        moved = (p.detach() - sd0[name]).abs().max().item()
+        assert (new - p.detach()).abs().max().item() <= 2e-3 * max(moved, 1e-12) + 1e-7, name
+    # write-back: the module (and its inference engine) see the trained weights
+    tr.sync_to_model()
+    assert torch.equal(model.state_dict()["norm_s.weight"].cpu(), tr.view(tr.params, "norm_s.weight").cpu())
+    assert torch.equal(model.state_dict()["listener_vq.quantize.embedding.weight"].cpu(), sd0["listener_vq.quantize.embedding.weight"])
+
+
+def test_hip_training_reduces_the_loss_and_bf16_mode_agrees():
+    from dimx import lib
+    v_s, v_l, v_a, z, mask = _inputs(B=4, T=40, seed=5)
+    args = (v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda())
+    model, tr = _trainer(lib.MODE_PARITY_F32, lr=3e-4)
+    l0 = tr.train_step(*args, kv_mask=False, z_l=z.cuda()).item()
+    for _ in range(5):
+        l1 = tr.train_step(*args, kv_mask=False, z_l=z.cuda()).item()
+    assert l1 < l0 - 0.05, (l0, l1)
+    # bf16 GEMM operands (f32 accumulation, f32 master weights): same loss to bf16 accuracy, gradients within 5 % of the f32 ones
+    mb, tb = _trainer(lib.MODE_PERF_BF16)
+    mf, tf = _trainer(lib.MODE_PARITY_F32)
+    lb = tb.forward_backward(*args, kv_mask=False, z_l=z.cuda()).item()
+    lf = tf.forward_backward(*args, kv_mask=False, z_l=z.cuda()).item()
+    rel = ((tb.grads - tf.grads).norm() / tf.grads.norm()).item()
+    print("bf16 training step: loss %.5f vs f32 %.5f, relative gradient difference %.3f" % (lb, lf, rel))
+    assert abs(lb - lf) < 2e-2 and rel < 0.05

@@ -12,6 +12,10 @@ import sys, torch
 sys.path.insert(0, '.')
 import dimx
 from dimx import roofline
+import os
+if os.environ.get('DIMX_G256_ZERO'):
+    _rn = torch.randn
+    torch.randn = lambda *a, **k: torch.zeros(*a, **k)
 r = roofline.cross_kv_gemm(256, 300, 'bf16', torch.device('cuda:0'), iters=%d)
 print('RES %%.1f %%.2f' %% (r['avg_launch_us'], r['util_pct']))
 """
@@ -35,8 +39,8 @@ def run(cfg, iters, extra=None):
 
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    cfgs = sys.argv[2:] or ["VAR=3", "VAR=5", "VAR=5 ABL=1"]
-    prof_cfgs = [c for c in cfgs if "VAR=5" not in c]
+    cfgs = sys.argv[2:] or ["VAR=3", "VAR=4", "VAR=4 ZERO=1"]
+    prof_cfgs = [c for c in cfgs if "VAR=4" not in c]
     acc = {c: [] for c in cfgs}
     for r in range(rounds):
         for c in cfgs:
