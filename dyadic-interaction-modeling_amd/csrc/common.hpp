@@ -336,6 +336,8 @@ struct DecodeAttnArgs {
     float scale;
 };
 int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s);
+// attention / GEMM co-residency probe (gemm.hip fused_probe_kernel; tools/fuse_probe.py)
+int launch_fused_probe(const GemmArgs& g, const DecodeAttnArgs& d, int which, unsigned* hw_id, hipStream_t s);
 
 int launch_vq_argmin(const float* z, int N, const float* Et /*[128][512]*/, const float* ee /*[512]*/,
                      int32_t* idx, float* best_d, float* margin, hipStream_t s);

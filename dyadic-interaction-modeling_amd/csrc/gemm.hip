@@ -17,6 +17,7 @@
 //     can write row-major activations, head-major K/V caches or the transposed V^T the attention
 //     kernel consumes.
 #include "common.hpp"
+#include "decode_attn_body.hpp"
 
 namespace dimx {
 
@@ -881,8 +882,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmArgs a
 // critical paths.)
 // ABLW (tuning only, tools/gemm_ab.py): 1 = consumers skip reads + MFMA, 2 = loaders issue no DMA after the prologue,
 // 3 = the W pieces are replaced by a second copy of the A pieces (every DMA an L2 hit).
-template <typename T, typename OutT, int STAGES, bool PROF = false, int ABLW = 0>
-__global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
+// The body as a device function (the block's index and the block count come as arguments, the LDS from the caller) so that
+// the attention / GEMM co-residency probe below can run it next to decode-attention blocks in one launch.
+template <typename T, typename OutT, int STAGES, bool PROF, int ABLW>
+__device__ __forceinline__ void gemm_ws_body(const GemmArgs& a, int block_id, int nblocks, unsigned char* smem, float* ln_sm) {
     constexpr int BM = 64, BN = 64, NL = 4;
     constexpr int EPC = Elem<T>::kPerChunk;
     constexpr int BK = 8 * EPC;
@@ -890,16 +893,14 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
     constexpr int LPT = LA + LW;
     constexpr int TILE_BYTES = (BM + BN) * 128;
     static_assert(STAGES >= 3 && (STAGES - 1) * LPT < 64, "ring depth");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
-    __shared__ __attribute__((aligned(16))) float ln_sm[128];  // deferred LayerNorm: mean[64], rstd[64] of the tile's rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;  // XCD-aware order, n-major for few row tiles: see gemm_glds_kernel
+    int bid = block_id;  // XCD-aware order, n-major for few row tiles: see gemm_glds_kernel
     {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+        const int nblk = nblocks, q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     const int split = bid / ntiles, tile = bid - split * ntiles;
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
     // PROF (tools/gemm_phases.py): 64 wall-clock stamps per block, 0-31 by consumer wave 0, 32-63 by loader wave 4
     auto stamp = [&](int i) {
         if (PROF && lane == 0 && (wave == 0 || wave == 4) && i < 32)
-            a.prof[(size_t)blockIdx.x * 64 + (wave == 4 ? 32 : 0) + i] = wall_clock64();
+            a.prof[(size_t)block_id * 64 + (wave == 4 ? 32 : 0) + i] = wall_clock64();
     };
     stamp(0);
 
@@ -1080,11 +1081,61 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
         }
     }
     epilogue<T, OutT, 1, 1>(a, acc, m0 + wm * 32, n0 + wn * 32, half, l31, split,
-                            (PROF && wave == 0 && lane == 0) ? a.prof + (size_t)blockIdx.x * 64 : nullptr);
+                            (PROF && wave == 0 && lane == 0) ? a.prof + (size_t)block_id * 64 : nullptr);
     if (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(29);
     }
+}
+
+template <typename T, typename OutT, int STAGES, bool PROF = false, int ABLW = 0>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
+    constexpr int TILE_BYTES = (64 + 64) * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float ln_sm[128];  // deferred LayerNorm: mean[64], rstd[64] of the tile's rows
+    gemm_ws_body<T, OutT, STAGES, PROF, ABLW>(a, blockIdx.x, gridDim.x, smem, ln_sm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention / GEMM co-residency probe (tools/fuse_probe.py; VERDICT round 2, item 2: "hide the decode step's GEMM chain
+// under its attention: horizontal fusion over two half-batches").  Streams do not overlap the decode kernels and CU masks
+// starve the HBM stream (round 2); what is left to try is ONE launch whose blocks take either role: blocks of role 0 run the
+// loader/consumer decode GEMM (gemm_ws_body, 8 waves, 64 KiB of LDS), blocks of role 1 the one-query decode attention
+// (decode_attn_body with 8 waves = 8 (clip, head) pairs per block; scores in the first 8 x npad floats of the same dynamic
+// LDS).  Both fit a CU together (2 x 64 KiB LDS, 16 waves of <= 128 VGPRs).  Roles alternate along the dispatch order of
+// an XCD and flip parity every 32 blocks, so that under breadth-first placement every CU receives one block of each kind;
+// hw_id (optional) records HW_REG_HW_ID per block so that the achieved placement can be counted, not assumed.
+template <typename OutT>
+__global__ __launch_bounds__(512) void fused_probe_kernel(const GemmArgs g, const DecodeAttnArgs d, int n_gemm, int n_attn, int npad,
+                                                         unsigned* hw_id) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    __shared__ __attribute__((aligned(16))) float ln_sm[128];
+    __shared__ float red_m[8], red_l[8], red_acc[8 * 64];
+    const int b = blockIdx.x;
+    const int x = b & 7, q = b >> 3;                 // XCD and position in the XCD's dispatch sequence
+    const int parity = (q ^ (q >> 5)) & 1;           // alternate roles; flip every 32 positions (one round of the XCD's CUs)
+    // the two parity classes alternate in an XCD's sequence, so q / 2 positions of either class come before position q:
+    // class-local index id in [0, grid / 2).  A class that has run out of work serves the other class's indices beyond
+    // grid / 2 (which that class's own half of the grid cannot hold); what is left over returns at once.
+    const int halfgrid = gridDim.x >> 1;
+    int role = parity, id = (q >> 1) * 8 + x;
+    {
+        const int n_role = role ? n_attn : n_gemm, n_other = role ? n_gemm : n_attn;
+        if (id >= n_role) {
+            id = halfgrid + (id - n_role);
+            role ^= 1;
+            if (id >= n_other) return;
+        }
+    }
+    if (hw_id && threadIdx.x == 0) {
+        unsigned v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        hw_id[b] = (v & 0xffffffu) | ((xcc & 7u) << 24) | ((unsigned)role << 28);
+    }
+    if (role == 0) gemm_ws_body<bf16, OutT, 4, false, 0>(g, id, n_gemm, dyn, ln_sm);
+    else decode_attn_body<bf16, false, true, 1, 8>(d, id, (float*)dyn, npad, red_m, red_l, red_acc);
 }
 
 template <typename T, typename OutT, int STAGES, int ABLW = 0> static int launch_ws(const GemmArgs& a, hipStream_t s) {
@@ -1309,6 +1360,31 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     }
     DIMX_REQUIRE(a.out_dtype == DIMX_F32, DIMX_ERR_ARG, "gemm: f32 inputs produce f32 outputs");
     return launch_typed<float, float>(a, s);
+}
+
+
+// which: 0 = both roles in one launch, 1 = GEMM blocks only, 2 = attention blocks only (same kernel, same geometry)
+int launch_fused_probe(const GemmArgs& g0, const DecodeAttnArgs& d, int which, unsigned* hw_id, hipStream_t s) {
+    GemmArgs g = g0;
+    DIMX_REQUIRE(g.in_dtype == DIMX_BF16 && d.dtype == DIMX_BF16 && d.q_f32 && !d.knew, DIMX_ERR_ARG, "fused_probe: bf16, cross form");
+    DIMX_REQUIRE(g.K % 64 == 0 && g.ldw == g.K && d.n_keys <= 2048, DIMX_ERR_ARG, "fused_probe: shape");
+    g.splitk = 1;
+    const int n_gemm = which == 2 ? 0 : ceil_div(g.M, 64) * ceil_div(g.N, 64);
+    const int n_attn = which == 1 ? 0 : ceil_div(d.B * d.H, 8);
+    const int npad = (d.n_keys + 15) / 16 * 16;
+    DIMX_REQUIRE(8 * npad * 4 <= 4 * 16384, DIMX_ERR_ARG, "fused_probe: too many keys for the shared LDS window");
+    const int total = n_gemm + n_attn;
+    const int grid = (total + 15) / 16 * 16;  // whole (XCD round, parity pair) groups: surplus blocks return at once
+    const size_t lds = 4 * 16384;
+#define FP(OT)                                                                                                      \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute((const void*)fused_probe_kernel<OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((fused_probe_kernel<OT>), dim3(grid), dim3(512), lds, s, g, d, n_gemm, n_attn, npad, hw_id);  \
+    } while (0)
+    if (g.out_dtype == DIMX_BF16) FP(bf16); else FP(float);
+#undef FP
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
 }
 
 }  // namespace dimx

@@ -2029,6 +2029,40 @@ int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void
     return launch_decode_attn(a, (hipStream_t)stream);
 }
 
+int dimx_op_fused_probe(const void* A, const void* W, const float* bias, void* C, int out_dtype, int M, int N, int K, int act,
+                        const void* q, const void* kcache, const void* vcache, void* out, int B, int H, int Tmax, int n_keys,
+                        float scale, const uint8_t* kmask, int which, uint32_t* hw_id, void* stream) {
+    GemmArgs g;
+    gemm_args_init(g);
+    g.in_dtype = DIMX_BF16;
+    g.out_dtype = out_dtype;
+    g.A = A; g.lda = K;
+    g.W = W; g.ldw = K;
+    g.M = M; g.N = N; g.K = K;
+    g.bias = bias;
+    g.act = act;
+    gemm_set_plain_out(g, C, N);
+    DecodeAttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = DIMX_BF16;
+    a.q = q;
+    a.q_ld = H * 64;
+    a.kcache = const_cast<void*>(kcache);
+    a.vcache = const_cast<void*>(vcache);
+    a.Tmax = Tmax;
+    a.out = out;
+    a.o_ld = H * 64;
+    a.B = B;
+    a.H = H;
+    a.n_keys = n_keys;
+    a.kmask = kmask;
+    a.kmask_ld = n_keys;
+    a.scale = scale;
+    a.q_f32 = 1;
+    a.nslab = 1;
+    return launch_fused_probe(g, a, which, hw_id, (hipStream_t)stream);
+}
+
 int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, void* vcache, void* out, int B, int H,
                              int Tmax, const int32_t* step_dev, float scale, int q_is_f32, void* stream) {
     DecodeAttnArgs a;

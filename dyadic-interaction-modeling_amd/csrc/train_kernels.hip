@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void ln_colsums_kernel(const float* __restrict
     float sg = 0.f, sb = 0.f;
     if (c < C) {
         for (int r = r_begin + rl; r < r_end; r += 4) {
-            // row statistics recomputed per (row, column lane) would be M x C x C work: they come precomputed in x as xhat
+            // `x` holds xhat (tr_xhat): recomputing the row statistics per column lane would be M x C x C work
             const float g = dy[(size_t)r * C + c];
             sb += g;
             if (x) sg += g * x[(size_t)r * C + c];
@@ -455,12 +455,12 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int32_t* __res
 
 // ------------------------------------------------------------------------------------------------ optimiser
 // partial sums of squares over the flat gradient arena (fixed block partition -> deterministic), then the norm
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
-    __shared__ float sm[256];
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ part) {
+    __shared__ double sm[256];
     const long per = (n + gridDim.x - 1) / gridDim.x;
     const long lo = (long)blockIdx.x * per, hi = min(n, lo + per);
-    float s = 0.f;
-    for (long i = lo + threadIdx.x; i < hi; i += 256) s += g[i] * g[i];
+    double s = 0.0;  // 1e8 squares: f64 partial sums keep the norm (and with it the clip factor) exact to f32 rounding
+    for (long i = lo + threadIdx.x; i < hi; i += 256) s += (double)g[i] * (double)g[i];
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
@@ -470,9 +470,9 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
 }
 // out[0] = ||g||, out[1] = clip coefficient min(1, max_norm / (||g|| + 1e-6)) (1 when max_norm <= 0)
-__global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restrict__ part, int nblocks, float max_norm, float* __restrict__ out) {
-    __shared__ float sm[256];
-    float s = 0.f;
+__global__ __launch_bounds__(256) void norm_finish_kernel(const double* __restrict__ part, int nblocks, float max_norm, float* __restrict__ out) {
+    __shared__ double sm[256];
+    double s = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += 256) s += part[i];
     sm[threadIdx.x] = s;
     __syncthreads();
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const float nrm = sqrtf(sm[0]);
+        const float nrm = (float)sqrt(sm[0]);
         out[0] = nrm;
         out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (nrm + 1e-6f)) : 1.0f;
     }
@@ -614,11 +614,12 @@ int tr_embedding_bwd(const int32_t* tokens, const float* dx, float* dtable, int 
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
-// norm_out[0] = ||g||_2, norm_out[1] = clip coefficient; part: >= 1024 floats
+// norm_out[0] = ||g||_2, norm_out[1] = clip coefficient; part: >= 1024 floats of 8-byte aligned scratch (512 f64 partial sums)
 int tr_grad_norm(const float* g, long n, float max_norm, float* part, float* norm_out, hipStream_t s) {
-    const int nb = 1024;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, part);
-    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, s, part, nb, max_norm, norm_out);
+    const int nb = 512;
+    DIMX_REQUIRE(((uintptr_t)part % 8) == 0, DIMX_ERR_ARG, "grad_norm: scratch must be 8-byte aligned");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, (double*)part);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nb, max_norm, norm_out);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -169,12 +169,43 @@ def generate_sharded(model, v_speaker, v_listener, v_audio, mask, **forward_kw):
     return tokens, pred
 
 
+def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoch, log):
+    """train_epoch on the hand-written HIP training step (dimx.train_hip.HipTrainer): forward, backward, the gradient
+    all-reduce (one flat RCCL collective), clipping and AdamW all run in libdimx_hip.so; the loop only feeds batches.  The
+    trained parameters are written back into the module at the end of the epoch (evaluation / state_dict see them)."""
+    from . import train as T
+    model.train()
+    if ddist.world_size() > 1 and hasattr(loader, "__len__"):
+        T.assert_same_batch_count(len(loader), device)
+    losses, all_losses = [], []
+    for i, batch in enumerate(loader):
+        src_s_v, src_s_a, tgt, mask, _, _ = _prepare(batch, device)
+        loss = trainer.train_step(src_s_v, tgt, src_s_a, mask)
+        if scheduler is not None:
+            scheduler.step()
+        losses.append(loss)                      # device scalars: no host synchronisation per batch
+        if i % print_freq == 0:
+            vals = [float(v) for v in torch.stack(losses).cpu()]
+            all_losses += vals
+            log("Epoch %d Batch %d:\tLoss %.4f\tl_ce_l %.4f" % (epoch, i, float(np.mean(vals)), float(np.mean(vals))))
+            losses = []
+    if losses:
+        all_losses += [float(v) for v in torch.stack(losses).cpu()]
+    trainer.sync_to_model()
+    return float(np.mean(all_losses)) if all_losses else float("nan")
+
+
 def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, print_freq=2000, epoch=0, log=print):
     """reference code/x_engine_pt.py:9-60: one pass over the loader with zero_grad / forward(mode='train') / backward /
-    clip / step.  For N > 1 processes the gradients are averaged over RCCL before clipping (dimx.train.all_reduce_grads);
+    clip / step.  ``optimizer`` = a ``dimx.train_hip.HipTrainer``: the whole step runs on the hand-written HIP kernels (the
+    default of examples/finetune_s2s_pretrain.py); a torch optimiser keeps the PyTorch-autograd restatement of round 2
+    (dimx.train), which is the checker of the HIP path.  For N > 1 processes the gradients are averaged over RCCL before clipping (dimx.train.all_reduce_grads);
     every rank feeds its own loader shard (get_vico_dataloaders shards by rank through a DistributedSampler); the ranks must
     see the same number of batches (checked) and start from rank 0's parameters (broadcast once).  Returns the mean loss."""
     from . import train as T
+    from .train_hip import HipTrainer
+    if isinstance(optimizer, HipTrainer):
+        return _train_epoch_hip(model, loader, optimizer, device, scheduler, print_freq, epoch, log)
     model.train()
     T.set_trainable(model, True)
     params = [p for _, p in T.trainable_parameters(model)]

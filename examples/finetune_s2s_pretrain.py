@@ -1,9 +1,11 @@
 """The reference's fine-tuning driver (code/finetune_s2s_pretrain.py:105-143) on the dimx drop-ins: AdamW lr 1e-5,
 clip 1.0, frozen VQ-VAEs, evaluate_finetune_epoch + print_metrics after every epoch, best checkpoint by FD sum.
 Single process or `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/finetune_s2s_pretrain.py`
-(one process per GPU, gradients averaged over RCCL in 64 MiB buckets; every rank reads its own shard of the clips).
+(one process per GPU, one flat gradient all-reduce per step over RCCL; every rank reads its own shard of the clips).
+The training step -- forward, backward, clip, AdamW -- runs on the hand-written HIP kernels (dimx.train_hip.HipTrainer);
+`--backward autograd` selects the PyTorch-autograd restatement that serves as its checker.
 
-    python examples/finetune_s2s_pretrain.py [--epochs 2] [--clips 64] [--batch 4] [--max-len 120]
+    python examples/finetune_s2s_pretrain.py [--epochs 2] [--clips 64] [--batch 4] [--max-len 120] [--backward hip|autograd]
 """
 import argparse
 import os
@@ -28,12 +30,17 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--max-len", type=int, default=120)
     ap.add_argument("--out", default="best_vico_causal.pt")
+    ap.add_argument("--backward", default="hip", choices=["hip", "autograd"])
     args = ap.parse_args()
     rank, world, local = ddist.init_from_env()
     device = torch.device("cuda:{}".format(local))
     torch.cuda.set_device(device)
     model = SLMFT().to(device)
-    optimizer = T.make_optimizer(model, lr=1e-5)          # torch.optim.AdamW(model.parameters(), lr=1e-5)
+    if args.backward == "hip":
+        from dimx.train_hip import HipTrainer
+        optimizer = HipTrainer(model, lr=1e-5, clip=1.0)   # AdamW(lr=1e-5) + clip 1.0 (code/finetune_s2s_pretrain.py:119,132)
+    else:
+        optimizer = T.make_optimizer(model, lr=1e-5)      # torch.optim.AdamW(model.parameters(), lr=1e-5)
     have_vico = os.path.isdir("../data/vico_processed_30fps")
     if not have_vico and rank == 0:
         print("no ViCo data under ../data: SYNTHETIC clips -- the numbers below are not ViCo results")

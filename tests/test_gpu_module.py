@@ -204,6 +204,48 @@ def test_train_epoch_on_gpu_updates_the_engine_weights():
             assert torch.equal(v, m.state_dict()[k].cpu()), k
 
 
+def test_train_epoch_on_the_hip_training_step_matches_the_autograd_restatement():
+    """x_engine_pt.train_epoch driven by dimx.train_hip.HipTrainer (forward, backward, clip, AdamW all in libdimx_hip.so)
+    against the same epoch on the PyTorch-autograd restatement (dimx.train, the checker): same loss trajectory, same trained
+    parameters to optimiser rounding, and the module / inference engine see the trained weights after the epoch."""
+    from dimx import train as T
+    from dimx import x_engine_pt
+    from dimx.seq2seq_pretrain import SLMFT
+    from dimx.train_hip import HipTrainer
+    dev = torch.device("cuda:0")
+    B, Tn, lens = 4, 32, [32, 32, 20, 11]
+    v_s, v_l, v_a, mask = _clips(B, Tn, lens, seed=33)
+    src = torch.cat([v_s, v_a], -1) * mask[..., None]
+    loader = [(src, v_l * mask[..., None], lens, None, ["a", "b", "c", "d"])] * 3
+    m_hip, m_ref = SLMFT().to(dev), SLMFT().to(dev)
+    m_hip.mask_prob = m_ref.mask_prob = 0.0           # no random key mask: the two paths must see the same problem
+    tr = HipTrainer(m_hip, lr=1e-4, clip=1.0)
+    l_hip = x_engine_pt.train_epoch(m_hip, loader, tr, dev, log=lambda *_: None)
+    with torch.enable_grad():
+        opt = T.make_optimizer(m_ref, lr=1e-4)
+        l_ref = x_engine_pt.train_epoch(m_ref, loader, opt, dev, clip=1.0, log=lambda *_: None)
+    assert np.isfinite(l_hip) and abs(l_hip - l_ref) < 2e-3 * max(1.0, abs(l_ref)), (l_hip, l_ref)
+    sd_h, sd_r = m_hip.state_dict(), m_ref.state_dict()
+    moved, worst = 0.0, 0.0
+    fresh = SLMFT().state_dict()
+    for name, _, _ in tr.layout:
+        d0 = (sd_r[name].cpu() - fresh[name]).abs().max().item()
+        moved = max(moved, d0)
+        worst = max(worst, (sd_h[name].cpu() - sd_r[name].cpu()).abs().max().item())
+    # three Adam steps of lr 1e-4 move every trained element by ~3e-4; the two paths agree to a small fraction of that except
+    # where a gradient element is ~0 and Adam's g / (|g| + eps) turns rounding noise into a sign (a few elements)
+    assert moved > 1e-4 and worst <= 2.5 * moved, (moved, worst)
+    close = torch.cat([(sd_h[n].cpu() - sd_r[n].cpu()).abs().reshape(-1) for n, _, _ in tr.layout])
+    assert (close < 2e-5).float().mean().item() > 0.99
+    for k, v in fresh.items():                          # the frozen VQ-VAEs did not move
+        if k.startswith(("listener_vq.", "speaker_vq.")) and v.dtype.is_floating_point:
+            assert torch.equal(v, sd_h[k].cpu()), k
+    m_hip.eval()
+    with torch.no_grad():
+        _, _, after = m_hip(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mode="val", greedy=True)
+    assert torch.isfinite(after).all()
+
+
 def test_reference_sub_apis_with_the_reference_call_shapes(model, full_sd):
     """SURVEY 8b sub-APIs: forward_encoder alone (dimx_encode_speaker), forward_decoder(x_s, z_l, x_a, mask, mode)
     positionally with the x_s that forward_encoder returned (dimx_set_context), and VQAutoEncoder.decode(quant) on

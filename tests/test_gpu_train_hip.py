@@ -75,6 +75,10 @@ def test_hip_gradients_match_autograd_over_the_oracle_f32():
 
 
 def test_hip_adamw_step_matches_torch_adamw_on_the_oracle_gradients():
+    """clip_grad_norm_(1.0) + AdamW on the SAME gradients (the oracle's, written into the trainer's arena): the fused kernel
+    must reproduce torch.optim.AdamW to rounding.  (On its own gradients the first Adam step is a sign function of every
+    element -- lr * g / (|g| + eps) -- so elements whose gradient is ~0 amplify a 1e-10 difference to 2 lr; the gradient
+    parity itself is the previous test.)"""
     from dimx import lib
     from oracle import ref_cpu
     v_s, v_l, v_a, z, mask = _inputs()
@@ -83,17 +87,30 @@ def test_hip_adamw_step_matches_torch_adamw_on_the_oracle_gradients():
     sd0 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     _, _, o_grads, sd = _oracle_grads(sd0, v_s, v_a, z, mask, kv)
     trained = [(k, sd[k]) for k, g in o_grads.items() if g is not None and not k.startswith(("speaker_vq.", "listener_vq."))]
+    assert sorted(k for k, _ in trained) == sorted(n for n, _, _ in tr.layout)
+    tr.grads.zero_()
+    for name, p in trained:
+        tr.grad(name).copy_(p.grad.cuda())
+    norm64 = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in trained)).item()      # before clip_grad_norm_ scales .grad
     opt = torch.optim.AdamW([p for _, p in trained], lr=1e-3)
     norm_ref = torch.nn.utils.clip_grad_norm_([p for _, p in trained], 1.0)
     opt.step()
-    tr.forward_backward(v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda(), kv_mask=kv.cuda(), z_l=z.cuda())
+    arena64 = tr.grads.double().norm().item()
     norm = tr.step()
-    assert abs(norm.item() - norm_ref.item()) < 1e-3 * norm_ref.item()
+    print("gradient norm: HIP %.7f, arena in f64 %.7f, oracle grads in f64 %.7f, clip_grad_norm_ %.7f" % (norm.item(), arena64, norm64, norm_ref.item()))
+    assert abs(norm.item() - norm64) < 1e-5 * norm64
     for name, p in trained:
         new = tr.view(tr.params, name).cpu()
-        moved = (p.detach() - sd0[name]).abs().max().item()
-        assert (new - p.detach()).abs().max().item() <= 2e-3 * max(moved, 1e-12) + 1e-7, name
-    # write-back: the module (and its inference engine) see the trained weights
+        assert (new - p.detach()).abs().max().item() <= 2e-6, name       # updates are ~1e-3: agreement to 0.2 %
+    # a second step (moments in use, bias correction at step 2) on the same gradients
+    for name, p in trained:
+        tr.grad(name).copy_(p.grad.cuda() * 1.0)    # clip_grad_norm_ scaled p.grad in place: give the trainer the clipped ones
+    torch.nn.utils.clip_grad_norm_([p for _, p in trained], 1.0)
+    opt.step()
+    tr.step()
+    for name, p in trained:
+        assert (tr.view(tr.params, name).cpu() - p.detach()).abs().max().item() <= 4e-6, name
+    # write-back: the module (and its inference engine) see the trained weights, the frozen VQ-VAEs are untouched
     tr.sync_to_model()
     assert torch.equal(model.state_dict()["norm_s.weight"].cpu(), tr.view(tr.params, "norm_s.weight").cpu())
     assert torch.equal(model.state_dict()["listener_vq.quantize.embedding.weight"].cpu(), sd0["listener_vq.quantize.embedding.weight"])
