@@ -105,45 +105,65 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
         for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
     const float scale2 = a.scale * 1.4426950408889634f;
 
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int j0 = tile * 64;
-        __syncthreads();
-        // ---- stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]
+    // Staging is software-pipelined through registers (round 3): the global loads of tile t + 1 are issued right after tile
+    // t's operands went to LDS and land while tile t is being computed (S^T, softmax, P . V: ~1.5 k cycles per wave) -- the
+    // loop used to load, wait, store and only then compute, with nothing but other blocks to cover the L2 latency.
+    constexpr int KI = 64 * CPRK / NT, VI = NB * 32 * CPR / NT;
+    uint4 kreg[KI], vreg[VI];
+    auto load_tile = [&](int j0) {
 #pragma unroll
-        for (int i = 0; i < 64 * CPRK / NT; ++i) {
+        for (int i = 0; i < KI; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / CPRK, c = idx % CPRK;
             int key = j0 + row;
             key = key < a.Lk ? key : a.Lk - 1;
-            const uint4 v = (c * EPC < a.D) ? *(const uint4*)(K + (size_t)key * a.k_st + c * EPC)
-                                            : make_uint4(0, 0, 0, 0);
-            *(uint4*)(sK + row * ROWBK + ((c ^ swz(row)) << 4)) = v;
+            kreg[i] = (c * EPC < a.D) ? *(const uint4*)(K + (size_t)key * a.k_st + c * EPC) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NB * 32 * CPR / NT; ++i) {
+        for (int i = 0; i < VI; ++i) {
+            const int idx = tid + i * NT;
+            const int d = idx / CPR, c = idx % CPR;
+            const int jj = j0 + c * EPC;
+            vreg[i] = (d < a.D && a.Lk - jj > 0) ? *(const uint4*)(Vt + (size_t)d * a.v_sd + jj) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    // bf16 only: in the f32 parity mode the 16 extra 16-byte registers cost a wave of occupancy (248 -> 314 VGPRs)
+    constexpr bool PIPE = ES == 2;
+    if (PIPE && ntiles > 0) load_tile(0);
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int j0 = tile * 64;
+        if (!PIPE) load_tile(j0);
+        __syncthreads();
+        // ---- K tile [64 keys][64 d] and V^T tile [64 d][64 keys] from the registers to LDS
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx / CPRK, c = idx % CPRK;
+            *(uint4*)(sK + row * ROWBK + ((c ^ swz(row)) << 4)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VI; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / CPR, c = idx % CPR;
             {
                 const int d = row;
                 const int jj = j0 + c * EPC;
-                int nvalid = a.Lk - jj;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (d < a.D && nvalid > 0) {
-                    v = *(const uint4*)(Vt + (size_t)d * a.v_sd + jj);
-                    if (nvalid < EPC) {  // zero the keys beyond Lk: 0 * garbage must stay 0
-                        if (ES == 2) {
-                            uint16_t e[8];
-                            *(uint4*)e = v;
+                const int nvalid = a.Lk - jj;
+                uint4 v = vreg[i];
+                if (d < a.D && nvalid > 0 && nvalid < EPC) {  // zero the keys beyond Lk: 0 * garbage must stay 0
+                    if (ES == 2) {
+                        uint16_t e[8];
+                        *(uint4*)e = v;
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) e[q] = q < nvalid ? e[q] : (uint16_t)0;
-                            v = *(uint4*)e;
-                        } else {
-                            uint32_t e[4];
-                            *(uint4*)e = v;
+                        for (int q = 0; q < 8; ++q) e[q] = q < nvalid ? e[q] : (uint16_t)0;
+                        v = *(uint4*)e;
+                    } else {
+                        uint32_t e[4];
+                        *(uint4*)e = v;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) e[q] = q < nvalid ? e[q] : 0u;
-                            v = *(uint4*)e;
-                        }
+                        for (int q = 0; q < 4; ++q) e[q] = q < nvalid ? e[q] : 0u;
+                        v = *(uint4*)e;
                     }
                 }
                 if (ES == 2) {
@@ -155,6 +175,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
                 }
             }
         }
+        if (PIPE && tile + 1 < ntiles) load_tile(j0 + 64);  // in flight during this tile's compute
         // ---- key validity bits of this tile (wave-uniform 64-bit mask)
         const int jl = j0 + lane;
         bool kv = jl < a.Lk && jl < len_b;
@@ -210,22 +231,30 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
         }
         mx = fmaxf(mx, xor_lane_f32<32>(mx));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2<T>(m_run - m_new);
+        // bf16 mode: the running maximum (and with it the 32 accumulator rescales + one exp per tile) is only moved when some
+        // query's maximum grew by more than 2^8 -- probabilities relative to a slightly stale maximum are at most 256, well
+        // inside f32 / bf16 range, and the final normalisation divides it out.  The f32 parity mode keeps the exact form.
+        bool rescale = true;
+        if (ES == 2) rescale = __any((m_new - m_run) > 8.0f);
+        if (rescale) {
+            const float alpha = fast_exp2<T>(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2<T>(st[kt][r] - m_new);
+                const float p = fast_exp2<T>(st[kt][r] - m_run);
                 st[kt][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T . P^T
 #pragma unroll

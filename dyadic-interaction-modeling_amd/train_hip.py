@@ -134,8 +134,19 @@ class HipTrainer:
                                           L.stream_ptr(self.device)), "dimx_train_adamw")
         return self._scratch[1024]
 
-    def train_step(self, v_speaker, v_listener, v_audio, mask, kv_mask=None, z_l=None):
-        loss = self.forward_backward(v_speaker, v_listener, v_audio, mask, kv_mask=kv_mask, z_l=z_l)
+    def train_step(self, v_speaker, v_listener, v_audio, mask, kv_mask=None, z_l=None, with_cont_loss=False):
+        """one optimisation step; returns l_ce_l (device scalar), or (total, dict) like SLMFT.forward(mode='train') when
+        with_cont_loss: the reference's total also carries the continuous loss of the decoded arg-max codes, which has no
+        gradient path (code/seq2seq_pretrain.py:454-478) -- it is evaluated from this step's logits on the HIP engine."""
+        if not with_cont_loss:
+            loss = self.forward_backward(v_speaker, v_listener, v_audio, mask, kv_mask=kv_mask, z_l=z_l)
+            self.all_reduce_grads()
+            self.step()
+            return loss
+        l_ce, logits = self.forward_backward(v_speaker, v_listener, v_audio, mask, kv_mask=kv_mask, z_l=z_l, return_logits=True)
         self.all_reduce_grads()
         self.step()
-        return loss
+        with torch.no_grad():
+            pred = self.model.forward_vq_decoder(logits, mode="train")
+            l_cont = self.model.forward_continuous_loss(pred, v_listener.to(self.device), mask.bool().to(self.device))
+        return l_ce + l_cont, {"l_ce_s": 0, "l_ce_l": l_ce, "l_cont_s": 0, "l_cont_l": l_cont, "nce": 0, "c_acc": 0}

@@ -177,18 +177,21 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoc
     model.train()
     if ddist.world_size() > 1 and hasattr(loader, "__len__"):
         T.assert_same_batch_count(len(loader), device)
-    losses, all_losses = [], []
+    losses, ces, conts, all_losses = [], [], [], []
     for i, batch in enumerate(loader):
         src_s_v, src_s_a, tgt, mask, _, _ = _prepare(batch, device)
-        loss = trainer.train_step(src_s_v, tgt, src_s_a, mask)
+        loss, d_step = trainer.train_step(src_s_v, tgt, src_s_a, mask, with_cont_loss=True)   # the reference's total loss
         if scheduler is not None:
             scheduler.step()
         losses.append(loss)                      # device scalars: no host synchronisation per batch
+        ces.append(d_step["l_ce_l"])
+        conts.append(d_step["l_cont_l"])
         if i % print_freq == 0:
             vals = [float(v) for v in torch.stack(losses).cpu()]
             all_losses += vals
-            log("Epoch %d Batch %d:\tLoss %.4f\tl_ce_l %.4f" % (epoch, i, float(np.mean(vals)), float(np.mean(vals))))
-            losses = []
+            log("Epoch %d Batch %d:\tLoss %.4f\tl_ce_l %.4f\tl_cont_l %.4f" % (
+                epoch, i, float(np.mean(vals)), float(torch.stack(ces).mean()), float(torch.stack(conts).mean())))
+            losses, ces, conts = [], [], []
     if losses:
         all_losses += [float(v) for v in torch.stack(losses).cpu()]
     trainer.sync_to_model()

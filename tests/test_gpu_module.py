@@ -224,7 +224,7 @@ def test_train_epoch_on_the_hip_training_step_matches_the_autograd_restatement()
     with torch.enable_grad():
         opt = T.make_optimizer(m_ref, lr=1e-4)
         l_ref = x_engine_pt.train_epoch(m_ref, loader, opt, dev, clip=1.0, log=lambda *_: None)
-    assert np.isfinite(l_hip) and abs(l_hip - l_ref) < 2e-3 * max(1.0, abs(l_ref)), (l_hip, l_ref)
+    assert np.isfinite(l_hip) and abs(l_hip - l_ref) < 5e-3 * max(1.0, abs(l_ref)), (l_hip, l_ref)   # CE + continuous loss
     sd_h, sd_r = m_hip.state_dict(), m_ref.state_dict()
     moved, worst = 0.0, 0.0
     fresh = SLMFT().state_dict()
