@@ -28,9 +28,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PROFILES = os.path.join(os.path.dirname(HERE), "profiles")
 
 
-def kernel_source_hash(name="decode_attn.hip"):
-    with open(os.path.join(HERE, "csrc", name), "rb") as fh:
-        return hashlib.sha256(fh.read()).hexdigest()[:12]
+DECODE_ATTN_SOURCES = ("decode_attn.hip", "decode_attn_body.hpp")   # the kernel body lives in the header since round 3
+
+
+def kernel_source_hash(name=DECODE_ATTN_SOURCES):
+    """sha256[:12] over the source file(s) a kernel is built from (a PMC record only counts for the sources it was taken on)."""
+    names = (name,) if isinstance(name, str) else tuple(name)
+    hsh = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(HERE, "csrc", n), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:12]
 
 
 def pmc_traffic(B, T, mode):
@@ -183,7 +191,7 @@ def cross_kv_gemm(B, T, mode, device, iters=12):
     tf = flops / sec / 1e12
     peak = MFMA_PEAK_TFLOPS[mode]
     out = {"kernel": "%s (cross-attention K/V projection, %d layer%s per launch) M=%d N=%d K=%d" % (
-               "gemm256_kernel<bf16>" if bf else "gemm_glds_kernel<float>", nlayers, "s" if nlayers > 1 else "", M, N, K),
+               "gemm256p2_kernel<bf16>" if bf else "gemm_glds_kernel<float>", nlayers, "s" if nlayers > 1 else "", M, N, K),
            "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "util_pct": 100.0 * tf / peak,
            "avg_launch_us": sec * 1e6, "pmc_mfma_busy_pct": None}
     # MFMA busy cycles / kernel cycles from the PMC pass recorded for THIS kernel source (same rule as `traffic`): the
