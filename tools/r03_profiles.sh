@@ -54,3 +54,4 @@ bash tools/scale_check.sh 1 > $O/r03_scale_check_n1.txt 2>&1
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_l2
 ls -la $O
 tail -c 600 $O/r03_bench_line.json
+python -m pytest tests/test_gpu_module.py -q -x -k "hip_training_step or train_epoch" 2>&1 | tail -3
