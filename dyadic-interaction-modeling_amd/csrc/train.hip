@@ -299,6 +299,9 @@ int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C
     a.src = cross ? ctx : a.y;
     a.shape = shape;
     a.shape.ldq = a.shape.ldk = a.shape.ldv = a.shape.ldo = inner;
+    // perf mode: attention and its adjoints on the matrix cores (train_attn.hip); DIMX_TRAIN_ATTN_VALU=1 keeps the f32 kernels (A/B)
+    static const bool valu_only = getenv("DIMX_TRAIN_ATTN_VALU") && atoi(getenv("DIMX_TRAIN_ATTN_VALU")) != 0;
+    a.shape.mfma = (s.at == DIMX_BF16 && !valu_only) ? 1 : 0;
     TR(launch_layernorm(DIMX_F32, h_in, a.y, s.p(a.pre + "0.0.weight"), nullptr, M, C, s.st));
     DIMX_TRY(lin_fwd(s, a.q, a.y, C, M, a.qb, inner));
     DIMX_TRY(lin_fwd(s, a.k, a.src, a.Ck, a.Mk, a.kb, inner));
@@ -635,6 +638,26 @@ int dimx_train_adamw(float* params, const float* grads, float* exp_avg, float* e
     hipStream_t st = (hipStream_t)stream;
     DIMX_TRY(tr_grad_norm(grads, (long)n, max_norm, scratch, scratch + 1024, st));
     return tr_adamw(params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, step, scratch + 1024, st);
+}
+
+int dimx_op_train_attention(int mfma, const float* q, const float* k, const float* v, const float* d_o, const uint8_t* kmask,
+                            const uint8_t* kmask2, int B, int H, int Lq, int Lk, int causal, float scale, float* o, float* lse,
+                            float* delta, float* dq, float* dk, float* dv, void* stream) {
+    DIMX_REQUIRE(q && k && v && o && lse && B > 0 && H > 0 && Lq > 0 && Lk > 0, DIMX_ERR_ARG, "op_train_attention: bad argument");
+    DIMX_REQUIRE(!d_o || (delta && dq && dk && dv), DIMX_ERR_ARG, "op_train_attention: the backward pass needs delta, dq, dk, dv");
+    TrAttn t;
+    memset(&t, 0, sizeof(t));
+    t.B = B; t.H = H; t.Lq = Lq; t.Lk = Lk;
+    t.ldq = t.ldk = t.ldv = t.ldo = H * 64;
+    t.scale = scale;
+    t.causal = causal;
+    t.kmask = kmask;
+    t.kmask2 = kmask2;
+    t.mfma = mfma ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    DIMX_TRY(tr_attn_fwd(t, q, k, v, o, lse, st));
+    if (d_o) DIMX_TRY(tr_attn_bwd(t, q, k, v, o, d_o, lse, delta, dq, H * 64, dk, H * 64, dv, H * 64, st));
+    return DIMX_OK;
 }
 
 }  // extern "C"

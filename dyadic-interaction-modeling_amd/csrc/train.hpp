@@ -13,12 +13,16 @@ struct TrAttn {
     int causal;
     const uint8_t* kmask;    // [B, Lk] keep-mask (padding), optional
     const uint8_t* kmask2;   // [B, Lk] second keep-mask (the mask_prob draw), optional
+    int mfma;                // 1: the bf16 matrix-core kernels of train_attn.hip (perf mode), 0: the f32 VALU kernels (parity mode)
 };
 
 int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s);
 int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
 int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                 float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, hipStream_t s);
+int tr_attn_fwd_mfma(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
+int tr_attn_bwd_mfma(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                     const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, hipStream_t s);
 int tr_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, int accumulate, int M, int C, hipStream_t s);
 int tr_xhat(const float* x, float* xh, int M, int C, hipStream_t s);
 int tr_colsums(const float* xh, const float* dy, float* dg, float* db, int M, int C, float* part, int accumulate, hipStream_t s);

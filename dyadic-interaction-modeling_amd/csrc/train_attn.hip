@@ -1,0 +1,415 @@
+// train_attn.hip -- attention of the training step on the matrix cores (perf mode: bf16 operands, f32 accumulation and
+// statistics).  SURVEY 8 row f3; the mathematics is x-transformers' Attend (masked_fill(-max) before a float32 softmax) and
+// its adjoint, as the one-wave-per-row VALU kernels of train_kernels.hip state it for the f32 parity mode.
+//
+//   forward   O = softmax(scale . Q K^T + masks) V, LSE_i = max_i + log sum_i kept for the backward pass
+//   dQ        dS = P o (dO V^T - delta) . scale,  dQ = dS K          (P recomputed from the LSE, delta_i = dO_i . O_i)
+//   dK, dV    dK = dS^T Q,  dV = P^T dO
+//
+// All three kernels use v_mfma_f32_32x32x16_bf16 with one wave owning a 32-row strip, 4 waves per block, the other operand
+// streamed through LDS in 64-row tiles converted from the f32 activations on the way in.  The products are arranged so that
+// no probability ever changes lanes:
+//   * forward / dQ compute S^T = K Q^T (A = K rows from LDS, B = Q rows in registers): a lane owns ONE query (lane & 31) and
+//     16 keys of every 32-key block, so the softmax is lane-local and P^T / dS^T are already B operands of the second product
+//     (O^T = V^T P^T, dQ^T = K^T dS^T), whose A operand is read from a TRANSPOSED LDS tile with the keys in the order the
+//     accumulator rows have them: k-step j covers keys {16j + 4(lane>>5) + r, 16j + 8 + 4(lane>>5) + r}, r = 0..3.
+//   * dK / dV compute S = Q K^T (A = Q rows from LDS, B = K rows in registers): a lane owns ONE key and 16 queries per block,
+//     P and dS are B operands of dV^T = dO^T P and dK^T = Q^T dS with dO^T / Q^T read from transposed LDS tiles.
+// Outputs leave as 16-byte stores (an accumulator holds 4 consecutive head columns of one row).
+// Deterministic: no atomics, every output element is written by exactly one lane.
+#include "train.hpp"
+
+namespace dimx {
+
+namespace {
+
+constexpr int kLd = 72;  // LDS row stride in bf16 elements (144 B: 16-byte aligned rows, rows spread over the banks)
+constexpr int kTile = 64 * kLd;
+constexpr float kNegMaxF = -3.402823466e+38f;
+constexpr float kInf = __builtin_inff();
+
+__device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) {
+    return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+}
+
+// 64 rows x 64 head columns of an f32 [L, ld] matrix (rows r0.., rows >= L read as zero) -> row-major bf16 LDS tile
+__device__ __forceinline__ void stage_rows(uint16_t* dst, const float* __restrict__ src, int ld, int r0, int L, int tid) {
+    const int row = tid >> 2, c = (tid & 3) * 16;
+    float4 v[4];
+    if (r0 + row < L) {
+        const float4* p = (const float4*)(src + (size_t)(r0 + row) * ld + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = p[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    uint4* d = (uint4*)(dst + row * kLd + c);
+    d[0] = pack8(v[0], v[1]);
+    d[1] = pack8(v[2], v[3]);
+}
+
+// the same 64 x 64 block transposed: dst[column][row]
+__device__ __forceinline__ void stage_cols(uint16_t* dst, const float* __restrict__ src, int ld, int r0, int L, int tid) {
+    const int d = tid & 63, quad = tid >> 6;
+    float x[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 16 * p + 4 * quad + i;
+            x[p][i] = r < L ? src[(size_t)r * ld + d] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        *(uint2*)(dst + d * kLd + 16 * p + 4 * quad) = make_uint2(pack_bf16x2(x[p][0], x[p][1]), pack_bf16x2(x[p][2], x[p][3]));
+}
+
+// B operand straight from an f32 row in global memory: lane's row, columns 16 s + 8 (lane >> 5) .. + 7
+__device__ __forceinline__ void frag_rows_global(uint4 (&f)[4], const float* __restrict__ row_ptr, bool valid, int hl) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (valid) {
+            const float4* p = (const float4*)(row_ptr + 16 * s + 8 * hl);
+            f[s] = pack8(p[0], p[1]);
+        } else {
+            f[s] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
+// A operand of a row-major tile: row 32 rb + (lane & 31), columns 16 s + 8 (lane >> 5) .. + 7
+__device__ __forceinline__ uint4 frag_a(const uint16_t* tile, int rb, int s, int l31, int hl) {
+    return *(const uint4*)(tile + (32 * rb + l31) * kLd + 16 * s + 8 * hl);
+}
+
+// A operand of a transposed tile for k-step j: row 32 db + (lane & 31), columns in accumulator-row order
+__device__ __forceinline__ uint4 frag_at(const uint16_t* tile, int db, int j, int l31, int hl) {
+    const uint16_t* p = tile + (32 * db + l31) * kLd + 16 * j + 4 * hl;
+    const uint2 lo = *(const uint2*)p, hi = *(const uint2*)(p + 8);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// B operand of k-step j from two 32-row accumulator blocks of the first product
+__device__ __forceinline__ uint4 frag_b_acc(const f32x16_t (&x)[2], int j) {
+    const f32x16_t& a = x[j >> 1];
+    const int o = 8 * (j & 1);
+    return make_uint4(pack_bf16x2(a[o], a[o + 1]), pack_bf16x2(a[o + 2], a[o + 3]), pack_bf16x2(a[o + 4], a[o + 5]),
+                      pack_bf16x2(a[o + 6], a[o + 7]));
+}
+
+__device__ __forceinline__ float other_half(float x) { return __shfl_xor(x, 32, 64); }
+
+// keep / valid bit per key of a 64-key tile (wave-uniform 64-bit words)
+__device__ __forceinline__ void key_bits(const TrAttn& a, int b, int k0, int lane, uint64_t& keep, uint64_t& valid) {
+    const int key = k0 + lane;
+    const bool v = key < a.Lk;
+    bool kp = v;
+    if (v && a.kmask) kp = a.kmask[(size_t)b * a.Lk + key] != 0;
+    if (kp && a.kmask2) kp = a.kmask2[(size_t)b * a.Lk + key] != 0;
+    keep = __ballot(kp);
+    valid = __ballot(v);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(TrAttn a, const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, float* __restrict__ o,
+                                                            float* __restrict__ lse) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[kTile];
+    __shared__ __attribute__((aligned(16))) uint16_t Vt[kTile];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hl = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0b = blockIdx.x * 128, q0w = q0b + 32 * w, qi = q0w + l31;
+    const bool wave_on = q0w < a.Lq, q_ok = qi < a.Lq;
+    uint4 Qf[4];
+    frag_rows_global(Qf, q + ((size_t)b * a.Lq + (q_ok ? qi : 0)) * a.ldq + h * 64, q_ok, hl);
+    const float* kb = k + (size_t)b * a.Lk * a.ldk + h * 64;
+    const float* vb = v + (size_t)b * a.Lk * a.ldv + h * 64;
+    f32x16_t accO[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accO[0][i] = accO[1][i] = 0.f;
+    float m = kNegMaxF, lsum = 0.f;
+    int nkt = (a.Lk + 63) >> 6;
+    if (a.causal) nkt = min(nkt, (min(q0b + 127, a.Lq - 1) >> 6) + 1);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_rows(Ks, kb, a.ldk, kt * 64, a.Lk, tid);
+        stage_cols(Vt, vb, a.ldv, kt * 64, a.Lk, tid);
+        uint64_t keep, valid;
+        key_bits(a, b, kt * 64, lane, keep, valid);
+        __syncthreads();
+        if (!wave_on || (a.causal && kt * 64 > q0w + 31)) continue;
+        f32x16_t st[2];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[kb2][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma(st[kb2], frag_a(Ks, kb2, s, l31, hl), Qf[s]);
+        }
+        float mt = kNegMaxF;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kl = 32 * kb2 + 8 * (i >> 2) + 4 * hl + (i & 3);
+                const bool kp = ((keep >> kl) & 1) && !(a.causal && kt * 64 + kl > qi);
+                const bool vd = (valid >> kl) & 1;
+                const float s = vd ? (kp ? st[kb2][i] * a.scale : kNegMaxF) : -kInf;
+                st[kb2][i] = s;
+                mt = fmaxf(mt, s);
+            }
+        }
+        mt = fmaxf(mt, other_half(mt));
+        const float m_new = fmaxf(m, mt);
+        const float alpha = __expf(m - m_new);
+        m = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __expf(st[kb2][i] - m_new);
+                st[kb2][i] = p;
+                ps += p;
+            }
+        }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            accO[0][i] *= alpha;
+            accO[1][i] *= alpha;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 pb = frag_b_acc(st, j);
+            mma(accO[0], frag_at(Vt, 0, j, l31, hl), pb);
+            mma(accO[1], frag_at(Vt, 1, j, l31, hl), pb);
+        }
+    }
+    if (!q_ok) return;
+    const float ltot = lsum + other_half(lsum);
+    const float inv = 1.f / ltot;
+    float* op = o + ((size_t)b * a.Lq + qi) * a.ldo + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(op + 32 * db + 8 * g + 4 * hl) = make_float4(accO[db][4 * g] * inv, accO[db][4 * g + 1] * inv,
+                                                                    accO[db][4 * g + 2] * inv, accO[db][4 * g + 3] * inv);
+    }
+    if (hl == 0) lse[((size_t)b * a.H + h) * a.Lq + qi] = m + logf(ltot);
+}
+
+// delta_i = dO_i . O_i, one thread per (clip, head, query)
+__global__ __launch_bounds__(256) void attn_delta_kernel(TrAttn a, const float* __restrict__ o, const float* __restrict__ d_o,
+                                                         float* __restrict__ delta) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)a.B * a.H * a.Lq;
+    if (idx >= n) return;
+    const int i = (int)(idx % a.Lq);
+    const int h = (int)((idx / a.Lq) % a.H);
+    const int b = (int)(idx / ((long)a.Lq * a.H));
+    const float4* op = (const float4*)(o + ((size_t)b * a.Lq + i) * a.ldo + h * 64);
+    const float4* gp = (const float4*)(d_o + ((size_t)b * a.Lq + i) * a.ldo + h * 64);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float4 x = op[c], g = gp[c];
+        s += x.x * g.x + x.y * g.y + x.z * g.z + x.w * g.w;
+    }
+    delta[idx] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(256) void attn_dq_mfma_kernel(TrAttn a, const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const float* __restrict__ d_o,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ dq, int lddq) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[kTile];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[kTile];
+    __shared__ __attribute__((aligned(16))) uint16_t Kt[kTile];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hl = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0b = blockIdx.x * 128, q0w = q0b + 32 * w, qi = q0w + l31;
+    const bool wave_on = q0w < a.Lq, q_ok = qi < a.Lq;
+    uint4 Qf[4], Gf[4];
+    frag_rows_global(Qf, q + ((size_t)b * a.Lq + (q_ok ? qi : 0)) * a.ldq + h * 64, q_ok, hl);
+    frag_rows_global(Gf, d_o + ((size_t)b * a.Lq + (q_ok ? qi : 0)) * a.ldo + h * 64, q_ok, hl);
+    const float L = q_ok ? lse[((size_t)b * a.H + h) * a.Lq + qi] : kInf;
+    const float dl = q_ok ? delta[((size_t)b * a.H + h) * a.Lq + qi] : 0.f;
+    const float* kb = k + (size_t)b * a.Lk * a.ldk + h * 64;
+    const float* vb = v + (size_t)b * a.Lk * a.ldv + h * 64;
+    f32x16_t acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+    int nkt = (a.Lk + 63) >> 6;
+    if (a.causal) nkt = min(nkt, (min(q0b + 127, a.Lq - 1) >> 6) + 1);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_rows(Ks, kb, a.ldk, kt * 64, a.Lk, tid);
+        stage_rows(Vs, vb, a.ldv, kt * 64, a.Lk, tid);
+        stage_cols(Kt, kb, a.ldk, kt * 64, a.Lk, tid);
+        uint64_t keep, valid;
+        key_bits(a, b, kt * 64, lane, keep, valid);
+        __syncthreads();
+        if (!wave_on || (a.causal && kt * 64 > q0w + 31)) continue;
+        f32x16_t st[2], dp[2];
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[kb2][i] = dp[kb2][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                mma(st[kb2], frag_a(Ks, kb2, s, l31, hl), Qf[s]);
+                mma(dp[kb2], frag_a(Vs, kb2, s, l31, hl), Gf[s]);
+            }
+        }
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kl = 32 * kb2 + 8 * (i >> 2) + 4 * hl + (i & 3);
+                const bool kp = ((keep >> kl) & 1) && !(a.causal && kt * 64 + kl > qi);
+                const float p = kp ? __expf(st[kb2][i] * a.scale - L) : 0.f;  // a masked score has no gradient (masked_fill)
+                st[kb2][i] = p * (dp[kb2][i] - dl) * a.scale;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 sb = frag_b_acc(st, j);
+            mma(acc[0], frag_at(Kt, 0, j, l31, hl), sb);
+            mma(acc[1], frag_at(Kt, 1, j, l31, hl), sb);
+        }
+    }
+    if (!q_ok) return;
+    float* op = dq + ((size_t)b * a.Lq + qi) * lddq + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(op + 32 * db + 8 * g + 4 * hl) =
+                make_float4(acc[db][4 * g], acc[db][4 * g + 1], acc[db][4 * g + 2], acc[db][4 * g + 3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256) void attn_dkv_mfma_kernel(TrAttn a, const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ d_o,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+    __shared__ __attribute__((aligned(16))) uint16_t Qs[kTile];
+    __shared__ __attribute__((aligned(16))) uint16_t Gs[kTile];
+    __shared__ __attribute__((aligned(16))) uint16_t Qt[kTile];
+    __shared__ __attribute__((aligned(16))) uint16_t Gt[kTile];
+    __shared__ __attribute__((aligned(16))) float Ls[64];
+    __shared__ __attribute__((aligned(16))) float Ds[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hl = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int k0b = blockIdx.x * 128, k0w = k0b + 32 * w, kj = k0w + l31;
+    const bool wave_on = k0w < a.Lk, k_ok = kj < a.Lk;
+    bool kept = k_ok;
+    if (kept && a.kmask) kept = a.kmask[(size_t)b * a.Lk + kj] != 0;
+    if (kept && a.kmask2) kept = a.kmask2[(size_t)b * a.Lk + kj] != 0;
+    uint4 Kf[4], Vf[4];
+    frag_rows_global(Kf, k + ((size_t)b * a.Lk + (k_ok ? kj : 0)) * a.ldk + h * 64, k_ok, hl);
+    frag_rows_global(Vf, v + ((size_t)b * a.Lk + (k_ok ? kj : 0)) * a.ldv + h * 64, k_ok, hl);
+    const float* qb = q + (size_t)b * a.Lq * a.ldq + h * 64;
+    const float* gb = d_o + (size_t)b * a.Lq * a.ldo + h * 64;
+    const float* lp = lse + ((size_t)b * a.H + h) * a.Lq;
+    const float* dp_ = delta + ((size_t)b * a.H + h) * a.Lq;
+    f32x16_t accK[2], accV[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accK[0][i] = accK[1][i] = accV[0][i] = accV[1][i] = 0.f;
+    const int nqt = (a.Lq + 63) >> 6;
+    const int qt0 = a.causal ? min(k0b >> 6, nqt) : 0;  // a causal query tile below the block's first key sees none of its keys
+    for (int qt = qt0; qt < nqt; ++qt) {
+        __syncthreads();
+        stage_rows(Qs, qb, a.ldq, qt * 64, a.Lq, tid);
+        stage_rows(Gs, gb, a.ldo, qt * 64, a.Lq, tid);
+        stage_cols(Qt, qb, a.ldq, qt * 64, a.Lq, tid);
+        stage_cols(Gt, gb, a.ldo, qt * 64, a.Lq, tid);
+        if (tid < 64) {
+            const int qi = qt * 64 + tid;
+            Ls[tid] = qi < a.Lq ? lp[qi] : kInf;
+            Ds[tid] = qi < a.Lq ? dp_[qi] : 0.f;
+        }
+        __syncthreads();
+        if (!wave_on || (a.causal && qt * 64 + 63 < k0w)) continue;
+        f32x16_t st[2], dp[2];
+#pragma unroll
+        for (int qb2 = 0; qb2 < 2; ++qb2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[qb2][i] = dp[qb2][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                mma(st[qb2], frag_a(Qs, qb2, s, l31, hl), Kf[s]);
+                mma(dp[qb2], frag_a(Gs, qb2, s, l31, hl), Vf[s]);
+            }
+        }
+#pragma unroll
+        for (int qb2 = 0; qb2 < 2; ++qb2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = 32 * qb2 + 8 * g + 4 * hl;
+                const float4 L4 = *(const float4*)(Ls + ql), D4 = *(const float4*)(Ds + ql);
+                const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * g + r;
+                    const bool kp = kept && !(a.causal && kj > qt * 64 + ql + r);
+                    const float p = kp ? __expf(st[qb2][i] * a.scale - Lr[r]) : 0.f;
+                    st[qb2][i] = p;
+                    dp[qb2][i] = p * (dp[qb2][i] - Dr[r]) * a.scale;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 pb = frag_b_acc(st, j), sb = frag_b_acc(dp, j);
+            mma(accV[0], frag_at(Gt, 0, j, l31, hl), pb);
+            mma(accV[1], frag_at(Gt, 1, j, l31, hl), pb);
+            mma(accK[0], frag_at(Qt, 0, j, l31, hl), sb);
+            mma(accK[1], frag_at(Qt, 1, j, l31, hl), sb);
+        }
+    }
+    if (!k_ok) return;
+    float* kp_ = dk + ((size_t)b * a.Lk + kj) * lddk + h * 64;
+    float* vp_ = dv + ((size_t)b * a.Lk + kj) * lddv + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *(float4*)(kp_ + 32 * db + 8 * g + 4 * hl) =
+                make_float4(accK[db][4 * g], accK[db][4 * g + 1], accK[db][4 * g + 2], accK[db][4 * g + 3]);
+            *(float4*)(vp_ + 32 * db + 8 * g + 4 * hl) =
+                make_float4(accV[db][4 * g], accV[db][4 * g + 1], accV[db][4 * g + 2], accV[db][4 * g + 3]);
+        }
+    }
+}
+
+}  // namespace
+
+int tr_attn_fwd_mfma(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s) {
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((t.Lq + 127) / 128, t.H, t.B), dim3(256), 0, s, t, q, k, v, o, lse);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int tr_attn_bwd_mfma(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                     const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, hipStream_t s) {
+    const long n = (long)t.B * t.H * t.Lq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, o, d_o, delta);
+    hipLaunchKernelGGL(attn_dq_mfma_kernel, dim3((t.Lq + 127) / 128, t.H, t.B), dim3(256), 0, s, t, q, k, v, d_o, lse, delta, dq, lddq);
+    hipLaunchKernelGGL(attn_dkv_mfma_kernel, dim3((t.Lk + 127) / 128, t.H, t.B), dim3(256), 0, s, t, q, k, v, d_o, lse, delta, dk,
+                       lddk, dv, lddv);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+}  // namespace dimx

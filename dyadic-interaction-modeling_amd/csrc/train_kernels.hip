@@ -530,12 +530,14 @@ static AttnShape make_shape(const TrAttn& t) {
     return a;
 }
 int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s) {
+    if (t.mfma) return tr_attn_fwd_mfma(t, q, k, v, o, lse, s);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(t.Lq, t.H, t.B), dim3(64), 0, s, make_shape(t), q, k, v, o, lse);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
 int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                 float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, hipStream_t s) {
+    if (t.mfma) return tr_attn_bwd_mfma(t, q, k, v, o, d_o, lse, delta, dq, lddq, dk, lddk, dv, lddv, s);
     const AttnShape a = make_shape(t);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(t.Lq, t.H, t.B), dim3(64), 0, s, a, q, k, v, o, d_o, lse, dq, lddq, delta);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(t.Lk, t.H, t.B), dim3(64), 0, s, a, q, k, v, d_o, lse, delta, dk, lddk, dv, lddv);

@@ -79,6 +79,9 @@ SIGNATURES = {
                                             c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_train_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                  c_int, c_float, c_void_p, c_void_p]),
+    "dimx_op_train_attention": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "dimx_chain_faults": (c_int, [c_void_p]),
     "dimx_debug_chain_fault": (c_int, [c_void_p, c_int]),
     "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,

@@ -11,8 +11,9 @@ Path (reference lines in brackets):
 Deliberate, documented differences:
   * the no-arg constructor works without the reference's ``./runs/*/model.pth.tar`` files (deterministic
     synthetic weights); ``vq_speaker_ckpt`` / ``vq_listener_ckpt`` load them when they exist;
-  * ``speaker_ids`` / ``listener_ids`` conditioning (train_epoch only, code/x_engine.py:23) is not on the
-    evaluation path and raises NotImplementedError; the id-embedding tensors are still part of the state dict;
+  * ``speaker_ids`` / ``listener_ids`` conditioning (train_epoch only, code/x_engine.py:23) exists on the training
+    branch (``model.train()`` + grad enabled: ``dimx.train.legacy_loss`` on autograd, the VQ-VAE halves from the HIP
+    engine); the no-grad evaluation path raises NotImplementedError for them, x_engine.evaluate_epoch never passes them;
   * sampling randomness is injectable (``noise`` [T,B,512] Exp(1) variates, ``seed``, ``greedy``);
   * the per-clip Python loops [227-233] are one batched ragged pass on the GPU; results are identical.
 """
@@ -89,11 +90,47 @@ class ListenerGenerator(_EngineOwner):
         gs = (gt[:, 1:, :] - gt[:, :-1, :]).reshape(b * (t - 1), c)
         return torch.mean(F.pairwise_distance(ps, gs))
 
+    # ------------------------------------------------------------------ training (reference code/x_engine.py:8-36)
+    def train(self, mode=True):
+        """nn.Module.train with both VQ-VAEs kept in eval (reference :166, :170)."""
+        super().train(mode)
+        self.speaker_vq.eval()
+        self.listener_vq.eval()
+        return self
+
+    def _wants_grad(self):
+        return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _forward_autograd(self, v_speaker, v_listener, mask, speaker_ids=None, listener_ids=None, return_logits=False):
+        """The loop body's ``model(src, tgt, mask, speaker_ids=None, listener_ids=listener_ids)`` with a graph: frozen
+        halves (speaker features, listener codes) from the HIP engine, the generator + the listener VQ-VAE's decoder
+        + the id embeddings through dimx.train.legacy_loss."""
+        from . import train as T
+        mask = mask.bool()
+        with torch.no_grad():
+            eng, xs, xl, lens, m8 = self._prepare(v_speaker, v_listener, mask)
+            z_l = eng.vq_encode(1, xl, lens, pe_mode=0, pad_value=-100).long()
+            x_speaker = eng.legacy_speaker_features(xs, m8).clone()
+        P = dict(self.named_parameters())
+        pe = self.listener_vq.decoder.decoder_pos_embedding.pe
+        loss, pred, logits = T.legacy_loss(P, self.dims, self.vq_dims, x_speaker, z_l, v_listener.float(), mask, pe,
+                                           speaker_ids=speaker_ids, listener_ids=listener_ids)
+        self.last_logits = logits.detach()
+        if return_logits:
+            return loss, pred, logits
+        return loss, pred
+
     # ------------------------------------------------------------------ forward / generate
-    @torch.no_grad()
     def forward(self, v_speaker, v_listener, mask, speaker_ids=None, listener_ids=None, return_logits=False):
         """reference :220-278 -> (loss, pred_cont_seq [B,T-1,56]); ``self.last_logits`` keeps the [B,T-1,512]
-        teacher-forced logits (the reference discards them; code/x_engine.py:78 wants them for perplexity)."""
+        teacher-forced logits (the reference discards them; code/x_engine.py:78 wants them for perplexity).
+        In training (``model.train()``, grad enabled, parameters requiring grad) the loss carries an autograd graph."""
+        if self._wants_grad():
+            return self._forward_autograd(v_speaker, v_listener, mask, speaker_ids, listener_ids, return_logits)
+        with torch.no_grad():
+            return self._forward_nograd(v_speaker, v_listener, mask, speaker_ids, listener_ids, return_logits)
+
+    def _forward_nograd(self, v_speaker, v_listener, mask, speaker_ids=None, listener_ids=None, return_logits=False):
         if speaker_ids is not None or listener_ids is not None:
             raise NotImplementedError("speaker_ids / listener_ids conditioning is a training-only path "
                                       "(code/x_engine.py:23); evaluation calls model(src, tgt, mask)")

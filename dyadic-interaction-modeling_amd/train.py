@@ -5,10 +5,15 @@ What is differentiated is the teacher-forced path of ``SLMFT.forward(mode='train
 encoder_s -> encoder_joint -> norm_s -> context -> AutoregressiveWrapper.forward -> cross entropy.  The continuous
 loss has no gradient path in the reference either (its ``pred`` comes from an argmax / one-hot of the logits, :454-464),
 and both VQ-VAEs are frozen (:348-366), so the listener code targets and the decoded motion are taken from the HIP engine
-(no graph) and only the transformer stack is restated here with differentiable PyTorch-ROCm ops (rocBLAS / hipBLASLt
-GEMMs, fused softmax): the backward pass runs on autograd, not on hand-written HIP kernels -- those are the inference
-path; hand-written backward kernels are the next step of this row.  After ``optimizer.step()`` the
-engine notices the changed parameters and re-packs them before its next launch.
+(no graph).
+
+Two implementations of that step live in the package:
+  * ``dimx.train_hip.HipTrainer`` -- forward + backward + clip + AdamW on hand-written HIP kernels (csrc/train.hip), the
+    one ``x_engine_pt.train_epoch`` uses when it is handed a HipTrainer;
+  * this module -- the same mathematics on PyTorch-ROCm autograd (rocBLAS / hipBLASLt GEMMs), kept as the
+    ``torch.optim`` route of ``train_epoch`` and as the functional layers the LEGACY generator's loop (``legacy_loss``,
+    reference code/x_engine.py:8-36) differentiates.  After ``optimizer.step()`` the engine notices the changed
+    parameters and re-packs them before its next launch.
 
 Multi-GPU: one process per GPU, replicated weights, per-rank batch shard; ``all_reduce_grads`` averages the gradients in
 ~64 MiB flat buckets over RCCL (xGMI ring: a few large collectives instead of one per tensor) before clipping.
@@ -109,6 +114,90 @@ def slmft_loss(P, dims, v_speaker, v_audio, mask, z_l, kv_mask=None):
     logits = xt_decoder_logits(P, "decoder_joint.net.", inp, ctx, mask, kv_mask, dims.dec_depth, dims.heads)
     loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), z_l[:, 1:].reshape(-1), ignore_index=-100)
     return loss, logits
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# legacy ListenerGenerator (reference code/seq2seq.py:138-278) -- what code/x_engine.py:8-36 trains
+# ---------------------------------------------------------------------------------------------------------------------
+LEGACY_TRAINABLE_PREFIXES = ("generator.", "listener_vq.decoder.", "speaker_embeddings.", "listener_embeddings.",
+                             "fc_speaker.", "fc_listener.")
+
+
+def legacy_trainable_parameters(model):
+    """reference code/seq2seq.py:165-176: the speaker VQ-VAE and the listener VQ-VAE's encoder + codebook are frozen,
+    the listener VQ-VAE's DECODER, the generator and the id-embedding layers train."""
+    return [(n, p) for n, p in model.named_parameters() if n.startswith(LEGACY_TRAINABLE_PREFIXES)]
+
+
+def set_legacy_trainable(model, flag=True):
+    for _, p in legacy_trainable_parameters(model):
+        p.requires_grad_(flag)
+    return model
+
+
+def _gelu_tanh(x):
+    return x * (0.5 * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x * x * x))))
+
+
+def vq_decoder(P, pre, zq, heads, layers, pe):
+    """Differentiable TransformerDecoder of the listener VQ-VAE (reference code/models/stage1_BIWI.py:376-393): linear,
+    Conv1d(k5, replicate) + LeakyReLU(0.2) + InstanceNorm over time, linear, + pe[batch row], ``layers`` pre-LN
+    {attention with packed qkv and scale hidden^-0.5, tanh-GELU MLP} blocks, bias-free output map.  zq [B,L,128]."""
+    B, n, _ = zq.shape
+    c = pre + "decoder."
+    h = F.linear(zq, P[c + "decoder_linear_embedding_pre.net.weight"], P[c + "decoder_linear_embedding_pre.net.bias"])
+    x = F.conv1d(F.pad(h.transpose(1, 2), (2, 2), mode="replicate"), P[c + "expander.0.0.weight"], P[c + "expander.0.0.bias"])
+    h = F.instance_norm(F.leaky_relu(x, 0.2), eps=1e-5).transpose(1, 2)
+    h = F.linear(h, P[c + "decoder_linear_embedding.net.weight"], P[c + "decoder_linear_embedding.net.bias"])
+    h = h + pe[:B]
+    H = h.shape[-1]
+    for i in range(layers):
+        a = "%sdecoder_transformer.net.%d.fn." % (c, 2 * i)
+        y = F.layer_norm(h, (H,), P[a + "norm.weight"], P[a + "norm.bias"], 1e-5)
+        q, k, v = F.linear(y, P[a + "fn.to_qkv.weight"]).view(B, n, 3, heads, H // heads).permute(2, 0, 3, 1, 4)
+        att = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (H ** -0.5), dim=-1)
+        o = torch.matmul(att, v).transpose(1, 2).reshape(B, n, H)
+        h = h + F.linear(o, P[a + "fn.to_out.weight"], P[a + "fn.to_out.bias"])
+        m = "%sdecoder_transformer.net.%d.fn." % (c, 2 * i + 1)
+        y = F.layer_norm(h, (H,), P[m + "norm.weight"], P[m + "norm.bias"], 1e-5)
+        y = _gelu_tanh(F.linear(y, P[m + "fn.l1.weight"], P[m + "fn.l1.bias"]))
+        h = h + F.linear(y, P[m + "fn.l2.weight"], P[m + "fn.l2.bias"])
+    return F.linear(h, P[c + "vertice_map_reverse.weight"])
+
+
+def legacy_loss(P, dims, vq_dims, x_speaker, z_l, v_listener, mask, pe, speaker_ids=None, listener_ids=None):
+    """Differentiable ``ListenerGenerator.forward`` (reference code/seq2seq.py:235-278 with Transformer.forward :46-67).
+    x_speaker [B,T,1024] and z_l [B,T] (-100 on padding) come from the frozen VQ-VAEs (HIP engine, no graph); ``pe`` is
+    the listener decoder's positional buffer.  ``listener_ids`` (the call of code/x_engine.py:24) prepends
+    fc_listener(relu(listener_embeddings[id])) to the encoder output, a True to the context mask and a -100 to the
+    targets; ``speaker_ids`` prepends fc_speaker(relu(speaker_embeddings[id])) to the encoder INPUT.
+    Returns (loss = cross entropy + continuous loss, pred_cont_seq [B,T-1,56], logits [B,T-1,512])."""
+    B = x_speaker.shape[0]
+    one = torch.ones(B, 1, dtype=torch.bool, device=mask.device)
+    cmask = mask
+    if speaker_ids is not None:
+        sid = F.linear(F.relu(P["speaker_embeddings.weight"][speaker_ids]), P["fc_speaker.weight"], P["fc_speaker.bias"])
+        x_speaker = torch.cat([sid[:, None], x_speaker], dim=1)
+        cmask = torch.cat([one, cmask], dim=1)
+    enc = xt_encoder(P, "generator.encoder.", x_speaker, cmask, False, dims.depth, dims.heads)
+    tgt = z_l
+    if listener_ids is not None:
+        lid = F.linear(F.relu(P["listener_embeddings.weight"][listener_ids]), P["fc_listener.weight"], P["fc_listener.bias"])
+        enc = torch.cat([lid[:, None], enc], dim=1)
+        cmask = torch.cat([one, cmask], dim=1)
+        tgt = torch.cat([torch.full_like(z_l[:, :1], -100), z_l], dim=1)
+    inp, target = tgt[:, :-1].clamp(min=0), tgt[:, 1:]
+    logits = xt_decoder_logits(P, "generator.decoder.net.", inp, enc, cmask, None, dims.depth, dims.heads, pos_emb=True)
+    loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), target.reshape(-1), ignore_index=-100)
+    if listener_ids is not None:
+        logits = logits[:, 1:]
+    zq = P["listener_vq.quantize.embedding.weight"][logits.argmax(-1)]
+    pred = vq_decoder(P, "listener_vq.", zq, vq_dims.heads, vq_dims.layers, pe)
+    m = mask[:, 1:].reshape(-1)
+    p = pred.reshape(-1, pred.shape[-1])[m]
+    t = v_listener[:, 1:].reshape(-1, pred.shape[-1])[m]
+    loss_cont = F.pairwise_distance(p[:, 6:], t[:, 6:]).mean() + F.pairwise_distance(p[:, :6], t[:, :6]).mean()
+    return loss + loss_cont, pred, logits
 
 
 # ---------------------------------------------------------------------------------------------------------------------

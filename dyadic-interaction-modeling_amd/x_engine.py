@@ -10,7 +10,8 @@ the [B,T-1,512] logits; with 512 code classes that indexes out of range.  The lo
 teacher-forced decoder logits, which ``ListenerGenerator.forward`` keeps as ``last_logits``.
 
 ``model`` may be the bare module or a wrapper exposing ``.module`` (the reference calls
-``model.module.generate`` on its DataParallel wrapper).  Training loops (``train_epoch``) are out of scope.
+``model.module.generate`` on its DataParallel wrapper).  ``train_epoch`` / ``train_continuous_epoch`` are the
+reference's loops (:8-62); the generator's backward pass runs on PyTorch-ROCm autograd (dimx.train.legacy_loss).
 """
 import numpy as np
 import torch
@@ -70,11 +71,53 @@ def evaluate_epoch(model, loader, device, generate_kw=None, verbose=True):
     return ppl
 
 
-def train_epoch(*args, **kwargs):
-    """Import-compatibility placeholder for reference code/x_engine.py:8-36 (the LEGACY ListenerGenerator's loop).
-    The training step that is built is the DIM-Listener one: dimx.x_engine_pt.train_epoch / dimx.train."""
-    raise NotImplementedError("the legacy ListenerGenerator's training loop is not built; the DIM-Listener (SLMFT) "
-                              "training step is dimx.x_engine_pt.train_epoch")
+def _train_loop(model, loader, optimizer, device, scheduler, clip, print_freq, epoch, step_loss):
+    """Loop body shared by the two reference loops: zero_grad, loss.mean().backward(), clip_grad_norm_, step, scheduler,
+    running mean printed every ``print_freq`` batches (reference code/x_engine.py:14-36, :40-62).  N > 1: gradients are
+    averaged over the ranks in flat buckets before the clip (dimx.train.all_reduce_grads); the reference's DataParallel
+    wrapper is replaced by one process per GPU."""
+    from . import train as T
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    try:
+        T.assert_same_batch_count(len(loader), device)
+    except TypeError:
+        pass
+    losses, seen = [], []
+    for i, batch in enumerate(loader):
+        optimizer.zero_grad()
+        loss = step_loss(batch)
+        loss.mean().backward()
+        T.all_reduce_grads(params)
+        if clip > 0:
+            torch.nn.utils.clip_grad_norm_(params, clip)
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        losses.append(loss.mean().item())
+        seen.append(losses[-1])
+        if i % print_freq == 0:
+            print("Epoch: [{0}][{1}/{2}]\tLoss {loss_avg:.4f}\t".format(epoch, i, len(loader), loss_avg=np.mean(losses)))
+            losses = []
+    return float(np.mean(seen)) if seen else float("nan")
 
 
-train_continuous_epoch = train_epoch
+def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, print_freq=100, epoch=0):
+    """reference code/x_engine.py:8-36: batches ``(src, tgt, src_len, (speaker_ids, listener_ids), data_ids)``;
+    ``model(src, tgt, mask, speaker_ids=None, listener_ids=listener_ids) -> (loss, pred)``.  Returns the epoch's mean
+    loss (the reference returns None; the value is extra)."""
+    def step_loss(batch):
+        src, tgt, src_len, (_speaker_ids, listener_ids) = batch[0], batch[1], batch[2], batch[3]
+        src, tgt, listener_ids = src.to(device), tgt.to(device), listener_ids.to(device)
+        loss, _ = model(src, tgt, _mask_from_lens(src, src_len, device), speaker_ids=None, listener_ids=listener_ids)
+        return loss
+    return _train_loop(model, loader, optimizer, device, scheduler, clip, print_freq, epoch, step_loss)
+
+
+def train_continuous_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, print_freq=100, epoch=0):
+    """reference code/x_engine.py:38-62: the same loop for a model whose ``model(src, tgt, mask)`` returns the loss
+    alone (the reference's ContinuousTransformer, which is not part of this build; any such module works)."""
+    def step_loss(batch):
+        src, tgt, src_len = batch[0].to(device), batch[1].to(device), batch[2]
+        return model(src, tgt, _mask_from_lens(src, src_len, device))
+    return _train_loop(model, loader, optimizer, device, scheduler, clip, print_freq, epoch, step_loss)

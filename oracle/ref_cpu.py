@@ -476,17 +476,36 @@ def legacy_generate(sd, start, seq_len, context, context_mask, noise=None, tempe
     return out[:, 1:]
 
 
-def listener_generator_forward(sd, v_speaker, v_listener, mask):
-    """ListenerGenerator.forward(v_speaker[B,T,824], v_listener[B,T,56], mask) with speaker_ids = listener_ids =
-    None (the call x_engine.evaluate_epoch makes, code/x_engine.py:76) -> (loss, pred_cont_seq [B,T-1,56]).
-    code/seq2seq.py:220-278."""
+def listener_generator_forward(sd, v_speaker, v_listener, mask, speaker_ids=None, listener_ids=None):
+    """ListenerGenerator.forward(v_speaker[B,T,824], v_listener[B,T,56], mask, speaker_ids, listener_ids)
+    -> (loss, pred_cont_seq [B,T-1,56]).  code/seq2seq.py:220-278 with Transformer.forward :46-67.
+    x_engine.evaluate_epoch calls it with both ids None (code/x_engine.py:76); x_engine.train_epoch with
+    speaker_ids=None and listener_ids given (code/x_engine.py:24): fc_listener(relu(listener_embeddings[id])) is put in
+    front of the encoder output, the context mask gets a leading True and the targets a leading -100 (:50-57), and the
+    extra first logit row is dropped (:64-65).  speaker_ids puts fc_speaker(relu(speaker_embeddings[id])) in front of
+    the encoder INPUT (:238-243)."""
+    B = v_speaker.shape[0]
     x_speaker = legacy_speaker_features(sd, v_speaker, mask)
     _, z_l = forward_vq(sd, v_speaker, v_listener, mask, with_speaker=False)
-    enc = xt_encoder(sd, "generator.encoder.", x_speaker, mask, causal=False, depth=6, heads=8)
-    inp, target = z_l[:, :-1], z_l[:, 1:]
+    cmask = mask
+    one = torch.ones(B, 1, dtype=torch.bool)
+    if speaker_ids is not None:
+        sid = _lin(F.relu(sd["speaker_embeddings.weight"][speaker_ids]), sd, "fc_speaker")
+        x_speaker = torch.cat([sid.unsqueeze(1), x_speaker], dim=1)
+        cmask = torch.cat([one, cmask], dim=1)
+    enc = xt_encoder(sd, "generator.encoder.", x_speaker, cmask, causal=False, depth=6, heads=8)
+    tgt = z_l
+    if listener_ids is not None:
+        lid = _lin(F.relu(sd["listener_embeddings.weight"][listener_ids]), sd, "fc_listener")
+        enc = torch.cat([lid.unsqueeze(1), enc], dim=1)
+        cmask = torch.cat([one, cmask], dim=1)
+        tgt = torch.cat([torch.full_like(z_l[:, :1], -100), z_l], dim=1)
+    inp, target = tgt[:, :-1], tgt[:, 1:]
     inp = torch.where(inp == -100, torch.zeros_like(inp), inp)
-    logits = legacy_decoder_logits(sd, inp, enc, mask)
+    logits = legacy_decoder_logits(sd, inp, enc, cmask)
     loss = F.cross_entropy(logits.permute(0, 2, 1), target, ignore_index=-100)
+    if listener_ids is not None:
+        logits = logits[:, 1:, :]
     pred_seq = logits.argmax(dim=-1)
     pred = vq_decode(sd, pred_seq, "listener_vq.")
     loss_cont = continuous_loss(pred, v_listener, mask)

@@ -174,6 +174,58 @@ def test_evaluate_epoch_protocol(legacy_sd):
     assert abs(ppl - np.exp(nll / cnt)) < 1e-3 * np.exp(nll / cnt)
 
 
+def test_train_epoch_on_the_legacy_generator(legacy_sd):
+    """reference code/x_engine.py:8-36 on the drop-in module: the training forward (frozen VQ halves from the HIP engine,
+    generator / listener VQ decoder / id embeddings on autograd) has the loss and gradients of autograd over the oracle;
+    three AdamW steps lower the loss, touch only what the reference trains, and the engine re-packs the new weights."""
+    from dimx import seq2seq, x_engine
+    from dimx import train as T
+    from oracle import ref_cpu
+    dev = torch.device("cuda:0")
+    model = seq2seq.ListenerGenerator().to(dev)
+    T.set_legacy_trainable(model)
+    model.train()
+    assert not model.speaker_vq.training and not model.listener_vq.training
+    v_s, v_l, mask = _case(2, 20, [20, 13], seed=21)
+    lid = torch.tensor([3, 41])
+    with torch.enable_grad():
+        loss, pred = model(v_s.to(dev), v_l.to(dev), mask.to(dev), speaker_ids=None, listener_ids=lid.to(dev))
+        loss.backward()
+        sd = {k: v.detach().clone().requires_grad_(k.startswith(T.LEGACY_TRAINABLE_PREFIXES)) for k, v in legacy_sd.items()}
+        o_loss, o_pred, _ = ref_cpu.listener_generator_forward(sd, v_s, v_l, mask, listener_ids=lid)
+        o_loss.backward()
+    assert abs(loss.item() - o_loss.item()) < 1e-4 * max(1.0, abs(o_loss.item()))
+    assert (pred.cpu() - o_pred).abs().max().item() < 1e-3
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if sd[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        rel = (p.grad.cpu() - sd[k].grad).abs().max().item() / max(sd[k].grad.abs().max().item(), 1e-8)
+        worst = max(worst, rel)
+        assert rel < 1e-3, (k, rel)
+    print("legacy training forward: worst relative gradient error vs autograd over the oracle %.2e" % worst)
+    # the loop
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tok0, _ = model.generate(v_s.to(dev), v_l.to(dev), mask.to(dev), greedy=True)
+    batch = (v_s, v_l, [20, 13], (torch.tensor([0, 1]), lid), ["a", "b"])
+    opt = torch.optim.AdamW([p for _, p in T.legacy_trainable_parameters(model)], lr=2e-4)
+    first = x_engine.train_epoch(model, [batch], opt, dev, clip=1.0)
+    for _ in range(3):
+        last = x_engine.train_epoch(model, [batch], opt, dev, clip=1.0)
+    assert last < first - 0.05, (first, last)
+    after = model.state_dict()
+    for k in before:
+        changed = not torch.equal(before[k], after[k])
+        if k.startswith(("speaker_vq.", "listener_vq.encoder.", "listener_vq.quantize.", "speaker_embeddings.", "fc_speaker.")):
+            assert not changed, k            # frozen, or without a gradient when speaker_ids is None
+        elif k.startswith(("generator.decoder.net.attn_layers", "listener_vq.decoder.decoder_transformer", "fc_listener.")):
+            assert changed, k
+    model.eval()
+    tok1, _ = model.generate(v_s.to(dev), v_l.to(dev), mask.to(dev), greedy=True)
+    assert tok1.shape == tok0.shape and not torch.equal(tok1, tok0)       # the engine sees the trained weights
+
+
 def test_fullsize_properties_B64_T300(legacy_sd):
     """size-independent properties at the C3 sequence length: batch / shard invariance of the generated tokens,
     determinism of the seeded sampler, KV-cached generation == teacher-forced logits (f32 parity mode)."""

@@ -133,3 +133,52 @@ def test_hip_training_reduces_the_loss_and_bf16_mode_agrees():
     rel = ((tb.grads - tf.grads).norm() / tf.grads.norm()).item()
     print("bf16 training step: loss %.5f vs f32 %.5f, relative gradient difference %.3f" % (lb, lf, rel))
     assert abs(lb - lf) < 2e-2 and rel < 0.05
+
+
+def _attend_reference(q, k, v, d_o, scale, causal, kmask, kmask2, H):
+    """x-transformers' Attend in float64 with autograd: masked_fill(-max of float32) before the softmax."""
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    with torch.enable_grad():
+        q, k, v = (t.double().detach().requires_grad_(True) for t in (q, k, v))
+        sp = lambda t, n: t.view(B, n, H, 64).transpose(1, 2)
+        dots = torch.matmul(sp(q, Lq), sp(k, Lk).transpose(-1, -2)) * scale
+        keep = torch.ones(B, 1, Lq, Lk, dtype=torch.bool, device=q.device)
+        if causal:
+            keep = keep & torch.ones(Lq, Lk, dtype=torch.bool, device=q.device).tril()
+        for m in (kmask, kmask2):
+            if m is not None:
+                keep = keep & m.bool()[:, None, None, :]
+        dots = dots.masked_fill(~keep, -torch.finfo(torch.float32).max)
+        o = torch.matmul(dots.softmax(-1), sp(v, Lk)).transpose(1, 2).reshape(B, Lq, H * 64)
+        o.backward(d_o.double())
+    return o.detach(), q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 70, 70, True, True), (2, 2, 299, 300, False, False), (1, 12, 300, 300, True, False),
+                                   (3, 2, 33, 129, False, True), (2, 1, 128, 64, True, True)])
+def test_training_attention_on_the_matrix_cores_matches_attend_and_its_adjoint(shape):
+    """train_attn.hip (bf16 MFMA, the perf mode's attention) and the f32 kernels against autograd over Attend in float64:
+    forward, dQ, dK, dV; causal / padding / mask_prob key masks, ragged tile edges (Lq, Lk not multiples of 32 / 64)."""
+    from dimx import engine as E
+    from dimx import prng
+    B, H, Lq, Lk, causal, masked = shape
+    dev = torch.device("cuda:0")
+    g = lambda name, n: torch.from_numpy(prng.normal(31, name, (B, n, H * 64))).to(dev)
+    q, k, v, d_o = g("ta.q", Lq), g("ta.k", Lk), g("ta.v", Lk), g("ta.do", Lq)
+    kmask = kmask2 = None
+    if masked:
+        kmask = torch.ones(B, Lk, dtype=torch.bool, device=dev)
+        kmask[-1, Lk - Lk // 4:] = False
+        kmask2 = torch.from_numpy(prng.integers(31, "ta.m2", (B, Lk), 0, 8)).to(dev) != 0
+        kmask2[:, 0] = True                      # AutoregressiveWrapper never drops the first token
+    scale = 0.125
+    ro, rq, rk, rv = _attend_reference(q, k, v, d_o, scale, causal, kmask, kmask2, H)
+    for mfma, tol in ((False, 2e-5), (True, 1e-2)):
+        o, lse, dq, dk, dv = E.op_train_attention(q, k, v, scale, d_o=d_o, causal=causal, kmask=kmask, kmask2=kmask2, mfma=mfma)
+        for name, got, ref in (("o", o, ro), ("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+            err = ((got.double() - ref).norm() / ref.norm()).item()
+            worst = ((got.double() - ref).abs().max() / ref.abs().max()).item()
+            print("train attention %s mfma=%d %s: relative error %.2e (max-norm %.2e)" % (shape, mfma, name, err, worst))
+            assert torch.isfinite(got).all()
+            assert err < tol and worst < 4 * tol, (name, mfma, err, worst)

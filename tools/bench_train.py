@@ -1,6 +1,6 @@
 """Wall time of the hand-written HIP training step (dimx.train_hip.HipTrainer: forward + backward + clip + AdamW) next to the
 PyTorch-autograd restatement it replaced (dimx.train, rocBLAS / hipBLASLt + autograd), same model, same batch.
-    python tools/bench_train.py [B=16] [T=300] [steps=5]
+    python tools/bench_train.py [B=16] [T=300] [steps=5] [which=all|bf16|f32|hip]
 """
 import sys
 import time
@@ -18,6 +18,7 @@ from dimx.train_hip import HipTrainer
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 Tn = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+which = sys.argv[4] if len(sys.argv) > 4 else "all"
 dev = torch.device("cuda:0")
 v_s = torch.from_numpy(prng.normal(1, "bt.vs", (B, Tn, 56))).to(dev)
 v_l = torch.from_numpy(prng.normal(1, "bt.vl", (B, Tn, 56))).to(dev)
@@ -36,6 +37,8 @@ def timed(fn):
 
 
 for mode, name in ((L.MODE_PERF_BF16, "bf16"), (L.MODE_PARITY_F32, "f32")):
+    if which not in ("all", "hip", name):
+        continue
     m = SLMFT(numeric_mode=mode).to(dev)
     with torch.no_grad():
         _, z = m.forward_vq(v_s, v_l, mask, with_speaker=False)
@@ -44,6 +47,8 @@ for mode, name in ((L.MODE_PERF_BF16, "bf16"), (L.MODE_PARITY_F32, "f32")):
     print("HIP training step  %-4s B=%d T=%d: %8.1f ms  (%.1f clips/s)" % (name, B, Tn, ms, B / ms * 1e3), flush=True)
     del tr, m
     torch.cuda.empty_cache()
+if which != "all":
+    sys.exit(0)
 m = SLMFT().to(dev)
 m.train()
 with torch.no_grad():
