@@ -595,7 +595,16 @@ static int train_run(dimx_handle h, const float* params, float* grads, const flo
         DIMX_TRY(attn_bwd(s, ca[i], dh, dctx));
         DIMX_TRY(attn_bwd(s, sa[i], dh, nullptr));
     }
-    TR(tr_embedding_bwd(inp, dh, s.g(dn + "token_emb.emb.weight"), s.Md, DD, d.num_tokens, st));
+    {   // d token_emb = onehot(inp)^T . dh on the library GEMM
+        const size_t mark = s.ar->off;
+        const int Mp = pad_to(s.Md, s.bk);
+        void* ohT = s.take((size_t)d.num_tokens * Mp * s.es());
+        void* dhT = s.take((size_t)DD * Mp * s.es());
+        TR(tr_onehot_t(s.at, inp, ohT, Mp, s.Md, d.num_tokens, st));
+        TR(tr_transpose_pad(s.at, dh, DD, dhT, Mp, s.Md, DD, st));
+        TR(gemm_f32(s, ohT, Mp, dhT, d.num_tokens, DD, Mp, s.g(dn + "token_emb.emb.weight"), DD, nullptr, nullptr, 0));
+        s.ar->off = mark;
+    }
     // context -> x_s (+ patch_embed_dec_s) ; the audio half has no parameters behind it
     TR(tr_copy_cols(dctx, DD, dx_s, d.dim, s.M, d.dim, 0, st));
     TR(tr_colsums(nullptr, dx_s, nullptr, s.g("patch_embed_dec_s"), s.M, d.dim, s.part, 0, st));

@@ -35,7 +35,7 @@ int tr_zero_rows(float* y, const uint8_t* keep, int M, int C, hipStream_t s);
 int tr_copy_cols(const float* src, int lds_, float* dst, int ldd, int M, int C, int accumulate, hipStream_t s);
 int tr_pos_grad(const float* dx, float* dtable, int B, int T, int C, float scale, hipStream_t s);
 int tr_cross_entropy(const float* logits, const int32_t* target, float* row_loss, float* dlogits, int R, float* loss_out, hipStream_t s);
-int tr_embedding_bwd(const int32_t* tokens, const float* dx, float* dtable, int M, int C, int rows, hipStream_t s);
+int tr_onehot_t(int out_dtype, const int32_t* tokens, void* out, int ld_out, int M, int rows, hipStream_t s);
 int tr_grad_norm(const float* g, long n, float max_norm, float* part, float* norm_out, hipStream_t s);
 int tr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
              const float* clip, hipStream_t s);

@@ -98,6 +98,10 @@ class ListenerGenerator(_EngineOwner):
         self.listener_vq.eval()
         return self
 
+    def dimx_trainable_parameters(self):
+        from . import train as T
+        return T.legacy_trainable_parameters(self)
+
     def _wants_grad(self):
         return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 

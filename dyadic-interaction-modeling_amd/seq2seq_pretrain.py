@@ -175,6 +175,10 @@ class SLMFT(_EngineOwner):
         return _masked_pairwise_loss(pred, target[:, 1:, :], mask[:, 1:])
 
     # ------------------------------------------------------------------ training
+    def dimx_trainable_parameters(self):
+        from . import train as T
+        return T.trainable_parameters(self)
+
     def _wants_grad(self, mode):
         return (mode == "train" and self.training and torch.is_grad_enabled()
                 and any(p.requires_grad for p in self.parameters()))
@@ -274,7 +278,9 @@ class SLM(_EngineOwner):
     dict entries.  The random frame masks of ``random_masking_unstructured`` (:170-183) are injectable
     (``mask_speaker`` / ``mask_listener`` bool [B,T], True = masked); by default they are drawn like the reference.
     The InfoNCE term (:270-289) is a handful of [B,384] torch ops on the engine's encoder outputs.
-    Backward / optimiser steps are out of scope."""
+    In training (``model.train()``, grad enabled, parameters requiring grad -- what ``x_engine_pt.train_epoch`` sets up for
+    code/train_s2s_pretrain.py:41-64) the loss carries an autograd graph (``dimx.train.slm_loss``; the frozen VQ encoders
+    run on the HIP engine); everything else is the HIP inference path."""
     engine_variant = "slm"
 
     def __init__(self, config_path=None, vq_speaker_ckpt=None, vq_listener_ckpt=None, synthetic_seed=20260928,
@@ -360,10 +366,44 @@ class SLM(_EngineOwner):
     def forward_continuous_loss(self, pred, target, mask):
         return _masked_pairwise_loss(pred, target[:, 1:, :], mask[:, 1:])
 
-    @torch.no_grad()
+    # ------------------------------------------------------------------ training
+    def dimx_trainable_parameters(self):
+        from . import train as T
+        return T.slm_trainable_parameters(self)
+
+    def train(self, mode=True):
+        """nn.Module.train with both VQ-VAEs kept in eval (reference :96, :105)."""
+        super().train(mode)
+        self.speaker_vq.eval()
+        self.listener_vq.eval()
+        return self
+
+    def _forward_autograd(self, v_speaker, v_listener, v_audio, mask, mask_ratio=0.15, mask_speaker=None, mask_listener=None,
+                          z_s=None, z_l=None):
+        from . import train as T
+        mask = mask.bool()
+        if z_s is None or z_l is None:
+            z_s, z_l = self.forward_vq(v_speaker, v_listener, mask)
+        if mask_speaker is None:
+            mask_speaker = self.random_masking_unstructured(v_speaker, mask, mask_ratio)
+        if mask_listener is None:
+            mask_listener = self.random_masking_unstructured(v_listener, mask, mask_ratio)
+        total, d = T.slm_loss(dict(self.named_parameters()), self.s2s, self.vq_dims, v_speaker.float(), v_listener.float(),
+                              v_audio.float(), mask, mask_speaker.bool(), mask_listener.bool(), z_s.long(), z_l.long(),
+                              self.speaker_vq.decoder.decoder_pos_embedding.pe, self.listener_vq.decoder.decoder_pos_embedding.pe)
+        return total, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}, None
+
     def forward(self, v_speaker, v_listener, v_audio, mask, speaker_ids=None, listener_ids=None, mode="train",
-                mask_speaker=None, mask_listener=None, return_aux=False):
+                mask_speaker=None, mask_listener=None, return_aux=False, z_s=None, z_l=None):
         """reference :300-323 -> (total_loss, d, None)."""
+        if (self.training and torch.is_grad_enabled() and not return_aux
+                and any(p.requires_grad for p in self.parameters())):
+            return self._forward_autograd(v_speaker, v_listener, v_audio, mask, mask_speaker=mask_speaker,
+                                          mask_listener=mask_listener, z_s=z_s, z_l=z_l)
+        with torch.no_grad():
+            return self._forward_nograd(v_speaker, v_listener, v_audio, mask, mask_speaker, mask_listener, return_aux)
+
+    def _forward_nograd(self, v_speaker, v_listener, v_audio, mask, mask_speaker=None, mask_listener=None, return_aux=False):
         mask = mask.bool()
         eng = self.engine(v_speaker.device)
         z_s, z_l = self.forward_vq(v_speaker, v_listener, mask)

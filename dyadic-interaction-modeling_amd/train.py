@@ -201,6 +201,69 @@ def legacy_loss(P, dims, vq_dims, x_speaker, z_l, v_listener, mask, pe, speaker_
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# SLM pre-training (reference code/seq2seq_pretrain.py:72-323) -- what code/train_s2s_pretrain.py:41-64 trains with
+# x_engine_pt.train_epoch
+# ---------------------------------------------------------------------------------------------------------------------
+SLM_FROZEN_PREFIXES = ("speaker_vq.encoder.", "speaker_vq.quantize.", "listener_vq.encoder.", "listener_vq.quantize.")
+
+
+def slm_trainable_parameters(model):
+    """reference :98-113: both VQ-VAEs' encoders and codebooks are frozen, their DECODERS and everything else train."""
+    return [(n, p) for n, p in model.named_parameters() if not n.startswith(SLM_FROZEN_PREFIXES)]
+
+
+def set_slm_trainable(model, flag=True):
+    for _, p in slm_trainable_parameters(model):
+        p.requires_grad_(flag)
+    return model
+
+
+def _masked_pairwise(pred, target, sel):
+    m = sel[:, 1:].reshape(-1)
+    p = pred.reshape(-1, pred.shape[-1])[m]
+    t = target[:, 1:].reshape(-1, pred.shape[-1])[m]
+    return F.pairwise_distance(p[:, 6:], t[:, 6:]).mean() + F.pairwise_distance(p[:, :6], t[:, :6]).mean()
+
+
+def slm_loss(P, dims, vq_dims, v_speaker, v_listener, v_audio, mask, mask_speaker, mask_listener, z_s, z_l, pe_s, pe_l):
+    """Differentiable ``SLM.forward`` (reference :300-323): masked speaker / listener streams through encoder_s / encoder_l
+    (bidirectional, key padding), the joint encoder over the 2T concatenation and over each stream alone (:200-221), InfoNCE
+    between the clip means (:270-289), the two cross-predicting decoders with absolute positional embedding (z_s from the
+    listener half of x_joint, z_l from the speaker half, :223-243), and the continuous losses of the decoded arg-max codes,
+    which train the two VQ-VAE DECODERS.  z_s / z_l [B,T]: codes from the frozen VQ encoders (HIP engine), unmasked;
+    mask_speaker / mask_listener: True = masked frame (its code is a target).  Returns (total, dict)."""
+    depth, heads = dims.enc_depth, dims.heads
+    vs = (v_speaker + P["patch_embed_s"]).masked_fill(mask_speaker[..., None], 0.0)
+    vl = (v_listener + P["patch_embed_l"]).masked_fill(mask_listener[..., None], 0.0)
+    x_s = xt_encoder(P, "encoder_s.", vs, mask, False, depth, heads)
+    x_l = xt_encoder(P, "encoder_l.", vl, mask, False, depth, heads)
+    x_joint = xt_encoder(P, "encoder_joint.", torch.cat([x_s, x_l], dim=1), torch.cat([mask, mask], dim=-1), False, depth, heads)
+    x_l = xt_encoder(P, "encoder_joint.", x_l, mask, False, depth, heads)
+    x_s = xt_encoder(P, "encoder_joint.", x_s, mask, False, depth, heads)
+    x_s, x_l = _ln(x_s, P["norm_s.weight"], P["norm_s.bias"]), _ln(x_l, P["norm_l.weight"], P["norm_l.bias"])
+    x_joint = _ln(x_joint, P["norm.weight"], P["norm.bias"])
+    valid = mask[..., None].to(x_s.dtype)
+    n = valid.sum(1)
+    s = F.normalize((x_s * valid).sum(1) / n, dim=-1)
+    l_ = F.normalize((x_l * valid).sum(1) / n, dim=-1)
+    total = s @ l_.t() / 0.05
+    nce = -torch.mean(torch.diag(F.log_softmax(total, dim=0)))
+    c_acc = (F.softmax(total.detach(), dim=0).argmax(0) == torch.arange(total.shape[0], device=total.device)).sum() / total.shape[0]
+    T = mask.shape[1]
+    out = {}
+    for tag, z, msk, xj, patch, vq, pe, tgt in (("s", z_s, mask_speaker, x_joint[:, T:], "patch_embed_dec_l", "speaker_vq.", pe_s, v_speaker),
+                                                ("l", z_l, mask_listener, x_joint[:, :T], "patch_embed_dec_s", "listener_vq.", pe_l, v_listener)):
+        z = torch.where(msk, z, torch.full_like(z, -100))
+        ctx = torch.cat([xj + P[patch], v_audio], dim=-1)
+        logits = xt_decoder_logits(P, "decoder_joint.net.", z[:, :-1].clamp(min=0), ctx, mask, None, dims.dec_depth, heads, pos_emb=True)
+        out["l_ce_" + tag] = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), z[:, 1:].reshape(-1), ignore_index=-100)
+        pred = vq_decoder(P, vq, P[vq + "quantize.embedding.weight"][logits.argmax(-1)], vq_dims.heads, vq_dims.layers, pe)
+        out["l_cont_" + tag] = _masked_pairwise(pred, tgt, msk)
+    out["nce"], out["c_acc"] = nce, c_acc
+    return out["l_ce_s"] + out["l_ce_l"] + out["l_cont_s"] + out["l_cont_l"] + nce, out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # gradient synchronisation
 # ---------------------------------------------------------------------------------------------------------------------
 def all_reduce_grads(params, bucket_bytes=64 << 20):

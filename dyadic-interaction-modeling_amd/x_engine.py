@@ -86,8 +86,9 @@ def _train_loop(model, loader, optimizer, device, scheduler, clip, print_freq, e
     losses, seen = [], []
     for i, batch in enumerate(loader):
         optimizer.zero_grad()
-        loss = step_loss(batch)
-        loss.mean().backward()
+        with torch.enable_grad():        # a training loop differentiates whatever the caller's ambient grad mode is
+            loss = step_loss(batch)
+            loss.mean().backward()
         T.all_reduce_grads(params)
         if clip > 0:
             torch.nn.utils.clip_grad_norm_(params, clip)

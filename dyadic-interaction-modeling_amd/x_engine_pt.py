@@ -210,8 +210,12 @@ def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, prin
     if isinstance(optimizer, HipTrainer):
         return _train_epoch_hip(model, loader, optimizer, device, scheduler, print_freq, epoch, log)
     model.train()
-    T.set_trainable(model, True)
-    params = [p for _, p in T.trainable_parameters(model)]
+    inner = getattr(model, "module", model)
+    # what the reference trains differs per model: SLMFT freezes both VQ-VAEs (:348-366), SLM only their encoders + codebooks (:98-113)
+    named = inner.dimx_trainable_parameters() if hasattr(inner, "dimx_trainable_parameters") else T.trainable_parameters(model)
+    for _, p in named:
+        p.requires_grad_(True)
+    params = [p for _, p in named]
     if ddist.world_size() > 1:
         if hasattr(loader, "__len__"):
             T.assert_same_batch_count(len(loader), device if torch.device(device).type == "cuda" else None)

@@ -73,3 +73,56 @@ def test_slm_default_masks_and_bf16(slm_sd):
     m = SLM().cuda()
     total, d, _ = m(v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda())
     assert torch.isfinite(total) and 0.0 <= float(d["c_acc"]) <= 1.0
+
+
+def test_slm_training_forward_and_train_epoch(slm_sd):
+    """SLM in training (what code/train_s2s_pretrain.py:41-64 runs through x_engine_pt.train_epoch): the autograd forward
+    (frozen VQ encoders on the HIP engine) reports the losses of the HIP inference forward on the same masks, its gradients
+    are autograd's over the oracle, and AdamW steps through train_epoch lower the loss and leave the frozen parts alone."""
+    from dimx import train as T
+    from dimx import x_engine_pt
+    from dimx.seq2seq_pretrain import SLM
+    from oracle import ref_cpu
+    dev = torch.device("cuda:0")
+    v_s, v_l, v_a, mask, ms, ml = _case(3, 40, [40, 33, 12])
+    m = SLM().to(dev)
+    ref_total, ref_d, _ = m(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mask_speaker=ms.to(dev), mask_listener=ml.to(dev))
+    T.set_slm_trainable(m)
+    m.train()
+    with torch.enable_grad():
+        total, d, none = m(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mask_speaker=ms.to(dev), mask_listener=ml.to(dev))
+        assert none is None and total.requires_grad
+        total.backward()
+        trainable = lambda k: not k.startswith(T.SLM_FROZEN_PREFIXES) and not k.endswith(".pe")
+        sd = {k: v.detach().clone().requires_grad_(trainable(k)) for k, v in slm_sd.items()}
+        o_total, _, _ = ref_cpu.slm_forward(sd, v_s, v_l, v_a, mask, ms, ml)
+        o_total.backward()
+    for k in ("l_ce_s", "l_ce_l", "l_cont_s", "l_cont_l", "nce"):
+        assert abs(float(d[k]) - float(ref_d[k])) < 1e-3 * max(1.0, abs(float(ref_d[k]))), k
+    assert abs(total.item() - o_total.item()) < 1e-4 * abs(o_total.item())
+    worst = 0.0
+    for k, p in m.named_parameters():
+        g_o = sd[k].grad
+        if g_o is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        rel = (p.grad.cpu() - g_o).abs().max().item() / max(g_o.abs().max().item(), 1e-8)
+        worst = max(worst, rel)
+        assert rel < 1e-3, (k, rel)
+    print("SLM training forward: worst relative gradient error vs autograd over the oracle %.2e" % worst)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    src = torch.cat([v_s, v_a], dim=-1)
+    batch = (src, v_l, [40, 33, 12], None, None)
+    opt = torch.optim.AdamW([p for _, p in T.slm_trainable_parameters(m)], lr=1e-4)
+    with torch.enable_grad():
+        first = x_engine_pt.train_epoch(m, [batch], opt, dev, clip=1.0, log=lambda *_: None)
+        for _ in range(3):
+            last = x_engine_pt.train_epoch(m, [batch], opt, dev, clip=1.0, log=lambda *_: None)
+    assert last < first, (first, last)
+    after = m.state_dict()
+    for k in before:
+        changed = not torch.equal(before[k], after[k])
+        if k.startswith(T.SLM_FROZEN_PREFIXES):
+            assert not changed, k
+        elif k.startswith(("encoder_l.attn_layers", "decoder_joint.net.attn_layers", "speaker_vq.decoder.decoder_transformer")):
+            assert changed, k

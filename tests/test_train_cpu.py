@@ -149,3 +149,73 @@ def test_adamw_steps_reduce_the_loss_and_keep_the_vq_frozen():
     # inference mode keeps working as before: eval() -> no graph requested
     m.eval()
     assert not m._wants_grad("train")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SLM pre-training loss (reference code/seq2seq_pretrain.py:300-323; code/train_s2s_pretrain.py trains it with train_epoch)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_slm_pretraining_gradients_match_autograd_over_the_oracle():
+    """dimx.train.slm_loss (what SLM.forward returns in training) against torch autograd over the oracle's slm_forward:
+    total loss, its five terms and the gradient of every trainable tensor (both VQ decoders included) <= 1e-3 relative."""
+    sys.path.insert(0, ROOT)
+    import dimx  # noqa: F401
+    from dimx import prng, weights as W
+    from dimx import train as T
+    from oracle import ref_cpu
+    B, Tn = 3, 24
+    v_s = torch.from_numpy(prng.normal(11, "slmtr.vs", (B, Tn, 56)))
+    v_l = torch.from_numpy(prng.normal(11, "slmtr.vl", (B, Tn, 56)))
+    v_a = torch.from_numpy(prng.normal(11, "slmtr.va", (B, Tn, 768)))
+    mask = torch.ones(B, Tn, dtype=torch.bool)
+    mask[1, 17:] = False
+    g = torch.Generator().manual_seed(5)
+    ms = ref_cpu.slm_random_masks(mask, 0.3, g)
+    ml = ref_cpu.slm_random_masks(mask, 0.3, g)
+    sd0 = W.synth_state_dict(W.slm_spec(), 20260928)
+    trainable = lambda k: not k.startswith(T.SLM_FROZEN_PREFIXES) and sd0[k].dtype.is_floating_point and not k.endswith(".pe")
+    with torch.enable_grad():
+        sd = {k: v.detach().clone().requires_grad_(trainable(k)) for k, v in sd0.items()}
+        o_total, o_d, _ = ref_cpu.slm_forward(sd, v_s, v_l, v_a, mask, ms, ml)
+        o_total.backward()
+        z_s, z_l = ref_cpu.forward_vq(sd0, v_s, v_l, mask)
+        P = {k: v.detach().clone().requires_grad_(trainable(k)) for k, v in sd0.items()}
+        total, d = T.slm_loss(P, W.S2SDims(), W.VQDims(), v_s, v_l, v_a, mask, ms, ml, z_s, z_l,
+                              P["speaker_vq.decoder.decoder_pos_embedding.pe"], P["listener_vq.decoder.decoder_pos_embedding.pe"])
+        total.backward()
+    for k in ("l_ce_s", "l_ce_l", "l_cont_s", "l_cont_l", "nce"):
+        assert abs(float(d[k].detach()) - float(o_d[k].detach())) <= 1e-5 * max(1.0, abs(float(o_d[k].detach()))), k
+    assert float(d["c_acc"]) == float(o_d["c_acc"])
+    assert abs(total.item() - o_total.item()) <= 1e-5 * abs(o_total.item())
+    checked = 0
+    for k in P:
+        if not trainable(k):
+            continue
+        g_o = sd[k].grad
+        if g_o is None:
+            assert P[k].grad is None or float(P[k].grad.abs().max()) == 0.0, k
+            continue
+        assert P[k].grad is not None, k
+        scale = g_o.abs().max().item()
+        assert (P[k].grad - g_o).abs().max().item() <= 1e-3 * max(scale, 1e-8), k
+        checked += 1
+    assert checked > 250
+    for k in ("speaker_vq.decoder.vertice_map_reverse.weight", "listener_vq.decoder.vertice_map_reverse.weight",
+              "encoder_l.project_in.weight", "patch_embed_dec_l", "norm.weight"):
+        assert P[k].grad.abs().max() > 0, k
+
+
+def test_train_epoch_picks_each_models_trainable_set():
+    """x_engine_pt.train_epoch asks the module what the reference trains for it (SLMFT: both VQ-VAEs frozen; SLM: only their
+    encoders and codebooks)."""
+    sys.path.insert(0, ROOT)
+    import dimx  # noqa: F401
+    from dimx.seq2seq import ListenerGenerator
+    from dimx.seq2seq_pretrain import SLM, SLMFT
+    names = lambda m: {n for n, _ in m.dimx_trainable_parameters()}
+    slmft, slm, leg = names(SLMFT()), names(SLM()), names(ListenerGenerator())
+    assert not any(n.startswith(("speaker_vq.", "listener_vq.")) for n in slmft)
+    assert "listener_vq.decoder.vertice_map_reverse.weight" in slm and "speaker_vq.decoder.vertice_map_reverse.weight" in slm
+    assert not any(n.startswith(("speaker_vq.encoder.", "listener_vq.quantize.")) for n in slm)
+    assert "encoder_l.project_in.weight" in slm
+    assert "listener_vq.decoder.vertice_map_reverse.weight" in leg and "fc_listener.weight" in leg
+    assert not any(n.startswith("speaker_vq.") for n in leg)
