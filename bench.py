@@ -9,7 +9,9 @@ indices are all-gathered (RCCL over xGMI) inside the timed region.
 
 N = 1 workload = BASELINE config C3 (B=256, T=300, autoregressive decode, bf16 perf mode).
 Extra objects on the line: ``roofline`` (dominant kernel, timed live with HIP events) and ``cpu_baseline``
-(the CPU oracle on a bounded sample of the same workload, rank 0 at N=1 only).
+(the CPU oracle on a bounded sample of the same workload, rank 0 at N=1 only); beside them ``parity_mode`` (the same
+workload in the f32 mode), ``cross_attn_mfma`` (the K/V projection GEMM) and ``train_step`` (the HIP training step of
+SURVEY 8 row f3, B=16) -- all measured outside the timed region of ``value``.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--frames 300] [--mode bf16|f32]
 """
@@ -125,6 +127,33 @@ def cpu_baseline(T, timeout_s=300):
                 "sample": "cpu worker exceeded %d s on 8 clips x T=%d" % (timeout_s, T)}
 
 
+def train_step_line(device, T, B=16, warm=2, steps=8):
+    """SURVEY 8 row f3 next to the headline: one optimisation step of SLMFT (forward + backward + clip 1.0 + AdamW, the
+    reference's train_epoch body, code/x_engine_pt.py:9-60) on the hand-written HIP training step, bf16 operands with f32
+    accumulation and f32 master weights; B clips of T frames, listener codes from the frozen VQ-VAE precomputed (they do
+    not depend on the trained weights).  Reported beside the metric, never part of ``value``."""
+    from dimx.train_hip import HipTrainer
+    torch.cuda.empty_cache()
+    m = SLMFT(synthetic_seed=SEED, numeric_mode=L.MODE_PERF_BF16).to(device)
+    v_s, v_l, v_a, mask = synth_batch(B, T, device, salt=7)
+    _, z = m.forward_vq(v_s, v_l, mask, with_speaker=False)
+    tr = HipTrainer(m, lr=1e-5, clip=1.0)
+    for _ in range(warm):
+        tr.train_step(v_s, v_l, v_a, mask, kv_mask=False, z_l=z)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step(v_s, v_l, v_a, mask, kv_mask=False, z_l=z)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(loss)
+    del tr, m
+    torch.cuda.empty_cache()
+    return {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "batch": B, "frames": T, "dtype": "bf16", "steps": steps,
+            "warmup": warm, "note": "SLMFT training step (forward + backward + clip + AdamW) on the HIP kernels of "
+                                    "csrc/train*.hip; PyTorch autograd on rocBLAS for the same step: tools/bench_train.py"}
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
         _cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
@@ -140,6 +169,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true")
     args = ap.parse_args()
 
     rank, world, local = ddist.init_from_env()
@@ -224,6 +254,8 @@ def main():
         from dimx import roofline
         out["roofline"] = roofline.dominant_kernel(eng, B, T, args.mode)
         out["cross_attn_mfma"] = roofline.cross_kv_gemm(B, T, args.mode, device)
+    if world == 1 and args.mode == "bf16" and not args.no_train_step and args.samples == 1:
+        out["train_step"] = train_step_line(device, T)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T)
     print(json.dumps(out))

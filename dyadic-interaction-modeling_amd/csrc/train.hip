@@ -140,6 +140,7 @@ struct Step {
     int B, T, M, n, Md;
 
     size_t peak = 0;  // high-water mark of the arena: the sizing pass (ws == NULL) walks the same allocation sequence
+    PrepTable prep;   // weight operand copies queued by prep_lin, made by ONE launch in flush_prep
 
     bool live() const { return ar->base != nullptr; }
     size_t es() const { return dtype_size(at); }
@@ -171,12 +172,29 @@ Lin make_lin(const Step& s, const std::string& wname, const std::string& bname =
 }
 
 // operand copies of a weight for this step: [N][Kp] and its transpose [K][Np]
+int flush_prep(Step& s) {
+    if (s.live() && s.prep.n > 0) DIMX_TRY(tr_prep_weights(s.at, s.prep, s.st));
+    s.prep.n = 0;
+    s.prep.total_tiles = 0;
+    return DIMX_OK;
+}
+// queued: the copies exist after the next flush_prep (every *_prepare group ends with one)
 int prep_lin(Step& s, Lin& l) {
     const int Kp = pad_to(l.K, s.bk), Np = pad_to(l.N, s.bk);
     l.w_op = s.take((size_t)l.N * Kp * s.es());
     l.wt_op = s.take((size_t)l.K * Np * s.es());
-    TR(launch_cast_pad(s.at, s.P + l.w, l.K, nullptr, l.w_op, Kp, l.N, l.K, s.st));
-    TR(tr_transpose_pad(s.at, s.P + l.w, l.K, l.wt_op, Np, l.N, l.K, s.st));
+    if (s.prep.n == kPrepMax) DIMX_TRY(flush_prep(s));
+    PrepDesc& d = s.prep.d[s.prep.n++];
+    d.src = s.P + l.w;
+    d.w = l.w_op;
+    d.wt = l.wt_op;
+    d.N = l.N;
+    d.K = l.K;
+    d.Kp = Kp;
+    d.Np = Np;
+    d.tile0 = s.prep.total_tiles;
+    d.tiles_k = ceil_div(Kp, 32);
+    s.prep.total_tiles += ceil_div(Np, 32) * d.tiles_k;
     return DIMX_OK;
 }
 
@@ -423,6 +441,7 @@ int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int 
         DIMX_TRY(attn_prepare(s, e.attn[i], pre + "attn_layers.layers." + std::to_string(2 * i) + "."));
         DIMX_TRY(ff_prepare(s, e.ff[i], pre + "attn_layers.layers." + std::to_string(2 * i + 1) + "."));
     }
+    DIMX_TRY(flush_prep(s));
     e.h.assign(2 * d.enc_depth + 1, nullptr);
     for (auto& p : e.h) p = s.f32((size_t)M * C);
     e.out = s.f32((size_t)M * C);
@@ -519,6 +538,8 @@ static int train_run(dimx_handle h, const float* params, float* grads, const flo
     s.M = B * T;
     s.n = T - 1;
     s.Md = B * (T - 1);
+    s.prep.n = 0;
+    s.prep.total_tiles = 0;
     const int DD = d.dim + d.dim_a, F = DD * d.ff_mult, inner = d.heads * d.dim_head;
     s.part = s.f32((size_t)2 * kTrSlabs * F);
     const bool live = ws != nullptr;
@@ -551,6 +572,7 @@ static int train_run(dimx_handle h, const float* params, float* grads, const flo
     }
     Lin lg = make_lin(s, dn + "to_logits.weight");
     DIMX_TRY(prep_lin(s, lg));
+    DIMX_TRY(flush_prep(s));
     std::vector<float*> hd(3 * d.dec_depth + 1);
     for (auto& p : hd) p = s.f32((size_t)s.Md * DD);
     TR(launch_gather_rows(DIMX_F32, s.p(dn + "token_emb.emb.weight"), DD, d.num_tokens, inp, hd[0], DD, s.Md, DD, st));

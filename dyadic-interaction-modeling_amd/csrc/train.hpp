@@ -16,6 +16,23 @@ struct TrAttn {
     int mfma;                // 1: the bf16 matrix-core kernels of train_attn.hip (perf mode), 0: the f32 VALU kernels (parity mode)
 };
 
+// operand copies of up to kPrepMax weight matrices in ONE launch: for each [N][K] f32 source the cast [N][Kp] (zero columns
+// K..Kp) and the transposed cast [K][Np] (zero columns N..Np)
+constexpr int kPrepMax = 64;
+struct PrepDesc {
+    const float* src;
+    void* w;
+    void* wt;
+    int N, K, Kp, Np;
+    int tile0;    // first 32 x 32 tile of this matrix in the launch
+    int tiles_k;  // tiles along K
+};
+struct PrepTable {
+    PrepDesc d[kPrepMax];
+    int n;
+    int total_tiles;
+};
+int tr_prep_weights(int out_dtype, const PrepTable& t, hipStream_t s);
 int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s);
 int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
 int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
