@@ -71,6 +71,19 @@ def evaluate_epoch(model, loader, device, generate_kw=None, verbose=True):
     return ppl
 
 
+def evaluate_continuous_epoch(model, loader, device, verbose=True):
+    """reference code/x_engine.py:90-105: mean of ``model(src, tgt, mask)`` (a model that returns its loss alone)."""
+    model.eval()
+    losses = []
+    with torch.no_grad():
+        for batch in loader:
+            src, tgt, src_len = batch[0].to(device), batch[1].to(device), batch[2]
+            losses.append(float(model(src, tgt, _mask_from_lens(src, src_len, device)).mean().item()))
+    if verbose:
+        print("Validation: Loss {loss:.4f}\t".format(loss=np.mean(losses)))
+    return float(np.mean(losses)) if losses else float("nan")
+
+
 def _train_loop(model, loader, optimizer, device, scheduler, clip, print_freq, epoch, step_loss):
     """Loop body shared by the two reference loops: zero_grad, loss.mean().backward(), clip_grad_norm_, step, scheduler,
     running mean printed every ``print_freq`` batches (reference code/x_engine.py:14-36, :40-62).  N > 1: gradients are

@@ -34,6 +34,28 @@ def _prepare(batch, device):
     return src_s_v.contiguous(), src_s_a.contiguous(), tgt, mask, list(src_len), data_ids
 
 
+def evaluate_epoch(model, loader, device, log=print):
+    """reference code/x_engine_pt.py:134-165 (the validation pass of code/train_s2s_pretrain.py:60): mean of
+    ``model(src_s_v, tgt, src_s_a, mask)[0]`` over the loader; the six loss terms averaged over the batches are printed."""
+    model.eval()
+    losses = []
+    d = {k: 0.0 for k in ("l_ce_s", "l_ce_l", "l_cont_s", "l_cont_l", "nce", "c_acc")}
+    n = 0
+    with torch.no_grad():
+        for batch in loader:
+            src_s_v, src_s_a, tgt, mask, _, _ = _prepare(batch, device)
+            loss, d_step, _ = model(src_s_v, tgt, src_s_a, mask)
+            losses.append(float(loss.mean().item()))
+            for k in d:
+                v = d_step.get(k, 0)
+                d[k] += float(v.mean().item()) if torch.is_tensor(v) else float(v)
+            n += 1
+    for k in d:
+        d[k] /= max(n, 1)
+    log(d)
+    return float(np.mean(losses)) if losses else float("nan")
+
+
 def evaluate_finetune_epoch(model, loader, device):
     """reference code/x_engine_pt.py:201-230 (teacher-forced forward, mode='train')."""
     y_trues_all, y_preds_all, x_all, data_ids_all = [], [], [], []

@@ -184,7 +184,8 @@ def main():
     print(json.dumps(report, indent=1, sort_keys=True))
 
 
-if __name__ == "__main__" and "--legacy" not in sys.argv and "--mymetrics" not in sys.argv and "--postprocess" not in sys.argv:
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--legacy", "--mymetrics", "--postprocess", "--host-protocol",
+                                                             "--train-protocol")):
     main()
 
 
@@ -339,3 +340,56 @@ def host_protocol_fixture():
 
 if __name__ == "__main__" and "--host-protocol" in sys.argv:
     host_protocol_fixture()
+
+
+def train_protocol_fixture():
+    """The reference's OWN training / validation loops (code/x_engine_pt.py:9-60, 134-165; code/x_engine.py:8-62, 90-105),
+    lifted out of their modules by AST like the evaluation loops above, run around the differentiable stubs of
+    tests/stub_model.py with plain SGD: the parameters they leave behind and the values they return are the fixture."""
+    import ast
+    import io
+    import contextlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stub_model
+
+    def lift(path, names, ns):
+        tree = ast.parse(open(os.path.join(REF, path)).read())
+        fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        assert len(fns) == len(names), (path, names)
+        exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+        return ns
+
+    base = {"torch": torch, "np": np, "nn": torch.nn, "tqdm": (lambda it, *a, **k: it)}
+    pt = lift("x_engine_pt.py", ("train_epoch", "evaluate_epoch"), dict(base))
+    lg = lift("x_engine.py", ("train_epoch", "train_continuous_epoch", "evaluate_continuous_epoch"), dict(base))
+    dev = torch.device("cpu")
+    out = {}
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink), torch.enable_grad():
+        m = stub_model.StubTrainPT()
+        opt = torch.optim.SGD(m.parameters(), lr=0.05)
+        sched = torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.9)
+        for ep in range(2):
+            m.train()
+            pt["train_epoch"](m, stub_model.protocol_batches(), opt, dev, scheduler=sched, clip=0.5, print_freq=1, epoch=ep)
+        out["pt_w_v"], out["pt_w_a"] = m.w_v.detach().numpy().copy(), m.w_a.detach().numpy().copy()
+        out["pt_val"] = np.float64(pt["evaluate_epoch"](m, stub_model.protocol_batches_with_ids(), dev))
+        out["pt_lr"] = np.float64(opt.param_groups[0]["lr"])
+        m = stub_model.StubTrainLegacy()
+        opt = torch.optim.SGD(m.parameters(), lr=0.1)
+        for ep in range(2):
+            lg["train_epoch"](m, stub_model.legacy_batches(), opt, dev, clip=0.3, print_freq=2, epoch=ep)
+        out["lg_w"], out["lg_emb"] = m.w.detach().numpy().copy(), m.emb.detach().numpy().copy()
+        m = stub_model.StubTrainContinuous()
+        opt = torch.optim.SGD(m.parameters(), lr=0.1)
+        for ep in range(2):
+            lg["train_continuous_epoch"](m, stub_model.legacy_batches(), opt, dev, clip=0.0, print_freq=2, epoch=ep)
+        out["ct_w"] = m.w.detach().numpy().copy()
+        out["ct_val"] = np.float64(lg["evaluate_continuous_epoch"](m, [b[:4] for b in stub_model.legacy_batches()], dev))
+    out["printed"] = np.array(sink.getvalue().splitlines())
+    np.savez_compressed(os.path.join(HERE, "train_protocol.npz"), **out)
+    print("train_protocol: pt val %.6f, continuous val %.6f, %d printed lines" % (out["pt_val"], out["ct_val"], len(out["printed"])))
+
+
+if __name__ == "__main__" and "--train-protocol" in sys.argv:
+    train_protocol_fixture()

@@ -66,3 +66,76 @@ def collate_items():
         items.append((torch.from_numpy(prng.normal(5, "coll.x.%d" % i, (n, 12))),
                       torch.from_numpy(prng.normal(5, "coll.y.%d" % i, (n, 7))), "n%d" % i, 3 + i, 40 - i, i % 3))
     return items
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# differentiable stand-ins for the TRAINING loops (tests/golden/make_golden.py --train-protocol runs the reference's own
+# train_epoch / evaluate_epoch / train_continuous_epoch / evaluate_continuous_epoch around them; tests/
+# test_host_protocol_golden.py runs dimx's).  Deterministic initial weights, no random number anywhere.
+# ---------------------------------------------------------------------------------------------------------------------
+def _det(*shape):
+    n = 1
+    for k in shape:
+        n *= k
+    return (torch.sin(torch.arange(n, dtype=torch.float64) * 0.37 + 0.2) * 0.1).float().reshape(shape)
+
+
+class StubTrainPT(torch.nn.Module):
+    """x_engine_pt protocol: model(src_s_v, tgt, src_s_a, mask, mode='train') -> (loss [1], dict of six terms, None)."""
+
+    def __init__(self):
+        super().__init__()
+        self.w_v = torch.nn.Parameter(_det(56, 56))
+        self.w_a = torch.nn.Parameter(_det(56, 16))
+        self.seen = []
+
+    def forward(self, v_speaker, v_listener, v_audio, mask, mode="train", **kw):
+        self.seen.append((mode, mask.clone()))
+        pred = v_speaker @ self.w_v.t() + v_audio[..., :16] @ self.w_a.t()
+        err = (pred - v_listener)[mask]
+        loss = (err ** 2).mean().reshape(1)
+        z = torch.zeros(())          # the reference's evaluate_epoch takes .mean() of every term (code/x_engine_pt.py:161)
+        d = {"l_ce_s": z, "l_ce_l": loss.detach() * 0.25, "l_cont_s": z, "l_cont_l": err.abs().mean().detach(),
+             "nce": z + 0.5, "c_acc": z}
+        return loss, d, None
+
+
+class StubTrainLegacy(torch.nn.Module):
+    """x_engine protocol: model(src, tgt, mask, speaker_ids=None, listener_ids=None) -> (loss [1], pred)."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(_det(6, 4))
+        self.emb = torch.nn.Parameter(_det(32, 6))
+        self.calls = []
+
+    def forward(self, src, tgt, mask, speaker_ids=None, listener_ids=None):
+        self.calls.append((mask.clone(), speaker_ids, listener_ids))
+        pred = src @ self.w.t()
+        if listener_ids is not None:
+            pred = pred + self.emb[listener_ids][:, None, :]
+        err = (pred - tgt)[mask]
+        return (err ** 2).mean().reshape(1), pred
+
+
+class StubTrainContinuous(StubTrainLegacy):
+    """the ContinuousTransformer protocol: model(src, tgt, mask) -> loss."""
+
+    def forward(self, src, tgt, mask):
+        return super().forward(src, tgt, mask)[0]
+
+
+def protocol_batches_with_ids():
+    """protocol_batches() with (speaker_ids, listener_ids) in the fourth slot (code/x_engine_pt.py:149 unpacks them)."""
+    return [(b[0], b[1], b[2], (torch.arange(len(b[2])), torch.arange(len(b[2])) + 3), b[4]) for b in protocol_batches()]
+
+
+def legacy_batches(n=5, B=3, T=7):
+    """(src, tgt, src_len, (speaker_ids, listener_ids), data_ids) -- what code/x_engine.py:15 unpacks."""
+    out = []
+    for i in range(n):
+        src = _det(B, T, 4) * (3.0 + i) + 0.05 * i
+        tgt = torch.cos(torch.arange(B * T * 6, dtype=torch.float64) * 0.11 + i).float().reshape(B, T, 6)
+        lens = [T, T - 2, 3]
+        out.append((src, tgt, lens, (torch.arange(B) + i, torch.arange(B) * 2 + i), ["c%d_%d" % (i, j) for j in range(B)]))
+    return out

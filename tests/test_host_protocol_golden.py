@@ -53,3 +53,68 @@ def test_pad_collate_matches_the_reference(gold):
     assert np.array_equal(xx.numpy(), gold["coll_x"]) and np.array_equal(yy.numpy(), gold["coll_y"])
     assert list(lens) == list(gold["coll_lens"]) and list(names) == list(gold["coll_names"])
     assert np.array_equal(sp.numpy(), gold["coll_speaker"]) and np.array_equal(li.numpy(), gold["coll_listener"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training / validation loops (tests/golden/train_protocol.npz: the reference's own loops around the stubs, plain SGD)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tgold(golden_dir):
+    return np.load(os.path.join(golden_dir, "train_protocol.npz"))
+
+
+def test_x_engine_pt_train_and_evaluate_epoch_leave_what_the_reference_leaves(tgold, capsys):
+    """dimx.x_engine_pt.train_epoch (torch-optimiser route) / evaluate_epoch around the stub == reference
+    code/x_engine_pt.py:9-60 / :134-165: same parameters after two epochs (SGD 0.05, clip 0.5, StepLR), same validation
+    mean, same scheduler state."""
+    from dimx import x_engine_pt
+    m = stub_model.StubTrainPT()
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.9)
+    dev = torch.device("cpu")
+    with torch.enable_grad():
+        for ep in range(2):
+            m.train()
+            x_engine_pt.train_epoch(m, stub_model.protocol_batches(), opt, dev, scheduler=sched, clip=0.5, print_freq=1, epoch=ep)
+    assert np.allclose(m.w_v.detach().numpy(), tgold["pt_w_v"], rtol=0, atol=1e-7)
+    assert np.allclose(m.w_a.detach().numpy(), tgold["pt_w_a"], rtol=0, atol=1e-7)
+    assert abs(opt.param_groups[0]["lr"] - float(tgold["pt_lr"])) < 1e-15
+    val = x_engine_pt.evaluate_epoch(m, stub_model.protocol_batches_with_ids(), dev, log=lambda *_: None)
+    assert abs(val - float(tgold["pt_val"])) < 1e-6 and not m.training
+    modes = [md for md, _ in m.seen]
+    assert modes.count("train") == len(modes)             # both loops call the model with its default / 'train' mode
+    mask = m.seen[0][1]
+    assert mask.shape == (4, 96) and mask.sum(1).tolist() == [96, 80, 71, 64]
+
+
+def test_x_engine_training_loops_leave_what_the_reference_leaves(tgold):
+    """dimx.x_engine.train_epoch / train_continuous_epoch / evaluate_continuous_epoch == reference code/x_engine.py:8-62,
+    90-105 around the stubs (SGD 0.1; clip 0.3 / none)."""
+    from dimx import x_engine
+    dev = torch.device("cpu")
+    m = stub_model.StubTrainLegacy()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    for ep in range(2):
+        x_engine.train_epoch(m, stub_model.legacy_batches(), opt, dev, clip=0.3, print_freq=2, epoch=ep)
+    assert np.allclose(m.w.detach().numpy(), tgold["lg_w"], rtol=0, atol=1e-7)
+    assert np.allclose(m.emb.detach().numpy(), tgold["lg_emb"], rtol=0, atol=1e-7)
+    _, sid, lid = m.calls[0]
+    assert sid is None and lid.tolist() == [0, 2, 4]
+    m = stub_model.StubTrainContinuous()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    for ep in range(2):
+        x_engine.train_continuous_epoch(m, stub_model.legacy_batches(), opt, dev, clip=0.0, print_freq=2, epoch=ep)
+    assert np.allclose(m.w.detach().numpy(), tgold["ct_w"], rtol=0, atol=1e-7)
+    val = x_engine.evaluate_continuous_epoch(m, [b[:4] for b in stub_model.legacy_batches()], dev, verbose=False)
+    assert abs(val - float(tgold["ct_val"])) < 1e-6
+
+
+def test_legacy_loop_prints_the_reference_lines(tgold, capsys):
+    """the running-mean lines of code/x_engine.py:32-36 (every print_freq batches, mean since the last print)."""
+    from dimx import x_engine
+    m = stub_model.StubTrainLegacy()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    x_engine.train_epoch(m, stub_model.legacy_batches(), opt, torch.device("cpu"), clip=0.3, print_freq=2, epoch=0)
+    got = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Epoch: [0]")]
+    want = [str(l) for l in tgold["printed"] if str(l).startswith("Epoch: [0]")][:len(got)]
+    assert got == want and len(got) == 3

@@ -124,3 +124,14 @@ def test_train_continuous_epoch_protocol():
     a = x_engine.train_continuous_epoch(m, _loader(), opt, torch.device("cpu"), clip=0.0)
     b = x_engine.train_continuous_epoch(m, _loader(), opt, torch.device("cpu"), clip=0.0)
     assert b < a
+
+
+def test_evaluate_continuous_epoch_protocol():
+    from dimx import x_engine
+    m = _StubContinuous()
+    batches = [b[:4] for b in _loader(3)]                         # reference :94: (src, tgt, src_len, _)
+    with torch.no_grad():
+        want = sum(float(m(b[0], b[1], x_engine._mask_from_lens(b[0], b[2], "cpu"))) for b in batches) / 3
+    m.train()
+    got = x_engine.evaluate_continuous_epoch(m, batches, torch.device("cpu"), verbose=False)
+    assert abs(got - want) < 1e-9 and not m.training
