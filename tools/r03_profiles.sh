@@ -49,9 +49,12 @@ python bench.py --steps 2 --warmup 1 --batch 64 --frames 1500 --no-cpu-baseline 
 python tools/g256_var.py 3 "VAR=3" "VAR=4" "VAR=4 ZERO=1" 2>&1 | grep -v amdgpu > $O/r03_g256_var.txt
 python tools/fuse_probe.py 128 2>&1 | grep -v amdgpu > $O/r03_fuse_probe.txt
 python tools/fuse_probe.py 256 2>&1 | grep -v amdgpu >> $O/r03_fuse_probe.txt
-python tools/bench_train.py 2>&1 | grep -v amdgpu > $O/r03_train_step.txt
+python tools/bench_train.py 16 300 5 all 2>&1 | grep -v amdgpu > $O/r03_train_step.txt
+DIMX_TRAIN_ATTN_VALU=1 python tools/bench_train.py 16 300 3 bf16 2>&1 | grep -v amdgpu | sed 's/^/DIMX_TRAIN_ATTN_VALU=1: /' >> $O/r03_train_step.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -- python tools/bench_train.py 16 300 3 bf16 > /dev/null 2>&1
+cp $(ls $O/kt_train/*/*kernel_stats.csv | head -1) $O/r03_train_step_kernel_stats.csv
 bash tools/scale_check.sh 1 > $O/r03_scale_check_n1.txt 2>&1
-rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_l2
+rm -rf $O/kt $O/kt_train $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_l2
 ls -la $O
 tail -c 600 $O/r03_bench_line.json
 python -m pytest tests/test_gpu_module.py -q -x -k "hip_training_step or train_epoch" 2>&1 | tail -3
