@@ -1,4 +1,5 @@
 set -x
 timeout 1200 python -m pytest tests/test_gpu_train_hip.py tests/test_gpu_module.py -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -4
 timeout 600 python tools/bench_train.py 16 300 8 bf16
-timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['train_step'])"
+timeout 600 python tools/bench_train.py 32 300 5 bf16
+timeout 600 python tools/bench_train.py 4 300 8 bf16
