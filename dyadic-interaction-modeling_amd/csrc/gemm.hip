@@ -1251,7 +1251,9 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
         return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
     }
     int cfg = a.cfg;
-    if (cfg == 0) cfg = tiles128 >= 512 ? 14 : gemm_cfg_small();  // measured on MI355X: 128x128 8-wave for large M
+    // measured on MI355X: 128x128 8-wave for large M; bf16 from 288 tiles (the dW of a 1152 x 4608 projection at 4 800 rows:
+    // 122.9 us on the 64 x 64 kernel, 80.4 on this one; 228 tiles and fewer: level or behind -- profiles/r03_train_gemm.txt)
+    if (cfg == 0) cfg = tiles128 >= (sizeof(T) == 2 ? 288 : 512) ? 14 : gemm_cfg_small();
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;

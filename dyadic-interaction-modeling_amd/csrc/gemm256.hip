@@ -899,6 +899,12 @@ bool gemm256_eligible(const GemmArgs& g) {
     // (N 2304, K 384) 276 -> 174 us, level from K = 1152 up; one and a half column tiles of a 384 x 384 projection stay behind
     static const bool all = getenv("DIMX_G256_ALL") != nullptr;
     if (!all && (g.K < 384 || g.N < 384 || (long)g.N * g.K < 384L * 1536L)) return false;
+    // ... and only with enough 256 x 256 tiles for the 256 CUs: at 4 800 rows (a training batch, a 16-clip prefill) N 768 K 1152
+    // has 57 tiles and took 29.7 us against 18.9 on the 128 x 128 kernel, N 384 K 1536 (38 tiles) 33.1 against 13.0 on the
+    // 64 x 64 one, 95 tiles (N 1152) 6 - 15 % behind; N 4608 K 1152 (342 tiles) 68.9 against 85.5 stays, and so do the 114 tiles
+    // of N 1536 K 384 with the GELU / bf16 epilogue (a 16-clip prefill was 0.5 ms slower without them) -- tools/
+    // bench_train_gemm.py, profiles/r03_train_gemm.txt
+    if (!all && (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) < 100) return false;
     if ((size_t)g.M * g.lda >= (1ull << 32) || (size_t)g.N * g.ldw >= (1ull << 32)) return false;  // 32-bit element offsets
     if (g.bias && ((uintptr_t)g.bias % 16)) return false;
     if (g.residual && (g.ldr % 4 || (uintptr_t)g.residual % 16)) return false;

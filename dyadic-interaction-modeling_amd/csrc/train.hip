@@ -217,15 +217,6 @@ int gemm_f32(Step& s, const void* A_op, int Kp, const void* W_op, int M, int N, 
     g.residual = residual;
     g.ldr = ldr;
     gemm_set_plain_out(g, C, ldc);
-    if (s.at == DIMX_BF16) {
-        // The library's automatic choice is tuned on prefill shapes (tens of thousands of rows).  A training batch has a few
-        // thousand: a 256 x 256 tiling then covers a fraction of the 256 CUs and the 64 x 64 kernel runs out of steam on wide
-        // outputs.  Measured at 4 800 rows (tools/bench_train_gemm.py, `profiles/r03_train_gemm.txt`): N 768 K 1152: 29.7 us
-        // (256 x 256, 57 tiles) vs 18.9 (128 x 128); N 384 K 1536: 33.1 vs 13.0 (64 x 64); dW of ff2 (1152 x 4608, K 4800):
-        // 122.9 (64 x 64) vs 80.4 (128 x 128); N 4608 K 1152: 68.9 (256 x 256, 342 tiles) stays.
-        const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 256), t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-        g.cfg = t256 >= 160 ? 0 : (t128 >= 288 ? 14 : 34);
-    }
     return launch_gemm(g, s.st);
 }
 
