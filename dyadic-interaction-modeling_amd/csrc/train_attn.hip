@@ -7,7 +7,8 @@
 //   dK, dV    dK = dS^T Q,  dV = P^T dO
 //
 // All three kernels use v_mfma_f32_32x32x16_bf16 with one wave owning a 32-row strip, 4 waves per block, the other operand
-// streamed through LDS in 64-row tiles converted from the f32 activations on the way in.  The products are arranged so that
+// streamed through LDS in 64-row tiles converted from the f32 activations on the way in (through registers: the loads of tile
+// t + 1 are issued before tile t is multiplied).  The products are arranged so that
 // no probability ever changes lanes:
 //   * forward / dQ compute S^T = K Q^T (A = K rows from LDS, B = Q rows in registers): a lane owns ONE query (lane & 31) and
 //     16 keys of every 32-key block, so the softmax is lane-local and P^T / dS^T are already B operands of the second product
@@ -36,38 +37,50 @@ __device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) {
     return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
 }
 
-// 64 rows x 64 head columns of an f32 [L, ld] matrix (rows r0.., rows >= L read as zero) -> row-major bf16 LDS tile
-__device__ __forceinline__ void stage_rows(uint16_t* dst, const float* __restrict__ src, int ld, int r0, int L, int tid) {
-    const int row = tid >> 2, c = (tid & 3) * 16;
+// Staging of a 64-row x 64-column block of an f32 [L, ld] matrix (rows r0.., rows >= L read as zero) goes through registers in
+// two halves, so that the global loads of tile t + 1 are in flight while tile t is being multiplied:
+//   RowsReg: thread t owns 16 consecutive columns of row t / 4            -> row-major bf16 LDS tile
+//   ColsReg: thread t owns column t % 64 of 16 rows (4 quads of 4)        -> TRANSPOSED tile dst[column][row]
+struct RowsReg {
     float4 v[4];
+};
+struct ColsReg {
+    float x[4][4];
+};
+__device__ __forceinline__ void load_rows(RowsReg& r, const float* __restrict__ src, int ld, int r0, int L, int tid) {
+    const int row = tid >> 2, c = (tid & 3) * 16;
     if (r0 + row < L) {
         const float4* p = (const float4*)(src + (size_t)(r0 + row) * ld + c);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = p[i];
+        for (int i = 0; i < 4; ++i) r.v[i] = p[i];
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 4; ++i) r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    uint4* d = (uint4*)(dst + row * kLd + c);
-    d[0] = pack8(v[0], v[1]);
-    d[1] = pack8(v[2], v[3]);
 }
-
-// the same 64 x 64 block transposed: dst[column][row]
-__device__ __forceinline__ void stage_cols(uint16_t* dst, const float* __restrict__ src, int ld, int r0, int L, int tid) {
+__device__ __forceinline__ void store_rows(uint16_t* dst, const RowsReg& r, int tid) {
+    const int row = tid >> 2, c = (tid & 3) * 16;
+    uint4* d = (uint4*)(dst + row * kLd + c);
+    d[0] = pack8(r.v[0], r.v[1]);
+    d[1] = pack8(r.v[2], r.v[3]);
+}
+__device__ __forceinline__ void load_cols(ColsReg& r, const float* __restrict__ src, int ld, int r0, int L, int tid) {
     const int d = tid & 63, quad = tid >> 6;
-    float x[4][4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = r0 + 16 * p + 4 * quad + i;
-            x[p][i] = r < L ? src[(size_t)r * ld + d] : 0.f;
+            const int row = r0 + 16 * p + 4 * quad + i;
+            r.x[p][i] = row < L ? src[(size_t)row * ld + d] : 0.f;
         }
     }
+}
+__device__ __forceinline__ void store_cols(uint16_t* dst, const ColsReg& r, int tid) {
+    const int d = tid & 63, quad = tid >> 6;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
-        *(uint2*)(dst + d * kLd + 16 * p + 4 * quad) = make_uint2(pack_bf16x2(x[p][0], x[p][1]), pack_bf16x2(x[p][2], x[p][3]));
+        *(uint2*)(dst + d * kLd + 16 * p + 4 * quad) =
+            make_uint2(pack_bf16x2(r.x[p][0], r.x[p][1]), pack_bf16x2(r.x[p][2], r.x[p][3]));
 }
 
 // B operand straight from an f32 row in global memory: lane's row, columns 16 s + 8 (lane >> 5) .. + 7
@@ -136,13 +149,23 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(TrAttn a, const floa
     float m = kNegMaxF, lsum = 0.f;
     int nkt = (a.Lk + 63) >> 6;
     if (a.causal) nkt = min(nkt, (min(q0b + 127, a.Lq - 1) >> 6) + 1);
+    RowsReg kr;
+    ColsReg vr;
+    if (nkt > 0) {
+        load_rows(kr, kb, a.ldk, 0, a.Lk, tid);
+        load_cols(vr, vb, a.ldv, 0, a.Lk, tid);
+    }
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        stage_rows(Ks, kb, a.ldk, kt * 64, a.Lk, tid);
-        stage_cols(Vt, vb, a.ldv, kt * 64, a.Lk, tid);
+        store_rows(Ks, kr, tid);
+        store_cols(Vt, vr, tid);
         uint64_t keep, valid;
         key_bits(a, b, kt * 64, lane, keep, valid);
         __syncthreads();
+        if (kt + 1 < nkt) {  // tile kt + 1 travels while tile kt is multiplied
+            load_rows(kr, kb, a.ldk, (kt + 1) * 64, a.Lk, tid);
+            load_cols(vr, vb, a.ldv, (kt + 1) * 64, a.Lk, tid);
+        }
         if (!wave_on || (a.causal && kt * 64 > q0w + 31)) continue;
         f32x16_t st[2];
 #pragma unroll
@@ -250,14 +273,26 @@ __global__ __launch_bounds__(256) void attn_dq_mfma_kernel(TrAttn a, const float
     for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
     int nkt = (a.Lk + 63) >> 6;
     if (a.causal) nkt = min(nkt, (min(q0b + 127, a.Lq - 1) >> 6) + 1);
+    RowsReg kr, vr;
+    ColsReg kc;
+    if (nkt > 0) {
+        load_rows(kr, kb, a.ldk, 0, a.Lk, tid);
+        load_rows(vr, vb, a.ldv, 0, a.Lk, tid);
+        load_cols(kc, kb, a.ldk, 0, a.Lk, tid);
+    }
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        stage_rows(Ks, kb, a.ldk, kt * 64, a.Lk, tid);
-        stage_rows(Vs, vb, a.ldv, kt * 64, a.Lk, tid);
-        stage_cols(Kt, kb, a.ldk, kt * 64, a.Lk, tid);
+        store_rows(Ks, kr, tid);
+        store_rows(Vs, vr, tid);
+        store_cols(Kt, kc, tid);
         uint64_t keep, valid;
         key_bits(a, b, kt * 64, lane, keep, valid);
         __syncthreads();
+        if (kt + 1 < nkt) {
+            load_rows(kr, kb, a.ldk, (kt + 1) * 64, a.Lk, tid);
+            load_rows(vr, vb, a.ldv, (kt + 1) * 64, a.Lk, tid);
+            load_cols(kc, kb, a.ldk, (kt + 1) * 64, a.Lk, tid);
+        }
         if (!wave_on || (a.causal && kt * 64 > q0w + 31)) continue;
         f32x16_t st[2], dp[2];
 #pragma unroll
@@ -328,18 +363,33 @@ __global__ __launch_bounds__(256) void attn_dkv_mfma_kernel(TrAttn a, const floa
     for (int i = 0; i < 16; ++i) accK[0][i] = accK[1][i] = accV[0][i] = accV[1][i] = 0.f;
     const int nqt = (a.Lq + 63) >> 6;
     const int qt0 = a.causal ? min(k0b >> 6, nqt) : 0;  // a causal query tile below the block's first key sees none of its keys
-    for (int qt = qt0; qt < nqt; ++qt) {
-        __syncthreads();
-        stage_rows(Qs, qb, a.ldq, qt * 64, a.Lq, tid);
-        stage_rows(Gs, gb, a.ldo, qt * 64, a.Lq, tid);
-        stage_cols(Qt, qb, a.ldq, qt * 64, a.Lq, tid);
-        stage_cols(Gt, gb, a.ldo, qt * 64, a.Lq, tid);
+    RowsReg qr, gr;
+    ColsReg qc, gc;
+    float lreg = kInf, dreg = 0.f;
+    auto load_tile = [&](int qt) {
+        load_rows(qr, qb, a.ldq, qt * 64, a.Lq, tid);
+        load_rows(gr, gb, a.ldo, qt * 64, a.Lq, tid);
+        load_cols(qc, qb, a.ldq, qt * 64, a.Lq, tid);
+        load_cols(gc, gb, a.ldo, qt * 64, a.Lq, tid);
         if (tid < 64) {
             const int qi = qt * 64 + tid;
-            Ls[tid] = qi < a.Lq ? lp[qi] : kInf;
-            Ds[tid] = qi < a.Lq ? dp_[qi] : 0.f;
+            lreg = qi < a.Lq ? lp[qi] : kInf;
+            dreg = qi < a.Lq ? dp_[qi] : 0.f;
+        }
+    };
+    if (qt0 < nqt) load_tile(qt0);
+    for (int qt = qt0; qt < nqt; ++qt) {
+        __syncthreads();
+        store_rows(Qs, qr, tid);
+        store_rows(Gs, gr, tid);
+        store_cols(Qt, qc, tid);
+        store_cols(Gt, gc, tid);
+        if (tid < 64) {
+            Ls[tid] = lreg;
+            Ds[tid] = dreg;
         }
         __syncthreads();
+        if (qt + 1 < nqt) load_tile(qt + 1);
         if (!wave_on || (a.causal && qt * 64 + 63 < k0w)) continue;
         f32x16_t st[2], dp[2];
 #pragma unroll

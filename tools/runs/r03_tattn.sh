@@ -1,5 +1,3 @@
 set -x
-timeout 1200 python -m pytest tests/test_gpu_train_hip.py tests/test_gpu_module.py -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -4
+timeout 1200 python -m pytest tests/test_gpu_train_hip.py -x -q -s 2>&1 | grep "train attention.*mfma=1\|passed\|failed" | tail -24
 timeout 600 python tools/bench_train.py 16 300 8 bf16
-timeout 600 python tools/bench_train.py 32 300 5 bf16
-timeout 600 python tools/bench_train.py 4 300 8 bf16
