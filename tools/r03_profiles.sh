@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # 1. headline line (value, parity_mode, roofline, cross_attn_mfma, cpu_baseline)
 python bench.py --steps 10 --warmup 2 > $O/r03_bench_line.json 2> $O/r03_bench_line.err
 # 2. kernel trace of the same workload
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode > $O/r03_bench_line_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode --no-train-step > $O/r03_bench_line_under_rocprof.json 2>/dev/null
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/r03_bench_kernel_stats.csv
 # 3. HBM traffic of the dominant kernel: separate PMC passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python tools/roofline_only.py > /dev/null 2>&1
