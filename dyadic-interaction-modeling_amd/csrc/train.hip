@@ -18,6 +18,7 @@
 // Activations needed by the backward pass are kept in the caller's workspace (dimx_train_workspace_bytes).
 #include <algorithm>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -141,6 +142,15 @@ struct Step {
 
     size_t peak = 0;  // high-water mark of the arena: the sizing pass (ws == NULL) walks the same allocation sequence
     PrepTable prep;   // weight operand copies queued by prep_lin, made by ONE launch in flush_prep
+    // operand copies of the forward pass's Linear inputs {cast [M][Kp], transposed cast [K][Mp]}, made by one launch per distinct
+    // input and kept for the backward pass (dW = dy^T . x needs the transposed one): q / k / v share theirs, the context is copied
+    // once for all four cross-attention layers.  Persistent arena allocations: never made inside a region that is rolled back.
+    struct OpCopy {
+        void* o;
+        void* t;
+        int Kp, Mp;
+    };
+    std::map<std::tuple<const float*, int, int, int>, OpCopy> ops;
 
     bool live() const { return ar->base != nullptr; }
     size_t es() const { return dtype_size(at); }
@@ -150,6 +160,9 @@ struct Step {
     void* take(size_t bytes) {
         void* q = ar->take(bytes);
         peak = ar->off > peak ? ar->off : peak;
+        // sizing pass (no workspace yet): a distinct, never dereferenced token per allocation instead of NULL, so that
+        // everything keyed by a buffer's address (the operand cache below) takes the same path as in the live pass
+        if (!q) q = (void*)(uintptr_t)((1ull << 44) + (ar->off - bytes));
         return q;
     }
     float* f32(size_t n_) { return (float*)take(n_ * sizeof(float)); }
@@ -192,6 +205,7 @@ int prep_lin(Step& s, Lin& l) {
     d.K = l.K;
     d.Kp = Kp;
     d.Np = Np;
+    d.lds = l.K;
     d.tile0 = s.prep.total_tiles;
     d.tiles_k = ceil_div(Kp, 32);
     s.prep.total_tiles += ceil_div(Np, 32) * d.tiles_k;
@@ -220,36 +234,43 @@ int gemm_f32(Step& s, const void* A_op, int Kp, const void* W_op, int M, int N, 
     return launch_gemm(g, s.st);
 }
 
-// operand copy of an f32 activation [M,K] -> [M,Kp] in the operand type
-void* as_operand(Step& s, const float* x, int ldx, int M, int K, int* Kp_out) {
-    const int Kp = pad_to(K, s.bk);
-    *Kp_out = Kp;
-    void* o = s.take((size_t)M * Kp * s.es());
-    if (s.live()) (void)launch_cast_pad(s.at, x, ldx, nullptr, o, Kp, M, K, s.st);
-    return o;
+// the cached operand pair of a forward input (made on first use; see Step::ops)
+const Step::OpCopy& fwd_operands(Step& s, const float* x, int ldx, int M, int K) {
+    const auto key = std::make_tuple(x, ldx, M, K);
+    auto it = s.ops.find(key);
+    if (it != s.ops.end()) return it->second;
+    Step::OpCopy c;
+    c.Kp = pad_to(K, s.bk);
+    c.Mp = pad_to(M, s.bk);
+    c.o = s.take((size_t)M * c.Kp * s.es());
+    c.t = s.take((size_t)K * c.Mp * s.es());
+    if (s.live()) (void)tr_prep_pair(s.at, x, ldx, M, K, c.o, c.Kp, c.t, c.Mp, s.st);
+    return s.ops.emplace(key, c).first->second;
 }
 
 // y = x . W^T (+ b) (+ residual)
 int lin_fwd(Step& s, const Lin& l, const float* x, int ldx, int M, float* y, int ldy, const float* residual = nullptr, int ldr = 0) {
-    int Kp;
-    const size_t mark = s.ar->off;
-    void* xo = as_operand(s, x, ldx, M, l.K, &Kp);
-    const int rc = gemm_f32(s, xo, Kp, l.w_op, M, l.N, Kp, y, ldy, l.b >= 0 ? s.P + l.b : nullptr, residual, ldr);  // K padded with zeros
-    s.ar->off = mark;  // the operand copy is dead after the launch (stream order protects it until then)
-    return rc;
+    const Step::OpCopy& c = fwd_operands(s, x, ldx, M, l.K);
+    return gemm_f32(s, c.o, c.Kp, l.w_op, M, l.N, c.Kp, y, ldy, l.b >= 0 ? s.P + l.b : nullptr, residual, ldr);  // K padded with zeros
 }
 
 // dx (+)= dy . W ; dW = dy^T . x ; db = colsum(dy).  x [M,K] (ldx), dy [M,N] (ldy) f32.  dx may be null.
 int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int ldy, int M, float* dx, int lddx, bool accumulate_dx) {
     const size_t mark = s.ar->off;
-    const int Mp = pad_to(M, s.bk);
-    int Np;
-    void* dyo = as_operand(s, dy, ldy, M, l.N, &Np);
-    if (dx) DIMX_TRY(gemm_f32(s, dyo, Np, l.wt_op, M, l.K, Np, dx, lddx, nullptr, accumulate_dx ? dx : nullptr, lddx));
+    const int Mp = pad_to(M, s.bk), Np = pad_to(l.N, s.bk);
+    void* dyo = s.take((size_t)M * Np * s.es());     // dy and dy^T in the operand type: one pass over dy
     void* dyT = s.take((size_t)l.N * Mp * s.es());
-    void* xT = s.take((size_t)l.K * Mp * s.es());
-    TR(tr_transpose_pad(s.at, dy, ldy, dyT, Mp, M, l.N, s.st));
-    TR(tr_transpose_pad(s.at, x, ldx, xT, Mp, M, l.K, s.st));
+    TR(tr_prep_pair(s.at, dy, ldy, M, l.N, dyo, Np, dyT, Mp, s.st));
+    if (dx) DIMX_TRY(gemm_f32(s, dyo, Np, l.wt_op, M, l.K, Np, dx, lddx, nullptr, accumulate_dx ? dx : nullptr, lddx));
+    const void* xT;
+    const auto it = s.ops.find(std::make_tuple(x, ldx, M, l.K));
+    if (it != s.ops.end()) {
+        xT = it->second.t;                            // made by the forward pass
+    } else {
+        void* t = s.take((size_t)l.K * Mp * s.es());
+        TR(tr_transpose_pad(s.at, x, ldx, t, Mp, M, l.K, s.st));
+        xT = t;
+    }
     TR(gemm_f32(s, dyT, Mp, xT, l.N, l.K, Mp, s.G + l.w, l.K, nullptr, nullptr, 0));  // contraction over the zero-padded rows
     if (l.b >= 0) TR(tr_colsums(nullptr, dy, nullptr, s.G + l.b, M, l.N, s.part, 0, s.st));
     s.ar->off = mark;
@@ -326,6 +347,7 @@ int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C
     DIMX_TRY(lin_fwd(s, a.v, a.src, a.Ck, a.Mk, a.vb, inner));
     TR(tr_attn_fwd(a.shape, a.qb, a.kb, a.vb, a.ob, a.lse, s.st));
     if (qmask) {  // out = to_out(o) with padded query rows zero-filled, then the residual
+        (void)fwd_operands(s, a.ob, inner, M, inner);  // persistent: before the mark
         const size_t mark = s.ar->off;
         float* tmp = s.f32((size_t)M * C);
         DIMX_TRY(lin_fwd(s, a.o, a.ob, inner, M, tmp, C));
@@ -446,6 +468,7 @@ int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int 
     for (auto& p : e.h) p = s.f32((size_t)M * C);
     e.out = s.f32((size_t)M * C);
     {
+        (void)fwd_operands(s, x_in, Cin, M, Cin);  // persistent: before the mark
         const size_t mark = s.ar->off;
         float* t = s.f32((size_t)M * C);
         DIMX_TRY(lin_fwd(s, e.pin, x_in, Cin, M, t, C));

@@ -24,6 +24,7 @@ struct PrepDesc {
     void* w;
     void* wt;
     int N, K, Kp, Np;
+    int lds;      // row stride of src (elements)
     int tile0;    // first 32 x 32 tile of this matrix in the launch
     int tiles_k;  // tiles along K
 };
@@ -33,6 +34,8 @@ struct PrepTable {
     int total_tiles;
 };
 int tr_prep_weights(int out_dtype, const PrepTable& t, hipStream_t s);
+// the same pair of copies for ONE matrix (an activation [rows][cols] with row stride lds): o [rows][Kp], t [cols][Mp]
+int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, void* o, int Kp, void* t, int Mp, hipStream_t s);
 int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s);
 int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
 int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,

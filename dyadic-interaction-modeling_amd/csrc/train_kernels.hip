@@ -46,20 +46,15 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 
 // Both operand copies of a group of weight matrices in one launch (a step makes 91 x 2 of them: as separate launches of
 // ~7 us they were 1.3 ms of a 19 ms step).  One block per 32 x 32 tile of the padded [Np][Kp] extent of its matrix.
-template <typename OutT>
-__global__ __launch_bounds__(256) void multi_prep_kernel(PrepTable t) {
-    __shared__ float tile[32][33];
-    int i = 0;
-    while (i + 1 < t.n && (int)blockIdx.x >= t.d[i + 1].tile0) ++i;
-    const PrepDesc& d = t.d[i];
-    const int lt = blockIdx.x - d.tile0, tn = lt / d.tiles_k, tk = lt % d.tiles_k;
+template <typename OutT> __device__ __forceinline__ void prep_tile(const PrepDesc& d, int lt, float (&tile)[32][33]) {
+    const int tn = lt / d.tiles_k, tk = lt % d.tiles_k;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     OutT* w = (OutT*)d.w;
     OutT* wt = (OutT*)d.wt;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = tn * 32 + ty + 8 * r, k = tk * 32 + tx;
-        const float v = (n < d.N && k < d.K) ? d.src[(size_t)n * d.K + k] : 0.f;
+        const float v = (n < d.N && k < d.K) ? d.src[(size_t)n * d.lds + k] : 0.f;
         tile[ty + 8 * r][tx] = v;
         if (n < d.N && k < d.Kp) store_from_f32<OutT>(w + (size_t)n * d.Kp + k, v);
     }
@@ -69,6 +64,19 @@ __global__ __launch_bounds__(256) void multi_prep_kernel(PrepTable t) {
         const int k = tk * 32 + ty + 8 * r, n = tn * 32 + tx;
         if (k < d.K && n < d.Np) store_from_f32<OutT>(wt + (size_t)k * d.Np + n, tile[tx][ty + 8 * r]);
     }
+}
+template <typename OutT>
+__global__ __launch_bounds__(256) void multi_prep_kernel(PrepTable t) {
+    __shared__ float tile[32][33];
+    int i = 0;
+    while (i + 1 < t.n && (int)blockIdx.x >= t.d[i + 1].tile0) ++i;
+    prep_tile<OutT>(t.d[i], blockIdx.x - t.d[i].tile0, tile);
+}
+// one matrix (an activation): cast + transposed cast in one pass over the source
+template <typename OutT>
+__global__ __launch_bounds__(256) void prep_pair_kernel(PrepDesc d) {
+    __shared__ float tile[32][33];
+    prep_tile<OutT>(d, blockIdx.x, tile);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
@@ -551,6 +559,26 @@ int tr_prep_weights(int out_dtype, const PrepTable& t, hipStream_t s) {
     DIMX_REQUIRE(t.n <= kPrepMax && t.total_tiles > 0, DIMX_ERR_ARG, "prep_weights: bad table");
     if (out_dtype == DIMX_BF16) hipLaunchKernelGGL(multi_prep_kernel<bf16>, dim3(t.total_tiles), dim3(256), 0, s, t);
     else hipLaunchKernelGGL(multi_prep_kernel<float>, dim3(t.total_tiles), dim3(256), 0, s, t);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, void* o, int Kp, void* t, int Mp, hipStream_t s) {
+    DIMX_REQUIRE(src && o && t && rows > 0 && cols > 0 && Kp >= cols && Mp >= rows, DIMX_ERR_ARG, "prep_pair: bad arguments");
+    PrepDesc d;
+    d.src = src;
+    d.w = o;
+    d.wt = t;
+    d.N = rows;
+    d.K = cols;
+    d.Kp = Kp;
+    d.Np = Mp;
+    d.lds = lds;
+    d.tile0 = 0;
+    d.tiles_k = ceil_div(Kp, 32);
+    const int tiles = ceil_div(Mp, 32) * d.tiles_k;
+    if (out_dtype == DIMX_BF16) hipLaunchKernelGGL(prep_pair_kernel<bf16>, dim3(tiles), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(prep_pair_kernel<float>, dim3(tiles), dim3(256), 0, s, d);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
