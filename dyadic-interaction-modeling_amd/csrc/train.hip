@@ -338,9 +338,10 @@ int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C
     a.src = cross ? ctx : a.y;
     a.shape = shape;
     a.shape.ldq = a.shape.ldk = a.shape.ldv = a.shape.ldo = inner;
-    // perf mode: attention and its adjoints on the matrix cores (train_attn.hip); DIMX_TRAIN_ATTN_VALU=1 keeps the f32 kernels (A/B)
+    // attention and its adjoints on the matrix cores (train_attn.hip): bf16 MFMA in the perf mode, exact-f32 MFMA in the parity
+    // mode; DIMX_TRAIN_ATTN_VALU=1 keeps the one-wave-per-row f32 VALU kernels (the plain form both are checked against)
     static const bool valu_only = getenv("DIMX_TRAIN_ATTN_VALU") && atoi(getenv("DIMX_TRAIN_ATTN_VALU")) != 0;
-    a.shape.mfma = (s.at == DIMX_BF16 && !valu_only) ? 1 : 0;
+    a.shape.mfma = valu_only ? 0 : (s.at == DIMX_BF16 ? 1 : 2);
     TR(launch_layernorm(DIMX_F32, h_in, a.y, s.p(a.pre + "0.0.weight"), nullptr, M, C, s.st));
     DIMX_TRY(lin_fwd(s, a.q, a.y, C, M, a.qb, inner));
     DIMX_TRY(lin_fwd(s, a.k, a.src, a.Ck, a.Mk, a.kb, inner));
@@ -707,7 +708,7 @@ int dimx_op_train_attention(int mfma, const float* q, const float* k, const floa
     t.causal = causal;
     t.kmask = kmask;
     t.kmask2 = kmask2;
-    t.mfma = mfma ? 1 : 0;
+    t.mfma = mfma < 0 ? 0 : (mfma > 2 ? 2 : mfma);
     hipStream_t st = (hipStream_t)stream;
     DIMX_TRY(tr_attn_fwd(t, q, k, v, o, lse, st));
     if (d_o) DIMX_TRY(tr_attn_bwd(t, q, k, v, o, d_o, lse, delta, dq, H * 64, dk, H * 64, dv, H * 64, st));

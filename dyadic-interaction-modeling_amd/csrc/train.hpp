@@ -13,7 +13,7 @@ struct TrAttn {
     int causal;
     const uint8_t* kmask;    // [B, Lk] keep-mask (padding), optional
     const uint8_t* kmask2;   // [B, Lk] second keep-mask (the mask_prob draw), optional
-    int mfma;                // 1: the bf16 matrix-core kernels of train_attn.hip (perf mode), 0: the f32 VALU kernels (parity mode)
+    int mfma;                // train_attn.hip on the matrix cores: 1 = bf16 operands (perf mode), 2 = exact f32 (parity mode); 0 = the f32 VALU kernels
 };
 
 // operand copies of up to kPrepMax weight matrices in ONE launch: for each [N][K] f32 source the cast [N][Kp] (zero columns

@@ -339,7 +339,8 @@ def op_attention(q, k, v, scale, causal=False, lens=None, kmask=None, bf16=False
 
 def op_train_attention(q, k, v, scale, d_o=None, causal=False, kmask=None, kmask2=None, mfma=False):
     """The training step's attention operator alone: q [B,Lq,H*64], k / v [B,Lk,H*64] f32 -> (o, lse) and, with d_o,
-    (o, lse, dq, dk, dv).  mfma: the bf16 matrix-core kernels of the perf mode instead of the f32 ones."""
+    (o, lse, dq, dk, dv).  mfma: 0 / False = the f32 VALU kernels, 1 / True = the bf16 matrix-core kernels of the perf mode,
+    2 = the exact-f32 matrix-core kernels of the parity mode."""
     lib = L.load()
     B, Lq, C = q.shape
     Lk, H = k.shape[1], C // 64
@@ -351,7 +352,7 @@ def op_train_attention(q, k, v, scale, d_o=None, causal=False, kmask=None, kmask
     delta = dq = dk = dv = None
     if d_o is not None:
         delta, dq, dk, dv = torch.empty_like(lse), torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    L.check(lib.dimx_op_train_attention(1 if mfma else 0, L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(d_o), L.ptr(kmask), L.ptr(kmask2),
+    L.check(lib.dimx_op_train_attention(int(mfma), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(d_o), L.ptr(kmask), L.ptr(kmask2),
                                         B, H, Lq, Lk, 1 if causal else 0, float(scale), L.ptr(o), L.ptr(lse), L.ptr(delta),
                                         L.ptr(dq), L.ptr(dk), L.ptr(dv), L.stream_ptr(q.device)), "dimx_op_train_attention")
     return (o, lse) if d_o is None else (o, lse, dq, dk, dv)

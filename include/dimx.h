@@ -235,8 +235,8 @@ int dimx_train_adamw(float* params, const float* grads, float* exp_avg, float* e
 /* The attention operator of the training step alone (unit parity): q [B,Lq,H*64], k / v [B,Lk,H*64] f32, head h at columns
  * 64 h; kmask / kmask2 [B,Lk] uint8 keep-masks (NULL = keep all), causal: key j > query i masked; masked scores are filled
  * with -FLT_MAX before the softmax (x-transformers' Attend).  Writes o [B,Lq,H*64] and lse [B,H,Lq]; with d_o also delta
- * [B,H,Lq], dq, dk, dv.  mfma = 1: the bf16 matrix-core kernels the perf mode trains with (csrc/train_attn.hip), 0: the f32
- * kernels of the parity mode. */
+ * [B,H,Lq], dq, dk, dv.  mfma = 1: the bf16 matrix-core kernels the perf mode trains with (csrc/train_attn.hip), 2: the same
+ * kernels on exact-f32 MFMA (what the parity mode trains with), 0: the one-wave-per-row f32 VALU kernels (the plain form). */
 int dimx_op_train_attention(int mfma, const float* q, const float* k, const float* v, const float* d_o, const uint8_t* kmask,
                             const uint8_t* kmask2, int B, int H, int Lq, int Lk, int causal, float scale, float* o, float* lse,
                             float* delta, float* dq, float* dk, float* dv, void* stream);

@@ -158,8 +158,9 @@ def _attend_reference(q, k, v, d_o, scale, causal, kmask, kmask2, H):
 @pytest.mark.parametrize("shape", [(2, 3, 70, 70, True, True), (2, 2, 299, 300, False, False), (1, 12, 300, 300, True, False),
                                    (3, 2, 33, 129, False, True), (2, 1, 128, 64, True, True)])
 def test_training_attention_on_the_matrix_cores_matches_attend_and_its_adjoint(shape):
-    """train_attn.hip (bf16 MFMA, the perf mode's attention) and the f32 kernels against autograd over Attend in float64:
-    forward, dQ, dK, dV; causal / padding / mask_prob key masks, ragged tile edges (Lq, Lk not multiples of 32 / 64)."""
+    """train_attn.hip (bf16 MFMA = the perf mode's attention, exact-f32 MFMA = the parity mode's) and the plain f32 VALU
+    kernels against autograd over Attend in float64: forward, dQ, dK, dV; causal / padding / mask_prob key masks, ragged
+    tile edges (Lq, Lk not multiples of 32 / 64)."""
     from dimx import engine as E
     from dimx import prng
     B, H, Lq, Lk, causal, masked = shape
@@ -174,7 +175,7 @@ def test_training_attention_on_the_matrix_cores_matches_attend_and_its_adjoint(s
         kmask2[:, 0] = True                      # AutoregressiveWrapper never drops the first token
     scale = 0.125
     ro, rq, rk, rv = _attend_reference(q, k, v, d_o, scale, causal, kmask, kmask2, H)
-    for mfma, tol in ((False, 2e-5), (True, 1e-2)):
+    for mfma, tol in ((0, 2e-5), (2, 2e-5), (1, 1e-2)):
         o, lse, dq, dk, dv = E.op_train_attention(q, k, v, scale, d_o=d_o, causal=causal, kmask=kmask, kmask2=kmask2, mfma=mfma)
         for name, got, ref in (("o", o, ro), ("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
             err = ((got.double() - ref).norm() / ref.norm()).item()
