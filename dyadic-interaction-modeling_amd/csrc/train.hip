@@ -235,23 +235,27 @@ int gemm_f32(Step& s, const void* A_op, int Kp, const void* W_op, int M, int N, 
 }
 
 // the cached operand pair of a forward input (made on first use; see Step::ops)
-const Step::OpCopy& fwd_operands(Step& s, const float* x, int ldx, int M, int K) {
+int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpCopy** out) {
     const auto key = std::make_tuple(x, ldx, M, K);
     auto it = s.ops.find(key);
-    if (it != s.ops.end()) return it->second;
-    Step::OpCopy c;
-    c.Kp = pad_to(K, s.bk);
-    c.Mp = pad_to(M, s.bk);
-    c.o = s.take((size_t)M * c.Kp * s.es());
-    c.t = s.take((size_t)K * c.Mp * s.es());
-    if (s.live()) (void)tr_prep_pair(s.at, x, ldx, M, K, c.o, c.Kp, c.t, c.Mp, s.st);
-    return s.ops.emplace(key, c).first->second;
+    if (it == s.ops.end()) {
+        Step::OpCopy c;
+        c.Kp = pad_to(K, s.bk);
+        c.Mp = pad_to(M, s.bk);
+        c.o = s.take((size_t)M * c.Kp * s.es());
+        c.t = s.take((size_t)K * c.Mp * s.es());
+        TR(tr_prep_pair(s.at, x, ldx, M, K, c.o, c.Kp, c.t, c.Mp, s.st));
+        it = s.ops.emplace(key, c).first;
+    }
+    if (out) *out = &it->second;
+    return DIMX_OK;
 }
 
 // y = x . W^T (+ b) (+ residual)
 int lin_fwd(Step& s, const Lin& l, const float* x, int ldx, int M, float* y, int ldy, const float* residual = nullptr, int ldr = 0) {
-    const Step::OpCopy& c = fwd_operands(s, x, ldx, M, l.K);
-    return gemm_f32(s, c.o, c.Kp, l.w_op, M, l.N, c.Kp, y, ldy, l.b >= 0 ? s.P + l.b : nullptr, residual, ldr);  // K padded with zeros
+    const Step::OpCopy* c;
+    DIMX_TRY(fwd_operands(s, x, ldx, M, l.K, &c));
+    return gemm_f32(s, c->o, c->Kp, l.w_op, M, l.N, c->Kp, y, ldy, l.b >= 0 ? s.P + l.b : nullptr, residual, ldr);  // K padded with zeros
 }
 
 // dx (+)= dy . W ; dW = dy^T . x ; db = colsum(dy).  x [M,K] (ldx), dy [M,N] (ldy) f32.  dx may be null.
@@ -348,7 +352,7 @@ int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C
     DIMX_TRY(lin_fwd(s, a.v, a.src, a.Ck, a.Mk, a.vb, inner));
     TR(tr_attn_fwd(a.shape, a.qb, a.kb, a.vb, a.ob, a.lse, s.st));
     if (qmask) {  // out = to_out(o) with padded query rows zero-filled, then the residual
-        (void)fwd_operands(s, a.ob, inner, M, inner);  // persistent: before the mark
+        DIMX_TRY(fwd_operands(s, a.ob, inner, M, inner, nullptr));  // persistent: before the mark
         const size_t mark = s.ar->off;
         float* tmp = s.f32((size_t)M * C);
         DIMX_TRY(lin_fwd(s, a.o, a.ob, inner, M, tmp, C));
@@ -469,7 +473,7 @@ int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int 
     for (auto& p : e.h) p = s.f32((size_t)M * C);
     e.out = s.f32((size_t)M * C);
     {
-        (void)fwd_operands(s, x_in, Cin, M, Cin);  // persistent: before the mark
+        DIMX_TRY(fwd_operands(s, x_in, Cin, M, Cin, nullptr));  // persistent: before the mark
         const size_t mark = s.ar->off;
         float* t = s.f32((size_t)M * C);
         DIMX_TRY(lin_fwd(s, e.pin, x_in, Cin, M, t, C));
