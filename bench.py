@@ -231,6 +231,8 @@ def main():
     }
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks
+    # batches dimx_generate had to regenerate because its XCD-local chain kernels / deferred LayerNorm reported a fault (0 expected)
+    out["chain_faults"] = int(eng.chain_faults())
     if world == 1 and args.mode == "bf16" and not args.no_parity_mode and args.samples == 1:
         # the same workload in the mode that meets north_star's tolerance (f32 operands, exact-f32 MFMA; VQ indices
         # and generated tokens bit-identical to the oracle): 2 warm-ups + 5 timed steps
