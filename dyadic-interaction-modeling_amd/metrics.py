@@ -33,6 +33,37 @@ def clip_fd(gt, pred):
     return calculate_frechet_distance(m1, s1, m2, s2)
 
 
+def frechet_distances_torch(y_true, y_pred, lens):
+    """The same Frechet distance for a whole batch at once, in torch float64 on whatever device the tensors live on (the GPU in
+    ``evaluate_test_epoch(fd_backend="device")``): y_true [B, L, F], y_pred [B, S, L, F], lens[j] = valid frames of clip j ->
+    fd [B, S].  Mean and unbiased covariance over the valid frames as eval_utils.py:6-10; the trace of the matrix square root
+    as sum sqrt(eig(A^T S2 A)) with S1 = A A^T (A = V sqrt(L) from eigh) -- the eigenvalues of S1 S2 without a non-symmetric
+    Schur form.  Mathematically the reference's quantity; NOT its arithmetic: scipy's sqrtm differs in the last digits and has
+    failure modes on rank-deficient covariances (clips shorter than F + 1 frames: complex results, the eps retry, the
+    "Imaginary component" ValueError) that this form does not have.  The host path above stays the default."""
+    import torch
+    B, S, L, F = y_pred.shape
+    dev = y_pred.device
+    n = torch.as_tensor(lens, dtype=torch.float64, device=dev)
+    m = (torch.arange(L, device=dev)[None, :] < n[:, None]).to(torch.float64)           # [B, L]
+
+    def stats(x, mm, nn):                      # x [..., L, F] float64, mm [..., L], nn [...]
+        mu = (x * mm[..., None]).sum(-2) / nn[..., None]
+        c = (x - mu[..., None, :]) * mm[..., None]
+        return mu, c.transpose(-1, -2) @ c / (nn[..., None, None] - 1.0)
+
+    mu1, s1 = stats(y_true.to(torch.float64), m, n)                                      # [B, F], [B, F, F]
+    mu2, s2 = stats(y_pred.to(torch.float64), m[:, None].expand(B, S, L), n[:, None].expand(B, S))
+    lam, V = torch.linalg.eigh(s1)
+    A = V * lam.clamp(min=0).sqrt()[..., None, :]                                        # S1 = A A^T
+    M = A.transpose(-1, -2)[:, None] @ s2 @ A[:, None]                                   # [B, S, F, F] symmetric PSD
+    M = 0.5 * (M + M.transpose(-1, -2))
+    tr_sqrt = torch.linalg.eigvalsh(M).clamp(min=0).sqrt().sum(-1)
+    diff = mu1[:, None] - mu2
+    tr = lambda t: torch.diagonal(t, dim1=-2, dim2=-1).sum(-1)
+    return (diff * diff).sum(-1) + tr(s1)[:, None] + tr(s2) - 2.0 * tr_sqrt
+
+
 def calculate_variance(activations):
     """eval_utils.py:48-49."""
     return np.sum(np.var(activations, axis=0))

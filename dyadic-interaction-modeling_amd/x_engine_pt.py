@@ -10,11 +10,34 @@ Multi-GPU: clips are independent, so each rank evaluates its own shard of every 
 replicated) and the per-clip predictions are all-gathered to every rank (``dimx.dist``); with one
 process the gather is the identity.
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
 from . import dist as ddist
 from .metrics import clip_fd
+
+_POOL = None
+
+
+def _metric_pool():
+    """Background worker(s) of the host-side Frechet distances.  One by default: scipy's sqrtm spends its 1.4 ms per (clip, try)
+    mostly under the GIL, more threads made it SLOWER (8 threads: 3.2 ms each on an 8-core host) -- the worker exists so that
+    the scoring of batch i overlaps the generation of batch i + 1, not to parallelise it.  DIMX_METRIC_THREADS overrides."""
+    global _POOL
+    n = int(os.environ.get("DIMX_METRIC_THREADS", "0")) or 1
+    if _POOL is None or _POOL._max_workers != n:
+        _POOL = ThreadPoolExecutor(max_workers=n, thread_name_prefix="dimx-fd")
+    return _POOL
+
+
+def _fd_or_error(gt, pred):
+    try:
+        return float(clip_fd(gt, pred)), None
+    except ValueError as e:          # scipy's "Imaginary component" on a degenerate clip
+        return float("inf"), e
 
 
 def _mask_from_lens(src, src_len, device):
@@ -91,8 +114,44 @@ def _gather_ragged(best, n_local, width, feat, device):
     return [None if n < 0 else pad[j, :n].copy() for j, n in enumerate(lens)]
 
 
+def _select_device(y_true, y_preds, lens, world, device):
+    """fd_backend="device": distances of all (clip, try) pairs in one batched float64 computation on the GPU; the first minimum
+    per clip wins (= the strict '<' of the reference's loop), a clip whose distances are all inf / nan keeps None."""
+    from .metrics import frechet_distances_torch
+    fd = frechet_distances_torch(y_true, y_preds, lens)                   # [nl, S]
+    fd = torch.where(torch.isnan(fd), torch.full_like(fd, float("inf")), fd)
+    win = fd.argmin(dim=1)
+    ok = torch.isfinite(fd.gather(1, win[:, None])[:, 0]).cpu().tolist()
+    chosen = y_preds[torch.arange(len(lens), device=y_preds.device), win].cpu().numpy()
+    best = [chosen[j][:lens[j]].copy() if ok[j] else None for j in range(len(lens))]
+    if world > 1:
+        best = _gather_ragged(best, len(lens), y_preds.shape[2], y_preds.shape[3], device)
+    return best
+
+
+def _select(pending, skip_degenerate, world, device):
+    """Best of the tries per clip, in the reference's order of evaluation (try-major, clip-minor; a candidate replaces the
+    current best only when its distance is strictly smaller; the first ValueError in that order propagates unless
+    skip_degenerate scores it as inf).  The distances come from the worker threads; which candidate wins does not depend
+    on how many there are."""
+    futs, samples, lens, nl, width, feat = pending
+    cur_best = [float("inf")] * nl
+    best = [None] * nl
+    for s_i, yp in enumerate(samples):
+        for j in range(nl):
+            cfid, err = futs[s_i][j].result()
+            if err is not None and not skip_degenerate:
+                raise err
+            if cfid < cur_best[j]:
+                best[j] = yp[j][:lens[j]].copy()
+                cur_best[j] = cfid
+    if world > 1:
+        best = _gather_ragged(best, nl, width, feat, device)
+    return best
+
+
 def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=True, skip_degenerate=False,
-                        **forward_kw):
+                        fd_backend="reference", **forward_kw):
     """reference code/x_engine_pt.py:232-277 (autoregressive generation, best of ``beam_size`` by FD; a candidate
     replaces the current best only when its FD is strictly smaller, and scipy's "Imaginary component" ValueError on a
     degenerate clip propagates, both as in the reference; ``skip_degenerate=True`` scores such a candidate as inf).
@@ -105,11 +164,22 @@ def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=Tru
     Multi-GPU (default process group initialised): every rank receives the full batch from its loader, generates and
     scores rows [lo, hi) of it (``batch_row_offset=lo`` and ``shard=(lo, B)`` keep positional rows and sampler
     streams those of the unsharded batch) and the selected predictions are all-gathered, so every rank returns the
-    complete lists."""
+    complete lists.
+
+    Host side: the beam_size x B Frechet distances of a batch (numpy covariance + scipy sqrtm in float64, the reference's own
+    arithmetic, 1.4 ms each) are computed by a background thread while the GPU generates the next batch, and the winner is then
+    picked in the reference's order -- same selections, bit for bit (tests/test_host_protocol_golden.py).  That arithmetic is
+    1.4 ms per (clip, try) of single-threaded scipy (it does not scale over threads): 3.6 s for 256 clips x 10 tries against
+    0.7 s of generation.  ``fd_backend="device"`` computes the same quantity for the whole batch in torch float64 on the GPU
+    (dimx.metrics.frechet_distances_torch: eigenvalues instead of scipy's sqrtm, so the last digits differ and rank-deficient
+    clips do not raise) and brings only the winners to the host."""
+    assert fd_backend in ("reference", "device")
     y_trues_all, y_preds_all, x_all, data_ids_all = [], [], [], []
     model.eval()
     batched = batched_samples and beam_size in BATCHED_SAMPLE_COUNTS
     rank, world = ddist.rank(), ddist.world_size()
+    pool = _metric_pool()
+    pending = None
     with torch.no_grad():
         for batch in loader:
             src_s_v, src_s_a, tgt, mask, src_len, data_ids = _prepare(batch, device)
@@ -123,21 +193,7 @@ def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=Tru
                 x_all.append(xs[j][:n])
             lo, hi = ddist.shard_bounds(B, rank, world)
             nl = hi - lo
-            cur_best = [float("inf")] * nl
-            best = [None] * nl
-
-            def consider(yp):           # yp [nl, T-1, 56] numpy: one sample per local clip
-                for j in range(nl):
-                    n = src_len[lo + j] - 1
-                    try:
-                        cfid = clip_fd(y_true[lo + j][:n], yp[j][:n])
-                    except ValueError:
-                        if not skip_degenerate:
-                            raise
-                        cfid = float("inf")
-                    if cfid < cur_best[j]:
-                        best[j] = yp[j][:n].copy()
-                        cur_best[j] = cfid
+            samples = []                 # per try: [nl, T-1, 56] numpy
             if nl > 0:
                 kw = dict(forward_kw)
                 if world > 1:
@@ -145,16 +201,29 @@ def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=Tru
                 sl = [t[lo:hi].contiguous() for t in (src_s_v, tgt, src_s_a, mask)]
                 if batched:
                     _, _, y_preds = model(sl[0], sl[1], sl[2], sl[3], mode="val", n_samples=beam_size, **kw)
-                    yp_all = y_preds.cpu().numpy()          # [nl, S, T-1, 56]
-                    for s_i in range(beam_size):
-                        consider(yp_all[:, s_i])
                 else:
-                    for _ in range(beam_size):
-                        _, _, y_preds = model(sl[0], sl[1], sl[2], sl[3], mode="val", **kw)
-                        consider(y_preds.cpu().numpy())
-            if world > 1:
-                best = _gather_ragged(best, nl, tgt.shape[1] - 1, tgt.shape[2], device)
-            y_preds_all.extend(best)
+                    y_preds = torch.stack([model(sl[0], sl[1], sl[2], sl[3], mode="val", **kw)[2] for _ in range(beam_size)], 1)
+                if fd_backend == "device":      # [nl, S, T-1, 56] stays on the device; only the winners travel
+                    if pending is not None:
+                        y_preds_all.extend(_select(pending, skip_degenerate, world, device))
+                        pending = None
+                    y_preds_all.extend(_select_device(tgt[lo:hi, 1:], y_preds, [src_len[lo + j] - 1 for j in range(nl)], world,
+                                                      device))
+                    continue
+                yp_all = y_preds.cpu().numpy()
+                samples = [yp_all[:, s_i] for s_i in range(beam_size)]
+            elif fd_backend == "device":
+                y_preds_all.extend(_gather_ragged([], 0, tgt.shape[1] - 1, tgt.shape[2], device) if world > 1 else [])
+                continue
+            # this batch's distances go to the worker threads; the PREVIOUS batch's are collected now, after this batch's
+            # generation has run in the meantime -- host scoring overlaps the GPU
+            if pending is not None:
+                y_preds_all.extend(_select(pending, skip_degenerate, world, device))
+            lens = [src_len[lo + j] - 1 for j in range(nl)]
+            futs = [[pool.submit(_fd_or_error, y_true[lo + j][:lens[j]], yp[j][:lens[j]]) for j in range(nl)] for yp in samples]
+            pending = (futs, samples, lens, nl, tgt.shape[1] - 1, tgt.shape[2])
+        if pending is not None:
+            y_preds_all.extend(_select(pending, skip_degenerate, world, device))
     return y_trues_all, y_preds_all, x_all, data_ids_all
 
 

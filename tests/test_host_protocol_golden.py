@@ -118,3 +118,24 @@ def test_legacy_loop_prints_the_reference_lines(tgold, capsys):
     got = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Epoch: [0]")]
     want = [str(l) for l in tgold["printed"] if str(l).startswith("Epoch: [0]")][:len(got)]
     assert got == want and len(got) == 3
+
+
+def test_device_frechet_backend_agrees_with_the_reference_arithmetic(gold):
+    """dimx.metrics.frechet_distances_torch (batched float64 torch, eigenvalue form) == the reference's numpy / scipy arithmetic
+    to 1e-6 relative on full-rank clips (the reference's np.mean of float32 frames is a float32 mean: 7e-9 observed), and evaluate_test_epoch(fd_backend="device") selects the candidates the reference's
+    own loop selected (tests/golden/host_protocol.npz)."""
+    from dimx import metrics, x_engine_pt
+    g = torch.Generator().manual_seed(3)
+    B, S, L, F = 5, 4, 90, 56
+    lens = [90, 77, 64, 90, 58]
+    yt = torch.randn(B, L, F, generator=g)
+    yp = 0.6 * yt[:, None] + 0.5 * torch.randn(B, S, L, F, generator=g)
+    fd = metrics.frechet_distances_torch(yt, yp, lens)
+    for j in range(B):
+        for s_i in range(S):
+            ref = metrics.clip_fd(yt[j, :lens[j]].numpy(), yp[j, s_i, :lens[j]].numpy())
+            assert abs(float(fd[j, s_i]) - ref) <= 1e-6 * abs(ref), (j, s_i, float(fd[j, s_i]), ref)
+    yt_, yp_, xs, ids = x_engine_pt.evaluate_test_epoch(stub_model.StubSLMFT(), stub_model.protocol_batches(), torch.device("cpu"),
+                                                        beam_size=10, fd_backend="device")
+    assert list(ids) == list(gold["test_ids"])
+    assert np.array_equal(_cat(yp_), gold["test_pred"])
