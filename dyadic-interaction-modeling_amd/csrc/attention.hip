@@ -51,7 +51,11 @@ template <typename T> __device__ __forceinline__ float fast_exp2(float x) {
 // DK = head-dim extent the kernel reduces over (64 for D in {48,64}; 96 for the 8 x 96 heads of the legacy
 // speaker VQ-VAE, hidden 768).  K rows are padded to DKP = 64 / 128 elements so the XOR swizzle stays a power
 // of two; the V^T tile has DK rows (NB = DK/32 output blocks) of 64 keys.
-template <typename T, int NW, int DK>
+// VROW (bf16, DK 64): V arrives row-major [key][d] like K (the fused q/k/v projection then has three row-contiguous destinations
+// and runs on the two-phase 256 x 256 GEMM); the transposition happens on the way into LDS -- a thread owns a column PAIR of
+// 4-key groups (one 4-byte load per key, coalesced over the 32 pairs of a key row), separates the two columns with v_perm_b32 and
+// writes two 8-byte pieces into the same swizzled V^T tile the rest of the kernel reads.  Same registers as the 16-byte staging.
+template <typename T, int NW, int DK, bool VROW = false>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;     // elements per 16-byte chunk
@@ -119,12 +123,31 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
             key = key < a.Lk ? key : a.Lk - 1;
             kreg[i] = (c * EPC < a.D) ? *(const uint4*)(K + (size_t)key * a.k_st + c * EPC) : make_uint4(0, 0, 0, 0);
         }
+        if constexpr (VROW) {
+            static_assert(!VROW || (sizeof(T) == 2 && DK == 64 && NW == 2), "row-major V: bf16, 64 head columns, 2 waves");
+            // thread = (column pair dp, key-group selector): 4 groups of 4 keys, one 4-byte load per key (2 columns of it)
+            const int dp = tid & 31, ksel = tid >> 5;
+            const uint16_t* vp = (const uint16_t*)Vt + 2 * dp;
 #pragma unroll
-        for (int i = 0; i < VI; ++i) {
-            const int idx = tid + i * NT;
-            const int d = idx / CPR, c = idx % CPR;
-            const int jj = j0 + c * EPC;
-            vreg[i] = (d < a.D && a.Lk - jj > 0) ? *(const uint4*)(Vt + (size_t)d * a.v_sd + jj) : make_uint4(0, 0, 0, 0);
+            for (int p = 0; p < 4; ++p) {
+                uint32_t e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // predicated loads, NOT load + select: a select consumes the value at once and the wave would wait for the
+                    // prefetch instead of computing under it (measured: 202 -> 397 us per call)
+                    const int key = j0 + 16 * p + 4 * ksel + i;
+                    e[i] = (2 * dp < a.D && key < a.Lk) ? *(const uint32_t*)(vp + (size_t)key * a.v_st) : 0u;
+                }
+                vreg[p] = make_uint4(e[0], e[1], e[2], e[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VI; ++i) {
+                const int idx = tid + i * NT;
+                const int d = idx / CPR, c = idx % CPR;
+                const int jj = j0 + c * EPC;
+                vreg[i] = (d < a.D && a.Lk - jj > 0) ? *(const uint4*)(Vt + (size_t)d * a.v_sd + jj) : make_uint4(0, 0, 0, 0);
+            }
         }
     };
     // bf16 only: in the f32 parity mode the 16 extra 16-byte registers cost a wave of occupancy (248 -> 314 VGPRs)
@@ -142,6 +165,21 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnArgs a) {
             const int row = idx / CPRK, c = idx % CPRK;
             *(uint4*)(sK + row * ROWBK + ((c ^ swz(row)) << 4)) = kreg[i];
         }
+        if constexpr (VROW) {
+            // keys 4 g4 .. 4 g4 + 3 of columns 2 dp (low halves) and 2 dp + 1 (high halves): two 8-byte pieces of the V^T tile, at the
+            // place the 16-byte staging of the transposed form puts them (chunk g4 / 2 swizzled by f / 2, halves swapped for odd f)
+            const int dp = tid & 31, ksel = tid >> 5, f = dp & 15;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int g4 = 4 * p + ksel;
+                const uint4 w = vreg[p];
+                const uint2 ev = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), __builtin_amdgcn_perm(w.w, w.z, 0x05040100u));
+                const uint2 od = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), __builtin_amdgcn_perm(w.w, w.z, 0x07060302u));
+                const int off = (((g4 >> 1) ^ (f >> 1)) << 4) + (((g4 & 1) ^ (f & 1)) << 3);
+                *(uint2*)(sV + (2 * dp) * ROWB + off) = ev;
+                *(uint2*)(sV + (2 * dp + 1) * ROWB + off) = od;
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < VI; ++i) {
             const int idx = tid + i * NT;
@@ -324,10 +362,17 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     DIMX_REQUIRE(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, DIMX_ERR_ARG, "attention: empty shape");
     DIMX_REQUIRE(a.D == 48 || a.D == 64 || a.D == 96, DIMX_ERR_ARG, "attention: head dim %d not in {48,64,96}", a.D);
     const int epc = a.dtype == DIMX_BF16 ? 8 : 4;
-    DIMX_REQUIRE(a.v_sd % epc == 0 && a.v_sd >= a.Lk && a.q_st % epc == 0 && a.k_st % epc == 0 && a.o_st % 4 == 0,
-                 DIMX_ERR_ARG, "attention: strides must keep 16-byte alignment (v_sd=%ld)", a.v_sd);
     constexpr int NW = 2;
     dim3 grid(ceil_div(a.Lq, 32 * NW), a.H, a.B), block(NW * 64);
+    if (a.v_rows) {
+        DIMX_REQUIRE(a.dtype == DIMX_BF16 && a.D <= 64 && a.v_st > 0 && a.q_st % epc == 0 && a.k_st % epc == 0 && a.o_st % 4 == 0,
+                     DIMX_ERR_ARG, "attention: row-major V needs bf16 operands and a head dim <= 64");
+        hipLaunchKernelGGL((attn_kernel<bf16, NW, 64, true>), grid, block, 0, s, a);
+        DIMX_HIP(hipGetLastError());
+        return DIMX_OK;
+    }
+    DIMX_REQUIRE(a.v_sd % epc == 0 && a.v_sd >= a.Lk && a.q_st % epc == 0 && a.k_st % epc == 0 && a.o_st % 4 == 0,
+                 DIMX_ERR_ARG, "attention: strides must keep 16-byte alignment (v_sd=%ld)", a.v_sd);
     if (a.D == 96) {
         if (a.dtype == DIMX_BF16)
             hipLaunchKernelGGL((attn_kernel<bf16, NW, 96>), grid, block, 0, s, a);

@@ -300,6 +300,8 @@ struct AttnArgs {
     long q_sb, q_st, q_sh;  // q element (b,i,h,d) at q + b*q_sb + i*q_st + h*q_sh + d
     long k_sb, k_st, k_sh;
     long v_sb, v_sh, v_sd;  // vt element (b,h,d,j) at vt + b*v_sb + h*v_sh + d*v_sd + j
+    int v_rows;             // 1: `vt` is V itself, row-major like k: element (b,j,h,d) at vt + b*v_sb + j*v_st + h*v_sh + d (bf16, D <= 64)
+    long v_st;
     long o_sb, o_st, o_sh;
     int B, H, Lq, Lk, D;
     float scale;

@@ -896,9 +896,10 @@ bool gemm256_eligible(const GemmArgs& g) {
     if (g.K % 64 != 0 || g.K != kext || g.M < 4096 || g.N < 256 || g.N % 8 != 0) return false;
     // measured (tools/bench_prefill.py, round 3, two-phase loop + scalar epilogue): ahead of the 128 x 128 kernel on every
     // prefill shape with min(N, K) >= 384 and N K >= 384 x 1536 -- (N 1536, K 384) 225 -> 199 us, (N 384, K 1536) 156 -> 128 us,
-    // (N 2304, K 384) 276 -> 174 us, level from K = 1152 up; one and a half column tiles of a 384 x 384 projection stay behind
+    // (N 2304, K 384) 276 -> 174 us, (N 1152, K 384: the VQ stacks' fused q/k/v, row-contiguous since V went row-major) 131 -> 85 us,
+    // level from K = 1152 up; the 384 x 384 projections stay behind (76 -> 106 us here)
     static const bool all = getenv("DIMX_G256_ALL") != nullptr;
-    if (!all && (g.K < 384 || g.N < 384 || (long)g.N * g.K < 384L * 1536L)) return false;
+    if (!all && (g.K < 384 || g.N < 384 || (long)g.N * g.K < 384L * 1152L)) return false;
     // ... and only with enough 256 x 256 tiles for the 256 CUs: at 4 800 rows (a training batch, a 16-clip prefill) N 768 K 1152
     // has 57 tiles and took 29.7 us against 18.9 on the 128 x 128 kernel, N 384 K 1536 (38 tiles) 33.1 against 13.0 on the
     // 64 x 64 one, 95 tiles (N 1152) 6 - 15 % behind; N 4608 K 1152 (342 tiles) 68.9 against 85.5 stays, and so do the 114 tiles

@@ -506,20 +506,29 @@ static int gemm_lin(const dimx_ctx* c, const void* A, int lda, const Linear& L, 
     return DIMX_OK;
 }
 
-// q / k row-major [M, segw], v transposed [B,H,D,Tp]
-static void set_qkv_out(GemmArgs& g, void* q, void* k, void* vt, int T, int H, int D, int Tp) {
+// Perf mode (round 3): V leaves the fused q/k/v projection row-major like q and k -- three row-contiguous destinations, which
+// is what the two-phase 256 x 256 GEMM stores -- and attn_kernel transposes it on the way into LDS (VROW).  The f32 parity mode
+// and the 96-column heads of the legacy speaker VQ-VAE keep the transposed destination.  DIMX_QKV_VT=1: the old form (A/B).
+static bool qkv_row_v(int at, int D) {
+    static const bool off = getenv("DIMX_QKV_VT") != nullptr;
+    return !off && at == DIMX_BF16 && D <= 64;
+}
+
+// q / k row-major [M, segw]; v transposed [B,H,D,Tp], or row-major too (rowv)
+static void set_qkv_out(GemmArgs& g, void* q, void* k, void* vt, int T, int H, int D, int Tp, bool rowv = false) {
     const int segw = H * D;
     g.rowT = T;
     g.nseg = 3;
     g.seg_width = segw;
-    for (int i = 0; i < 2; ++i) {
-        g.seg[i].ptr = i == 0 ? q : k;
+    for (int i = 0; i < (rowv ? 3 : 2); ++i) {
+        g.seg[i].ptr = i == 0 ? q : (i == 1 ? k : vt);
         g.seg[i].sb = (long)T * segw;
         g.seg[i].st = segw;
         g.seg[i].sh = D;
         g.seg[i].sd = 1;
         g.seg[i].D = D;
     }
+    if (rowv) return;
     g.seg[2].ptr = vt;
     g.seg[2].sb = (long)H * D * Tp;
     g.seg[2].sh = (long)D * Tp;
@@ -529,7 +538,7 @@ static void set_qkv_out(GemmArgs& g, void* q, void* k, void* vt, int T, int H, i
 }
 
 static void set_attn_packed(AttnArgs& a, int dtype, const void* q, const void* k, const void* vt, void* o, int B,
-                            int H, int Lq, int Lk, int D, int Tp_k) {
+                            int H, int Lq, int Lk, int D, int Tp_k, bool rowv = false) {
     memset(&a, 0, sizeof(a));
     const int segw = H * D;
     a.dtype = dtype;
@@ -546,6 +555,12 @@ static void set_attn_packed(AttnArgs& a, int dtype, const void* q, const void* k
     a.v_sb = (long)H * D * Tp_k;
     a.v_sh = (long)D * Tp_k;
     a.v_sd = Tp_k;
+    if (rowv) {
+        a.v_rows = 1;
+        a.v_sb = (long)Lk * segw;
+        a.v_st = segw;
+        a.v_sh = D;
+    }
     a.o_sb = (long)Lq * segw;
     a.o_st = segw;
     a.o_sh = D;
@@ -590,10 +605,11 @@ static int run_vq_blocks(const dimx_ctx* c, const VQGeom& vg, const VQBlock* blk
         DIMX_TRY(launch_layernorm(c->at, s.h, s.y, b.ln1_g, b.ln1_b, M, Hd, st));
         gemm_lin(c, s.y, Hd, b.qkv, M, g);
         g.out_dtype = c->at;
-        set_qkv_out(g, s.q, s.k, s.vt, T, heads, D, Tp);
+        const bool rowv = qkv_row_v(c->at, D);
+        set_qkv_out(g, s.q, s.k, s.vt, T, heads, D, Tp, rowv);
         DIMX_TRY(launch_gemm(g, st));
         AttnArgs a;
-        set_attn_packed(a, c->at, s.q, s.k, s.vt, s.o, B, heads, T, T, D, Tp);
+        set_attn_packed(a, c->at, s.q, s.k, s.vt, s.o, B, heads, T, T, D, Tp, rowv);
         a.scale = scale;
         a.lens = lens;
         DIMX_TRY(launch_attention(a, st));
@@ -1017,10 +1033,11 @@ static int run_xenc(const dimx_ctx* c, const EncGeom& eg, const XEnc& e, const v
         DIMX_TRY(launch_layernorm(c->at, s.h, s.y, e.attn[l].ln_g, nullptr, M, dim, st));
         gemm_lin(c, s.y, dim, e.attn[l].qkv, M, g);
         g.out_dtype = c->at;
-        set_qkv_out(g, s.q, s.k, s.vt, T, heads, D, Tp);
+        const bool rowv = qkv_row_v(c->at, D);
+        set_qkv_out(g, s.q, s.k, s.vt, T, heads, D, Tp, rowv);
         DIMX_TRY(launch_gemm(g, st));
         AttnArgs a;
-        set_attn_packed(a, c->at, s.q, s.k, s.vt, s.o, B, heads, T, T, D, Tp);
+        set_attn_packed(a, c->at, s.q, s.k, s.vt, s.o, B, heads, T, T, D, Tp, rowv);
         a.scale = 1.0f / sqrtf((float)D);
         a.causal = eg.causal;
         a.kmask = mask;
@@ -1437,9 +1454,10 @@ int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, c
         DIMX_TRY(launch_layernorm(h->at, s.h, s.y, h->dec.self_[l].ln_g, nullptr, M, DD, st));
         gemm_lin(h, s.y, DD, h->dec.self_[l].qkv, M, g);
         g.out_dtype = h->at;
-        set_qkv_out(g, s.q, s.k, s.vt, n, heads, D, np);
+        const bool rowv = qkv_row_v(h->at, D);
+        set_qkv_out(g, s.q, s.k, s.vt, n, heads, D, np, rowv);
         DIMX_TRY(launch_gemm(g, st));
-        set_attn_packed(a, h->at, s.q, s.k, s.vt, s.o, B, heads, n, n, D, np);
+        set_attn_packed(a, h->at, s.q, s.k, s.vt, s.o, B, heads, n, n, D, np, rowv);
         a.scale = scale;
         a.causal = 1;
         a.kmask = kv_mask;
@@ -1994,6 +2012,27 @@ int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, v
     a.q_sb = (long)Lq * ldq; a.q_st = ldq; a.q_sh = D;
     a.k_sb = (long)Lk * ldk; a.k_st = ldk; a.k_sh = D;
     a.v_sb = (long)H * D * ld_vt; a.v_sh = (long)D * ld_vt; a.v_sd = ld_vt;
+    a.o_sb = (long)Lq * ldo; a.o_st = ldo; a.o_sh = D;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D;
+    a.scale = scale;
+    a.causal = causal;
+    a.lens = lens;
+    a.kmask = kmask;
+    a.kmask_ld = Lk;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+int dimx_op_attention_rowv(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk, int D, int ldq,
+                           int ldk, int ldv, int ldo, float scale, int causal, const int32_t* lens, const uint8_t* kmask,
+                           void* stream) {
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = DIMX_BF16;
+    a.q = q; a.k = k; a.vt = v; a.o = out;
+    a.q_sb = (long)Lq * ldq; a.q_st = ldq; a.q_sh = D;
+    a.k_sb = (long)Lk * ldk; a.k_st = ldk; a.k_sh = D;
+    a.v_rows = 1;
+    a.v_sb = (long)Lk * ldv; a.v_st = ldv; a.v_sh = D;
     a.o_sb = (long)Lq * ldo; a.o_st = ldo; a.o_sh = D;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.D = D;
     a.scale = scale;

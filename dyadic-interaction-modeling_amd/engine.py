@@ -319,11 +319,19 @@ def op_instnorm(x, lens=None, out_bf16=False):
     return y
 
 
-def op_attention(q, k, v, scale, causal=False, lens=None, kmask=None, bf16=False):
-    """q [B,Lq,H,D], k/v [B,Lk,H,D] -> [B,Lq,H,D]; v is transposed to [B,H,D,Lk_pad] here."""
+def op_attention(q, k, v, scale, causal=False, lens=None, kmask=None, bf16=False, row_v=False):
+    """q [B,Lq,H,D], k/v [B,Lk,H,D] -> [B,Lq,H,D]; v is transposed to [B,H,D,Lk_pad] here, or (row_v, bf16) handed over
+    row-major like k."""
     lib = L.load()
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
+    if row_v:
+        q_, k_, v_ = (t.to(torch.bfloat16).reshape(B, -1, H * D).contiguous() for t in (q, k, v))
+        out = torch.empty(B, Lq, H * D, dtype=torch.bfloat16, device=q.device)
+        L.check(lib.dimx_op_attention_rowv(L.ptr(q_), L.ptr(k_), L.ptr(v_), L.ptr(out), B, H, Lq, Lk, D, H * D, H * D, H * D, H * D,
+                                           float(scale), 1 if causal else 0, L.ptr(lens), L.ptr(kmask), L.stream_ptr(q.device)),
+                "dimx_op_attention_rowv")
+        return out.view(B, Lq, H, D)
     dt = torch.bfloat16 if bf16 else torch.float32
     Lp = (Lk + 7) // 8 * 8
     q_ = q.to(dt).reshape(B, Lq, H * D).contiguous()

@@ -93,6 +93,8 @@ SIGNATURES = {
     "dimx_op_attention": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
                                   c_void_p]),
+    "dimx_op_attention_rowv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "dimx_op_decode_attn": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p, c_int, c_int, c_void_p]),
     "dimx_op_fused_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -269,6 +269,11 @@ int dimx_op_instnorm(int out_dtype, const float* x, void* y, const int32_t* lens
 int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int H,
                       int Lq, int Lk, int D, int ldq, int ldk, int ld_vt, int ldo, float scale,
                       int causal, const int32_t* lens, const uint8_t* kmask, void* stream);
+/* The same attention with v row-major like k ([B,Lk,H*D] bf16; what the perf mode's fused q/k/v projection writes since round 3:
+ * three row-contiguous destinations for the 256x256 GEMM, the transposition happens on the way into LDS).  bf16, D in {48,64}. */
+int dimx_op_attention_rowv(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk, int D, int ldq,
+                           int ldk, int ldv, int ldo, float scale, int causal, const int32_t* lens, const uint8_t* kmask,
+                           void* stream);
 /* One-query (autoregressive step) attention over a [B,H,Tmax,64] K/V cache, n_keys keys per (clip,head);
  * q/out are [B,H*64].  kmask optional [B,n_keys].  Cross-attention form (no cache append).
  * nsplit: waves per (clip, head) sharing the keys (1, 2, 4; 0 = automatic).  q_is_f32: q is a single f32 slab

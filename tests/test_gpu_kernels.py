@@ -213,6 +213,29 @@ def test_attention(dev, B, H, Lq, Lk, D, causal, lens, rand_mask, bf16):
         assert e < (2e-2 if bf16 else 2e-5), "attention err %g" % e
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,D,causal,lens,rand_mask", [
+    (2, 8, 40, 40, 48, False, [40, 13], False), (1, 8, 300, 300, 48, False, None, False),
+    (2, 12, 299, 299, 64, True, None, True), (2, 12, 129, 130, 64, False, None, True), (1, 12, 5, 5, 64, True, None, False)])
+def test_attention_with_row_major_v_is_the_same_kernel(dev, B, H, Lq, Lk, D, causal, lens, rand_mask):
+    """the row-major-V staging (what the perf mode's fused q/k/v projection feeds since round 3) builds the same LDS tile as the
+    transposed-V staging: bit-identical outputs."""
+    from dimx import engine
+    g = torch.Generator().manual_seed(Lq * 17 + D)
+    q, k, v = (torch.randn(B, L_, H, D, generator=g) for L_ in (Lq, Lk, Lk))
+    scale = 384 ** -0.5 if D == 48 else 0.125
+    kmask = None
+    if rand_mask:
+        kmask = (torch.rand(B, Lk, generator=g) > 0.3).to(torch.uint8)
+        kmask[:, 0] = 1
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    args = (q.to(dev), k.to(dev), v.to(dev), scale, causal, lens_t, kmask.to(dev) if kmask is not None else None)
+    a = engine.op_attention(*args, bf16=True)
+    b = engine.op_attention(*args, bf16=True, row_v=True)
+    for i in range(B):
+        n = lens[i] if lens else Lq
+        assert torch.equal(a[i, :n], b[i, :n])
+
+
 def test_vq_argmin_and_sampler(dev, golden_dir):
     from dimx import engine
     from oracle import ref_cpu
