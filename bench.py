@@ -154,6 +154,93 @@ def train_step_line(device, T, B=16, warm=2, steps=8):
                                     "csrc/train*.hip; PyTorch autograd on rocBLAS for the same step: tools/bench_train.py"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def ensure_ranks(args, argv):
+    """``--gpus N`` must mean N ranks, one per GPU -- or a non-zero exit, never a line that says ``n_gpus: 1``.
+
+    * under torchrun (WORLD_SIZE set): WORLD_SIZE must equal N, else exit 2;
+    * plain ``python bench.py --gpus N`` with N > 1: this process becomes the launcher -- it re-executes itself as
+      ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+      bench.py <same arguments>`` (one process per GPU, HSA_ENABLE_IPC_MODE_LEGACY=0), after checking that N GPUs are
+      visible (exit 2 with a message otherwise)."""
+    want = max(1, args.gpus)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != want:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d (refusing to report "
+                             "a %s-rank run as %d GPUs)" % (want, env_world, want, env_world, want))
+        return
+    if want == 1:
+        return
+    if not args.stub:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < want:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible on this node" % (want, have))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(want),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)      # the launcher's exit code is torchrun's
+
+
+class _StubModel:
+    """LAUNCHER SELF-TEST ONLY (``--stub``, tests/test_bench_launcher.py): a CPU stand-in with SLMFT's call shape whose
+    tokens depend on the clip's content, the seed and the GLOBAL row (shard window), so that the rank plumbing -- launch,
+    sharding, all-gather, digest, the JSON line -- runs on gloo without a GPU.  Its line says so and is not a measurement."""
+
+    def __call__(self, v_s, v_l, v_a, mask, mode="val", seed=0, return_tokens=True, n_samples=1, shard=None,
+                 batch_row_offset=0, **kw):
+        B, T = mask.shape
+        lo = shard[0] if shard else 0
+        rows = torch.arange(lo, lo + B)[:, None]
+        t = torch.arange(T - 1)[None, :]
+        tokens = (rows * 7919 + t * 104729 + int(seed) * 31 + (v_s[:, :T - 1, 0] * 1000).long()
+                  + (batch_row_offset - lo) * 17) % 512
+        pred = (tokens[..., None].float() * 1e-3).expand(B, T - 1, 56).contiguous()
+        return torch.zeros(()), {}, pred, tokens
+
+
+def shard_check(make_model, device, rank, world, T=60, per_rank=8):
+    """The SAME seeded global batch of G = per_rank * N clips generated by N ranks (rank r: rows [r G/N, (r+1) G/N) with
+    its sampler window and batch_row_offset) and all-gathered must equal what ONE rank generates for all G
+    clips, bit for bit (f32 parity mode): sha256 of both on the line (what tools/scale_check.py computes across
+    separate runs, here inside the one run the driver launches)."""
+    import hashlib
+    G = per_rank * world
+    lo = rank * per_rank
+    def clips(name, c):
+        return torch.from_numpy(prng.normal(SEED, "bench.shard." + name, (G, T, c)))
+    v_s, v_l, v_a = clips("v_speaker", 56), clips("v_listener", 56), clips("v_audio", 768)
+    model = make_model()
+    def run(a, b):
+        m = torch.ones(b - a, T, dtype=torch.bool, device=device)
+        m = mark_prefix(m) if device.type == "cuda" else m
+        _, _, pred, tok = model(v_s[a:b].to(device), v_l[a:b].to(device), v_a[a:b].to(device), m, mode="val",
+                                seed=SEED + 5, return_tokens=True, shard=(a, G), batch_row_offset=a)
+        return tok.reshape(b - a, T - 1).to(torch.int32), pred.reshape(b - a, -1).float().contiguous()
+    tok, pred = run(lo, lo + per_rank)
+    all_tok = ddist.all_gather_rows(tok)
+    all_pred = ddist.all_gather_rows(pred)
+    out = None
+    if rank == 0:
+        one_tok, one_pred = run(0, G)
+        d_sh = hashlib.sha256(all_tok.cpu().numpy().tobytes()).hexdigest()
+        d_one = hashlib.sha256(one_tok.cpu().numpy().tobytes()).hexdigest()
+        out = {"global_batch": G, "frames": T, "dtype": "f32", "tokens_sha256_sharded": d_sh, "tokens_sha256_one_rank": d_one,
+               "identical": d_sh == d_one, "max_abs_pred_diff": float((all_pred - one_pred).abs().max())}
+    ddist.barrier()
+    return out
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
         _cpu_worker(int(sys.argv[2]), int(sys.argv[3]))
@@ -170,21 +257,38 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
+    ap.add_argument("--no-shard-check", action="store_true")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher self-test on CPU / gloo, no kernels
     args = ap.parse_args()
 
-    rank, world, local = ddist.init_from_env()
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU")
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+    ensure_ranks(args, sys.argv[1:])          # N > 1 from plain python: re-executes under torch.distributed.run
+    rank, world, local = ddist.init_from_env("gloo" if args.stub else None)
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: %d rank(s) initialised for --gpus %d" % (world, args.gpus))
+    if args.stub:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU")
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
     B, T = args.batch, args.frames
     mode = L.MODE_PERF_BF16 if args.mode == "bf16" else L.MODE_PARITY_F32
 
-    model = SLMFT(synthetic_seed=SEED, numeric_mode=mode).eval()
-    v_s, v_l, v_a, mask = synth_batch(B, T, device, salt=rank)
-    eng = model.engine(device)
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    if args.stub:
+        model, eng = _StubModel(), None
+        g = torch.Generator().manual_seed(SEED + rank)
+        v_s, v_l, v_a = (torch.randn(B, T, c, generator=g) for c in (56, 56, 8))
+        mask = torch.ones(B, T, dtype=torch.bool)
+    else:
+        model = SLMFT(synthetic_seed=SEED, numeric_mode=mode).eval()
+        v_s, v_l, v_a, mask = synth_batch(B, T, device, salt=rank)
+        eng = model.engine(device)
 
     def step(i):
         _, _, pred, tokens = model(v_s, v_l, v_a, mask, mode="val", seed=SEED + i + 1, return_tokens=True,
@@ -195,42 +299,63 @@ def main():
     for i in range(args.warmup):
         step(i)
     ddist.barrier()
-    torch.cuda.synchronize(device)
+    sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         pred, gathered = step(args.warmup + i)
-    torch.cuda.synchronize(device)
+    sync()
     ddist.barrier()
-    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, device if world > 1 else None)
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, device if (world > 1 and device.type == "cuda") else None)
     assert gathered.shape == (world * B * args.samples, T - 1) and torch.isfinite(pred).all()
 
-    rccl_ranks = None
+    rccl_ranks = 1
+    check = None
     if world > 1:
         import torch.distributed as tdist
         one = torch.ones(1, device=device)
-        tdist.all_reduce(one)                 # RCCL saw this many ranks
+        tdist.all_reduce(one)                 # the collective library (RCCL on GPUs) saw this many ranks
         rccl_ranks = int(one.item())
+        if not args.no_shard_check:
+            check = shard_check((lambda: _StubModel()) if args.stub else
+                                (lambda: SLMFT(synthetic_seed=SEED, numeric_mode=L.MODE_PARITY_F32).eval()),
+                                device, rank, world)
         tdist.barrier()
         tdist.destroy_process_group()
     if rank != 0:
         return
     ms = elapsed / args.steps * 1e3
     clips_s = world * B * args.samples * args.steps / elapsed
+    names = {(256, 300): "C3", (64, 1500): "C5 per-GPU shard"}
+    if world > 1 and (B, T) == (256, 300):
+        tag = "C4 layout (256 clips per GPU x %d GPUs)" % world
+    else:
+        tag = names.get((B, T), "custom")
     out = {
         "metric": "listener clips/sec (T=%d, EMOCA-56)" % T + ("" if args.samples == 1 else " x %d samples per clip in one pass" % args.samples),
         "value": clips_s, "unit": "clips/s" if args.samples == 1 else "generated sequences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.mode == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": "C3: B=%d/GPU synthetic dyad clips, T=%d, SLMFT.forward(mode='val'): listener VQ "
+        "config": {"workload": "%s: B=%d/GPU synthetic dyad clips, T=%d, SLMFT.forward(mode='val'): listener VQ "
                                "encode + encoder + %d-step AR decode (top-k 52 sampling) + VQ decode"
-                               % (B, T, T - 1),
+                               % (tag, B, T, T - 1),
                    "global_batch": world * B, "seq_len": T, "parallelism": "dp%d (clips sharded, all-gather of "
                    "code indices)" % world},
         "achieved_tflops_necessary_work": clips_s * GFLOP_PER_CLIP_T300 * (T / 300.0) / 1e3,
+        "rccl_ranks": rccl_ranks,
     }
-    if rccl_ranks is not None:
-        out["rccl_ranks"] = rccl_ranks
+    if args.stub:
+        out["metric"] = "LAUNCHER SELF-TEST (--stub: CPU stand-in on gloo, no kernels) -- not a measurement"
+        out["data"] = "stub"
+    if check is not None:
+        out["shard_check"] = check
+    if rccl_ranks != world or (check is not None and not check["identical"]):
+        print(json.dumps(out))
+        raise SystemExit("bench.py: collective saw %d of %d ranks / sharded generation %s the one-rank result"
+                         % (rccl_ranks, world, "equals" if (check is None or check["identical"]) else "DIFFERS from"))
+    if args.stub:
+        print(json.dumps(out))
+        return
     # batches dimx_generate had to regenerate because its XCD-local chain kernels / deferred LayerNorm reported a fault (0 expected)
     out["chain_faults"] = int(eng.chain_faults())
     if world == 1 and args.mode == "bf16" and not args.no_parity_mode and args.samples == 1:
@@ -256,6 +381,8 @@ def main():
         from dimx import roofline
         out["roofline"] = roofline.dominant_kernel(eng, B, T, args.mode)
         out["cross_attn_mfma"] = roofline.cross_kv_gemm(B, T, args.mode, device)
+        if args.mode == "bf16":
+            out["cross_attn_bundle"] = roofline.cross_attn_bundle(B, T, args.mode, device, out["roofline"], out["cross_attn_mfma"])
     if world == 1 and args.mode == "bf16" and not args.no_train_step and args.samples == 1:
         out["train_step"] = train_step_line(device, T)
     if world == 1 and not args.no_cpu_baseline:

@@ -16,6 +16,8 @@
 // the same key order is used for the V^T operand, so P never moves between lanes.  The V operand is
 // consumed transposed ([B,H,D,Lk]), which is how the QKV GEMM epilogue writes it.
 // One wave = 32 queries, NW waves per block share the K / V^T tiles (64 keys) staged in LDS.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace dimx {
@@ -365,6 +367,10 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     constexpr int NW = 2;
     dim3 grid(ceil_div(a.Lq, 32 * NW), a.H, a.B), block(NW * 64);
     if (a.v_rows) {
+        // round 4: row-major V with 48- / 64-wide heads takes the shared-tile kernel of attention_tr.hip (DIMX_ATTN_OLD=1: this file's
+        // VROW form, for A/B runs)
+        static const bool old_form = getenv("DIMX_ATTN_OLD") != nullptr;
+        if (!old_form && a.dtype == DIMX_BF16 && (a.D == 48 || a.D == 64)) return launch_attention_tr(a, s);
         DIMX_REQUIRE(a.dtype == DIMX_BF16 && a.D <= 64 && a.v_st > 0 && a.q_st % epc == 0 && a.k_st % epc == 0 && a.o_st % 4 == 0,
                      DIMX_ERR_ARG, "attention: row-major V needs bf16 operands and a head dim <= 64");
         hipLaunchKernelGGL((attn_kernel<bf16, NW, 64, true>), grid, block, 0, s, a);

@@ -311,6 +311,7 @@ struct AttnArgs {
     int kmask_ld;
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
+int launch_attention_tr(const AttnArgs& a, hipStream_t s);  // attention_tr.hip: bf16, D 48 / 64, q / k / v row-major
 
 struct DecodeAttnArgs {
     int dtype;             // storage type of q / caches / out

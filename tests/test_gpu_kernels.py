@@ -213,12 +213,34 @@ def test_attention(dev, B, H, Lq, Lk, D, causal, lens, rand_mask, bf16):
         assert e < (2e-2 if bf16 else 2e-5), "attention err %g" % e
 
 
+def _attention_f64(q, k, v, scale, causal, lens, kmask):
+    """softmax(q k^T scale + masks) v in float64 on bf16-rounded operands (x-transformers' -max fill == -inf for rows with a visible key)."""
+    qd, kd, vd = (t.to(torch.bfloat16).double() for t in (q, k, v))
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    s = torch.einsum("bihd,bjhd->bhij", qd, kd) * scale
+    keep = torch.ones(B, 1, Lq, Lk, dtype=torch.bool)
+    if causal:
+        keep = keep & (torch.arange(Lk)[None, :] <= torch.arange(Lq)[:, None])[None, None]
+    if lens is not None:
+        keep = keep & (torch.arange(Lk)[None, :] < torch.tensor(lens)[:, None])[:, None, None, :]
+    if kmask is not None:
+        keep = keep & kmask.bool()[:, None, None, :]
+    s = s.masked_fill(~keep, float("-inf"))
+    return torch.einsum("bhij,bjhd->bihd", torch.softmax(s, -1), vd)
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,D,causal,lens,rand_mask", [
     (2, 8, 40, 40, 48, False, [40, 13], False), (1, 8, 300, 300, 48, False, None, False),
-    (2, 12, 299, 299, 64, True, None, True), (2, 12, 129, 130, 64, False, None, True), (1, 12, 5, 5, 64, True, None, False)])
-def test_attention_with_row_major_v_is_the_same_kernel(dev, B, H, Lq, Lk, D, causal, lens, rand_mask):
-    """the row-major-V staging (what the perf mode's fused q/k/v projection feeds since round 3) builds the same LDS tile as the
-    transposed-V staging: bit-identical outputs."""
+    (2, 12, 299, 299, 64, True, None, True), (2, 12, 129, 130, 64, False, None, True), (1, 12, 5, 5, 64, True, None, False),
+    (3, 12, 300, 300, 64, True, [300, 171, 64], False), (2, 12, 299, 300, 64, False, [300, 201], False),
+    (1, 8, 299, 299, 48, False, None, False), (1, 12, 700, 700, 64, True, None, True), (9, 3, 33, 65, 64, False, None, True),
+    (2, 8, 64, 64, 48, True, None, False), (1, 12, 1500, 1500, 64, True, None, False)])
+def test_row_major_v_attention_matches_f64_and_the_transposed_v_kernel(dev, B, H, Lq, Lk, D, causal, lens, rand_mask):
+    """round 4: row-major q / k / v with 48- / 64-wide heads run on attention_tr.hip (5-wave blocks on one XCD per (clip, head),
+    V through the transposing LDS read).  Checked against float64 on the same bf16-rounded operands and against the
+    transposed-V kernel of attention.hip (whose VROW form was bit-identical to it in round 3): both within bf16 output
+    rounding + the bf16 rounding of P."""
     from dimx import engine
     g = torch.Generator().manual_seed(Lq * 17 + D)
     q, k, v = (torch.randn(B, L_, H, D, generator=g) for L_ in (Lq, Lk, Lk))
@@ -229,11 +251,15 @@ def test_attention_with_row_major_v_is_the_same_kernel(dev, B, H, Lq, Lk, D, cau
         kmask[:, 0] = 1
     lens_t = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
     args = (q.to(dev), k.to(dev), v.to(dev), scale, causal, lens_t, kmask.to(dev) if kmask is not None else None)
-    a = engine.op_attention(*args, bf16=True)
-    b = engine.op_attention(*args, bf16=True, row_v=True)
+    a = engine.op_attention(*args, bf16=True).float().cpu()
+    b = engine.op_attention(*args, bf16=True, row_v=True).float().cpu()
+    ref = _attention_f64(q, k, v, scale, causal, lens, kmask).float()
+    assert torch.isfinite(b).all()
     for i in range(B):
-        n = lens[i] if lens else Lq
-        assert torch.equal(a[i, :n], b[i, :n])
+        n = min(lens[i], Lq) if lens else Lq           # rows of padded queries are never read by valid rows
+        assert (b[i, :n] - ref[i, :n]).abs().max().item() < 2.5e-2
+        assert (b[i, :n] - a[i, :n]).abs().max().item() < 2.5e-2
+        assert (b[i, :n] - ref[i, :n]).abs().mean().item() < 2e-3
 
 
 def test_vq_argmin_and_sampler(dev, golden_dir):
