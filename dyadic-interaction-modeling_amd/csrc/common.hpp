@@ -309,6 +309,7 @@ struct AttnArgs {
     const int32_t* lens;   // [B] optional
     const uint8_t* kmask;  // [B, kmask_ld] optional
     int kmask_ld;
+    int dbg;               // attention_tr.hip ablation bits (DIMX_ATTN_DBG, tuning only: results are wrong when set)
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 int launch_attention_tr(const AttnArgs& a, hipStream_t s);  // attention_tr.hip: bf16, D 48 / 64, q / k / v row-major

@@ -109,12 +109,17 @@ def _loader(ds, batch_size, shuffle, rank=0, world=1, seed=0):
 
 
 def get_vico_dataloaders(batch_size, data_path="../data/vico_processed_30fps", meta_data_path="../data/RLD_data.csv",
-                         synthetic=None, rank=None, world=None, seed=0):
+                         synthetic=None, rank=None, world=None, seed=0, shard_eval=False):
     """reference :461-478 -> {'train', 'valid', 'all'} loaders.  ``synthetic`` (a dict of SyntheticDyadDataset
     kwargs) asks for synthetic clips of the same format; without it the ViCo files must exist -- like the reference,
     which fails on a missing data directory -- so metrics on random clips can never pass for ViCo results.
-    ``rank`` / ``world`` (default: the initialised process group) shard every loader across the ranks of a multi-GPU job;
-    call ``loader.sampler.set_epoch(e)`` per epoch for a fresh shuffle."""
+    ``rank`` / ``world`` (default: the initialised process group) shard the TRAINING loaders ('train', 'all') across the ranks
+    of a multi-GPU job (``train_epoch`` calls ``loader.sampler.set_epoch(epoch)`` for a fresh shuffle per epoch).  The
+    evaluation loader 'valid' is NOT sharded by default: the evaluation loops (``evaluate_test_epoch`` /
+    ``evaluate_finetune_epoch``) expect every rank to see the same full batch -- the first splits its rows over the ranks itself
+    and all-gathers the winners, the second scores the whole set on every rank -- so a rank-sharded 'valid' loader would pair
+    gathered predictions with another rank's targets.  ``shard_eval=True`` shards 'valid' too, for callers
+    that gather targets / ids themselves."""
     if world is None:
         from .. import dist as ddist
         rank, world = ddist.rank(), ddist.world_size()
@@ -127,5 +132,6 @@ def get_vico_dataloaders(batch_size, data_path="../data/vico_processed_30fps", m
         kw = dict(synthetic or {})
         train = SyntheticDyadDataset(**kw)
         val = SyntheticDyadDataset(**{**kw, "seed": kw.get("seed", 20260928) + 1})
-    return {"train": _loader(train, batch_size, True, rank, world, seed), "valid": _loader(val, batch_size, False, rank, world, seed),
+    ev_rank, ev_world = (rank, world) if shard_eval else (0, 1)
+    return {"train": _loader(train, batch_size, True, rank, world, seed), "valid": _loader(val, batch_size, False, ev_rank, ev_world, seed),
             "all": _loader(data.ConcatDataset([train, val]), batch_size, True, rank, world, seed)}

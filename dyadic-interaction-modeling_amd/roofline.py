@@ -255,7 +255,7 @@ def prefill_cross_attention(B, T, device, iters=10):
     sec = _time_launches(run, 3, iters)
     flops = 4.0 * B * H * Lq * Lk * D
     tf = flops / sec / 1e12
-    return {"kernel": "attn_tr_kernel<64, 5> (row-major q / k / v, Lq %d x Lk %d, 12 heads x 64, context mask)" % (Lq, Lk),
+    return {"kernel": "attn_tr_kernel<64, 2> (persistent, row-major q / k / v, Lq %d x Lk %d, 12 heads x 64, context mask)" % (Lq, Lk),
             "avg_launch_us": sec * 1e6, "achieved": tf, "unit": "TFLOP/s", "util_pct": 100.0 * tf / MFMA_PEAK_TFLOPS["bf16"]}
 
 

@@ -73,6 +73,38 @@ class HipTrainer:
                 p = named[name]
                 p.copy_(self.params[off:off + numel].view_as(p))
 
+    # ------------------------------------------------------------------ torch.optim.AdamW <-> arenas
+    def import_optimizer_state(self, optimizer):
+        """adopt the moments / step count a torch.optim.AdamW already holds for the trained parameters (resuming from an
+        ``optimizer.load_state_dict``); parameters without state start from zero moments like a fresh AdamW."""
+        named = self._named()
+        step = 0
+        with torch.no_grad():
+            for name, off, numel in self.layout:
+                st = optimizer.state.get(named[name])
+                if not st:
+                    continue
+                self.exp_avg[off:off + numel].copy_(st["exp_avg"].reshape(-1).to(self.device, torch.float32))
+                self.exp_avg_sq[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1).to(self.device, torch.float32))
+                step = max(step, int(st["step"]))
+        self.step_count = max(self.step_count, step)
+
+    def export_optimizer_state(self, optimizer):
+        """write the moments and the step count into ``optimizer.state`` (the entries torch.optim.AdamW keeps per parameter), so
+        ``optimizer.state_dict()`` / a later autograd epoch continue from what the HIP steps left."""
+        named = self._named()
+        with torch.no_grad():
+            for name, off, numel in self.layout:
+                p = named[name]
+                st = optimizer.state[p]
+                for key, arena in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                    src = arena[off:off + numel].view_as(p)
+                    if key in st and st[key].shape == p.shape and st[key].device == p.device:
+                        st[key].copy_(src)
+                    else:
+                        st[key] = src.to(p.device, copy=True)
+                st["step"] = torch.tensor(float(self.step_count))
+
     def view(self, arena, name):
         for n, off, numel in self.layout:
             if n == name:

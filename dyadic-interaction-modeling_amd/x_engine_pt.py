@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import dist as ddist
+from . import lib as L
 from .metrics import clip_fd
 
 _POOL = None
@@ -260,17 +261,83 @@ def generate_sharded(model, v_speaker, v_listener, v_audio, mask, **forward_kw):
     return tokens, pred
 
 
-def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoch, log):
+def _set_epoch(loader, epoch):
+    """a DistributedSampler reshuffles per epoch only when told the epoch (otherwise every epoch replays the same order and
+    every rank keeps the same fixed subset)."""
+    sampler = getattr(loader, "sampler", None)
+    if sampler is not None and hasattr(sampler, "set_epoch"):
+        sampler.set_epoch(epoch)
+
+
+def _adopt_hyperparameters(trainer, optimizer):
+    """lr / betas / eps / weight_decay of a torch.optim.AdamW, read from its param_groups at every step (so a torch LR scheduler
+    attached to that optimizer drives the HIP step)."""
+    g = optimizer.param_groups[0]
+    trainer.lr, trainer.betas, trainer.eps, trainer.weight_decay = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+
+
+def _hip_trainer_for(model, optimizer, device, log):
+    """The HipTrainer that stands in for ``optimizer`` (a torch.optim.AdamW over this SLMFT's parameters), or None when the
+    reference call cannot be mapped onto the HIP step -- then the PyTorch-autograd restatement runs it, and the reason is logged.
+    Cached on the module per optimizer object: the AdamW moments and the step count live in the trainer's flat arenas between
+    epochs and are exported into ``optimizer.state`` at the end of every epoch (``optimizer.state_dict()`` stays meaningful)."""
+    from .train_hip import HipTrainer
+    inner = getattr(model, "module", model)
+    why = None
+    if getattr(inner, "engine_variant", None) != "slmft" or not hasattr(inner, "draw_kv_mask"):
+        why = "the HIP training step covers SLMFT (fine-tuning); %s trains on the autograd restatement" % type(inner).__name__
+    elif type(optimizer) is not torch.optim.AdamW:
+        why = "optimizer %s is not torch.optim.AdamW" % type(optimizer).__name__
+    elif torch.device(device).type != "cuda" or next(inner.parameters()).device.type != "cuda":
+        why = "module / device not on a ROCm GPU"
+    else:
+        gs = optimizer.param_groups
+        keys = ("lr", "betas", "eps", "weight_decay")
+        if any(g.get("amsgrad") or g.get("maximize") for g in gs):
+            why = "amsgrad / maximize are not implemented in dimx_train_adamw"
+        elif any(tuple(map(str, (g[k] for k in keys))) != tuple(map(str, (gs[0][k] for k in keys))) for g in gs[1:]):
+            why = "param_groups with different hyper-parameters"
+    if why is None:
+        cached = getattr(inner, "_dimx_hip_trainer", None)
+        if cached is not None and cached[0] is optimizer:
+            return cached[1]
+        tr = HipTrainer(inner, device=device)
+        have = {id(p) for g in optimizer.param_groups for p in g["params"]}
+        named = dict(inner.named_parameters())
+        missing = [n for n, _, _ in tr.layout if id(named[n]) not in have]
+        if missing:
+            why = "the optimizer does not hold %d of the %d trained tensors (first: %s)" % (len(missing), len(tr.layout), missing[0])
+        else:
+            tr.import_optimizer_state(optimizer)
+            inner._dimx_hip_trainer = (optimizer, tr)
+            return tr
+    log("train_epoch: " + why + " -- running this epoch on PyTorch autograd (dimx.train)")
+    return None
+
+
+def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoch, log, clip=None, optimizer=None):
     """train_epoch on the hand-written HIP training step (dimx.train_hip.HipTrainer): forward, backward, the gradient
     all-reduce (one flat RCCL collective), clipping and AdamW all run in libdimx_hip.so; the loop only feeds batches.  The
-    trained parameters are written back into the module at the end of the epoch (evaluation / state_dict see them)."""
+    trained parameters are written back into the module at the end of the epoch (evaluation / state_dict see them).
+    ``clip`` (when given) is the reference's argument and replaces the trainer's own; ``optimizer`` (a torch.optim.AdamW the
+    trainer stands in for) supplies lr / betas / eps / weight_decay per step and receives the moments at the end."""
     from . import train as T
     model.train()
+    if clip is not None:
+        trainer.clip = float(clip)
+    if scheduler is not None and optimizer is None:
+        optimizer = getattr(scheduler, "optimizer", None)
+        if optimizer is None or not hasattr(optimizer, "param_groups"):
+            raise L.DimxError("train_epoch: a scheduler needs a torch optimizer whose param_groups carry the learning rate; "
+                              "build it on torch.optim.AdamW and pass that optimizer, or set trainer.lr yourself")
     if ddist.world_size() > 1 and hasattr(loader, "__len__"):
         T.assert_same_batch_count(len(loader), device)
+    _set_epoch(loader, epoch)
     losses, ces, conts, all_losses = [], [], [], []
     for i, batch in enumerate(loader):
         src_s_v, src_s_a, tgt, mask, _, _ = _prepare(batch, device)
+        if optimizer is not None:
+            _adopt_hyperparameters(trainer, optimizer)
         loss, d_step = trainer.train_step(src_s_v, tgt, src_s_a, mask, with_cont_loss=True)   # the reference's total loss
         if scheduler is not None:
             scheduler.step()
@@ -286,20 +353,39 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoc
     if losses:
         all_losses += [float(v) for v in torch.stack(losses).cpu()]
     trainer.sync_to_model()
+    if optimizer is not None and type(optimizer) is torch.optim.AdamW:
+        trainer.export_optimizer_state(optimizer)
     return float(np.mean(all_losses)) if all_losses else float("nan")
 
 
-def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, print_freq=2000, epoch=0, log=print):
+def train_epoch(model, loader, optimizer, device, scheduler=None, clip=None, print_freq=2000, epoch=0, log=print, backward="auto"):
     """reference code/x_engine_pt.py:9-60: one pass over the loader with zero_grad / forward(mode='train') / backward /
-    clip / step.  ``optimizer`` = a ``dimx.train_hip.HipTrainer``: the whole step runs on the hand-written HIP kernels (the
-    default of examples/finetune_s2s_pretrain.py); a torch optimiser keeps the PyTorch-autograd restatement of round 2
-    (dimx.train), which is the checker of the HIP path.  For N > 1 processes the gradients are averaged over RCCL before clipping (dimx.train.all_reduce_grads);
-    every rank feeds its own loader shard (get_vico_dataloaders shards by rank through a DistributedSampler); the ranks must
-    see the same number of batches (checked) and start from rank 0's parameters (broadcast once).  Returns the mean loss."""
+    clip / step (``clip`` None = the reference's default 0., no clipping).
+
+    The reference's own call -- ``train_epoch(model, loader, torch.optim.AdamW(model.parameters(), lr=1e-5), device, clip=1.0)``
+    (code/finetune_s2s_pretrain.py:118-132) -- lands on the hand-written HIP training step: for an SLMFT on a GPU a
+    ``HipTrainer`` stands in for the AdamW (hyper-parameters read from its param_groups at every step, so torch schedulers
+    work; moments exported into ``optimizer.state`` after the epoch; ``sync_to_model()`` at the end of the epoch).  A
+    ``HipTrainer`` may also be passed as ``optimizer`` directly.  ``backward="autograd"`` (or a model / optimiser the HIP step
+    does not cover: SLM pre-training, the legacy generator, other optimisers) runs the PyTorch-autograd restatement
+    (dimx.train), which is the checker of the HIP path.  For N > 1 processes the gradients are averaged over RCCL before
+    clipping; every rank feeds its own loader shard (get_vico_dataloaders shards the training loaders by rank; the sampler is
+    told the epoch here); the ranks must see the same number of batches (checked) and start from rank 0's parameters."""
     from . import train as T
     from .train_hip import HipTrainer
     if isinstance(optimizer, HipTrainer):
-        return _train_epoch_hip(model, loader, optimizer, device, scheduler, print_freq, epoch, log)
+        return _train_epoch_hip(model, loader, optimizer, device, scheduler, print_freq, epoch, log, clip=clip)
+    if backward not in ("auto", "hip", "autograd"):
+        raise ValueError("backward must be 'auto', 'hip' or 'autograd'")
+    if backward != "autograd":
+        tr = _hip_trainer_for(model, optimizer, device, log)
+        if tr is not None:
+            return _train_epoch_hip(model, loader, tr, device, scheduler, print_freq, epoch, log,
+                                    clip=0.0 if clip is None else clip, optimizer=optimizer)
+        if backward == "hip":
+            raise L.DimxError("train_epoch(backward='hip'): this call cannot run on the HIP training step (see the log line)")
+    clip = 0.0 if clip is None else clip
+    _set_epoch(loader, epoch)
     model.train()
     inner = getattr(model, "module", model)
     # what the reference trains differs per model: SLMFT freezes both VQ-VAEs (:348-366), SLM only their encoders + codebooks (:98-113)

@@ -16,7 +16,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dimx  # noqa: E402,F401
 from dimx import dist as ddist  # noqa: E402
-from dimx import train as T  # noqa: E402
 from dimx.dataset.data_loader import get_vico_dataloaders  # noqa: E402
 from dimx.mymetrics import print_metrics  # noqa: E402
 from dimx.seq2seq_pretrain import SLMFT  # noqa: E402
@@ -30,27 +29,25 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--max-len", type=int, default=120)
     ap.add_argument("--out", default="best_vico_causal.pt")
-    ap.add_argument("--backward", default="hip", choices=["hip", "autograd"])
+    ap.add_argument("--backward", default="hip", choices=["hip", "autograd"],
+                    help="hip: forward + backward + clip + AdamW on csrc/train*.hip; autograd: the PyTorch restatement (checker)")
     args = ap.parse_args()
     rank, world, local = ddist.init_from_env()
     device = torch.device("cuda:{}".format(local))
     torch.cuda.set_device(device)
     model = SLMFT().to(device)
-    if args.backward == "hip":
-        from dimx.train_hip import HipTrainer
-        optimizer = HipTrainer(model, lr=1e-5, clip=1.0)   # AdamW(lr=1e-5) + clip 1.0 (code/finetune_s2s_pretrain.py:119,132)
-    else:
-        optimizer = T.make_optimizer(model, lr=1e-5)      # torch.optim.AdamW(model.parameters(), lr=1e-5)
+    # the reference's own lines (code/finetune_s2s_pretrain.py:118-119): train_epoch maps this AdamW onto the HIP training step
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-5)
     have_vico = os.path.isdir("../data/vico_processed_30fps")
     if not have_vico and rank == 0:
         print("no ViCo data under ../data: SYNTHETIC clips -- the numbers below are not ViCo results")
     dataset = get_vico_dataloaders(batch_size=args.batch,
                                    synthetic=None if have_vico else {"n_clips": args.clips, "max_len": args.max_len,
-                                                                     "min_len": 24, "seed": 20260928 + rank})
+                                                                     "min_len": 24, "seed": 20260928})   # same clips on every rank: the sampler shards them
     best = float("inf")
     for epoch in range(args.epochs):
         loss = train_epoch(model, dataset["train"], optimizer, device, scheduler=None, clip=1.0, print_freq=100,
-                           epoch=epoch, log=print if rank == 0 else (lambda *_: None))
+                           epoch=epoch, log=print if rank == 0 else (lambda *_: None), backward=args.backward)
         y_true, y_pred, x, _ = evaluate_finetune_epoch(model, dataset["valid"], device)
         if rank == 0:
             a, b = print_metrics(y_true, y_pred, x)

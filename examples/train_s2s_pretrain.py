@@ -39,7 +39,7 @@ def main():
         print("no dyad data under ../data: SYNTHETIC clips -- the losses below say nothing about the real task")
     dataset = get_vico_dataloaders(batch_size=args.batch,
                                    synthetic=None if have_vico else {"n_clips": args.clips, "max_len": args.max_len,
-                                                                     "min_len": 24, "seed": 20260928 + rank})
+                                                                     "min_len": 24, "seed": 20260928})   # same clips on every rank: the sampler shards them
     log = print if rank == 0 else (lambda *_: None)
     best = float("inf")
     for epoch in range(args.epochs):

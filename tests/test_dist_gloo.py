@@ -165,3 +165,59 @@ def test_sharded_generation_and_evaluation_equal_single_process_world2():
     part = m(v_s[4:], v_l[4:], v_a[4:], mask[4:])[2]
     good = m(v_s[4:], v_l[4:], v_a[4:], mask[4:], batch_row_offset=4, shard=(4, 7))[2]
     assert not torch.equal(part, full[4:]) and torch.equal(good, full[4:])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# evaluate_test_epoch over the loaders get_vico_dataloaders hands out.  The evaluation loop expects every
+# rank to see the SAME full batch (it splits the rows itself and all-gathers the winners); round 3 wrapped 'valid' in a
+# DistributedSampler, which paired gathered predictions with another rank's targets.  World size 2 must return exactly
+# the single-process lists -- targets, ids and the selected prediction of every clip.
+# ---------------------------------------------------------------------------------------------------------------
+def _loader_eval_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import dimx  # noqa: F401
+    from dimx import dist as dd
+    from dimx import x_engine_pt
+    from dimx.dataset.data_loader import get_vico_dataloaders
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank))
+        dd.init_from_env("gloo")
+    loaders = get_vico_dataloaders(batch_size=3, synthetic={"n_clips": 7, "max_len": 20, "min_len": 6, "seed": 11})
+    sharded = isinstance(loaders["train"].sampler, torch.utils.data.distributed.DistributedSampler)
+    eval_sharded = isinstance(loaders["valid"].sampler, torch.utils.data.distributed.DistributedSampler)
+    n_train = sum(b[0].shape[0] for b in loaders["train"])
+    yt, yp, xs, ids = x_engine_pt.evaluate_test_epoch(_StubListener(), loaders["valid"], torch.device("cpu"), beam_size=4)
+    q.put((rank, sharded, eval_sharded, n_train, [np.asarray(a) for a in yt], [np.asarray(a) for a in yp], list(ids)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _run_loader_eval(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_loader_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_evaluate_test_epoch_over_the_valid_loader_is_rank_invariant_world2():
+    import numpy as np
+    single = _run_loader_eval(1)[0]
+    assert not single[1] and not single[2] and single[3] == 7
+    both = _run_loader_eval(2)
+    assert sum(r[3] for r in both) == 8          # the TRAINING loader is sharded (7 clips -> 4 + 4 with one wrap-around)
+    for r in both:
+        assert r[1] and not r[2]                 # 'train' sharded, 'valid' not
+        assert r[6] == single[6] and len(r[5]) == 7
+        for a, b in zip(r[4], single[4]):
+            assert np.array_equal(a, b)          # targets in the single-process order
+        for a, b in zip(r[5], single[5]):
+            assert a.shape == b.shape and np.array_equal(a, b)     # the same winner for every clip
