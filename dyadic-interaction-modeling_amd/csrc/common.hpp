@@ -411,7 +411,8 @@ int launch_sample(const float* logits, int ld_logits, int R, int top_k, float te
                   int tok_col_from_step, int nslab, long slab_stride, float* logits_out, int logits_out_ld, int row0,
                   int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
                   hipStream_t s, const float* pos_table = nullptr, float pos_scale = 0.f, int pos_rows = 0,
-                  const int32_t* dev_params = nullptr);
+                  const int32_t* dev_params = nullptr,
+                  void* y_next = nullptr, const float* y_gamma = nullptr, int y_dtype = DIMX_F32);
 // generate(): zero the per-group step / done counters and store temperature + seed next to them (read by the sampler)
 int launch_gen_params(int32_t* base, int groups, float temperature, uint64_t seed, int row_off, int rows_total,
                       hipStream_t s);

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      float* __restrict__ x_next, int32_t* __restrict__ step_rw,
                                                      unsigned* __restrict__ done_ctr,
                                                      const float* __restrict__ pos_table, float pos_scale,
-                                                     int pos_rows, const int32_t* __restrict__ dev_params) {
+                                                     int pos_rows, const int32_t* __restrict__ dev_params,
+                                                     void* __restrict__ y_next, const float* __restrict__ y_gamma,
+                                                     int y_bf16) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint64_t step = step_dev ? (uint64_t)*step_dev : step_host;
     if (dev_params) {  // generate(): temperature / seed live in device memory so that the captured step graph
@@ -263,30 +265,74 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     if (x_next) {  // next step's decoder input: token embedding row (fused embed_step)
         const float2* src = (const float2*)(emb_table + (size_t)tok * emb_C);
         float2* dst = (float2*)(x_next + (size_t)row * emb_C);
-        if (pos_table && (int)step + 1 < pos_rows) {  // legacy decoder: + pos_emb[next position] * dim^-0.5
-            const float2* pr = (const float2*)(pos_table + (size_t)(step + 1) * emb_C);
-            for (int i = lane; i < emb_C / 2; i += 64) {
-                const float2 e = src[i], q = pr[i];
-                dst[i] = make_float2(__fadd_rn(e.x, __fmul_rn(q.x, pos_scale)), __fadd_rn(e.y, __fmul_rn(q.y, pos_scale)));
+        const bool with_pos = pos_table && (int)step + 1 < pos_rows;   // legacy decoder: + pos_emb[next position] * dim^-0.5
+        const float2* pr = with_pos ? (const float2*)(pos_table + (size_t)(step + 1) * emb_C) : nullptr;
+        // all of the row's loads in flight together, then the stores (a plain copy loop keeps load -> store order: up to
+        // 9 dependent L2 round trips at the tail of every decode step)
+        const int nv = emb_C / 2;
+        if (nv <= 16 * 64) {
+            float2 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = lane + 64 * k;
+                v[k] = src[i < nv ? i : nv - 1];
+            }
+            if (with_pos) {
+                float2 q[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    q[k] = pr[i < nv ? i : nv - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    v[k] = make_float2(__fadd_rn(v[k].x, __fmul_rn(q[k].x, pos_scale)), __fadd_rn(v[k].y, __fmul_rn(q[k].y, pos_scale)));
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = lane + 64 * k;
+                if (i < nv) dst[i] = v[k];
+            }
+            if (y_next) {
+                // round 4: the first decoder layer's pre-norm of this row rides along (y = LayerNorm(x) * gamma, no bias) -- one
+                // launch less per decode step.  Same lane <-> element map, summation order and wave reductions as
+                // add_slabs_layernorm_kernel (norm.hip), so the f32 parity mode's bits do not change.
+                float sm = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (lane + 64 * k < nv) sm += v[k].x + v[k].y;
+                const float inv_c = 1.0f / (float)emb_C;
+                const float mean = (y_bf16 ? wave_sum_sel<true>(sm) : wave_sum_sel<false>(sm)) * inv_c;
+                float qs = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (lane + 64 * k < nv) {
+                        const float a0 = v[k].x - mean, b0 = v[k].y - mean;
+                        qs += a0 * a0 + b0 * b0;
+                    }
+                const float rstd = rsqrtf((y_bf16 ? wave_sum_sel<true>(qs) : wave_sum_sel<false>(qs)) * inv_c + 1e-5f);
+                const float2* g2 = (const float2*)y_gamma;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < nv) {
+                        const float2 g = g2[i];
+                        const float o0 = (v[k].x - mean) * rstd * g.x, o1 = (v[k].y - mean) * rstd * g.y;
+                        if (y_bf16)
+                            *(uint32_t*)((bf16*)y_next + (size_t)row * emb_C + 2 * i) = pack_bf16x2(o0, o1);
+                        else
+                            *(float2*)((float*)y_next + (size_t)row * emb_C + 2 * i) = make_float2(o0, o1);
+                    }
+                }
             }
         } else {
-            // all of the row's loads in flight together, then the stores (a plain copy loop keeps load -> store order: up to
-            // 9 dependent L2 round trips at the tail of every decode step)
-            const int nv = emb_C / 2;
-            if (nv <= 16 * 64) {
-                float2 v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int i = lane + 64 * k;
-                    v[k] = src[i < nv ? i : nv - 1];
+            for (int i = lane; i < nv; i += 64) {
+                float2 e = src[i];
+                if (with_pos) {
+                    const float2 q = pr[i];
+                    e = make_float2(__fadd_rn(e.x, __fmul_rn(q.x, pos_scale)), __fadd_rn(e.y, __fmul_rn(q.y, pos_scale)));
                 }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int i = lane + 64 * k;
-                    if (i < nv) dst[i] = v[k];
-                }
-            } else {
-                for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+                dst[i] = e;
             }
         }
     }
@@ -482,13 +528,16 @@ int launch_sample(const float* logits, int ld_logits, int R, int top_k, float te
                   uint64_t seed, const int32_t* step_dev, uint64_t step_host, int32_t* tokens, int tok_ld,
                   int tok_col_from_step, int nslab, long slab_stride, float* logits_out, int logits_out_ld, int row0,
                   int rows_total, const float* emb_table, int emb_C, float* x_next, int32_t* step_rw, unsigned* done_ctr,
-                  hipStream_t s, const float* pos_table, float pos_scale, int pos_rows, const int32_t* dev_params) {
+                  hipStream_t s, const float* pos_table, float pos_scale, int pos_rows, const int32_t* dev_params,
+                  void* y_next, const float* y_gamma, int y_dtype) {
     DIMX_REQUIRE(logits && tokens && R > 0, DIMX_ERR_ARG, "sample: bad arguments");
+    DIMX_REQUIRE(!y_next || (x_next && y_gamma && emb_C % 128 == 0 && emb_C <= 2048), DIMX_ERR_ARG,
+                 "sample: the fused pre-norm needs the fused embedding and a width of k * 128 <= 2048");
     const int wpb = R <= 1024 ? 1 : 4;  // one row per block for decode-sized batches: all CUs busy
     hipLaunchKernelGGL(sample_kernel, dim3(ceil_div(R, wpb)), dim3(64 * wpb), 0, s, logits, ld_logits, R, top_k,
                        temperature, noise, seed, step_dev, step_host, tokens, tok_ld, tok_col_from_step, nslab < 1 ? 1 : nslab,
                        slab_stride, logits_out, logits_out_ld, row0, rows_total, emb_table, emb_C, x_next, step_rw, done_ctr,
-                       pos_table, pos_scale, pos_rows, dev_params);
+                       pos_table, pos_scale, pos_rows, dev_params, y_next, y_gamma, y_dtype == DIMX_BF16 ? 1 : 0);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

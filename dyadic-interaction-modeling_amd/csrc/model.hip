@@ -1565,8 +1565,13 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     ctx_mask += (size_t)clip0 * T;
     tokens += (size_t)row0 * n;
     if (logits_out) logits_out += (size_t)row0 * n * V;
+    // round 4: the sampler that writes the next step's embedding row also writes the first layer's pre-norm of it, so a step
+    // starts with y = LayerNorm(x) in place (DIMX_NO_FUSE_LN0=1: the separate launch, for A/B runs)
+    static const bool fuse_ln0 = getenv("DIMX_NO_FUSE_LN0") == nullptr;
     if (embed_only) {  // step 0 input = embedding of the start token (later steps: fused into the sampler)
-        return launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, S, st, pos, pos_scale);
+        DIMX_TRY(launch_embed_step(h->dec.tok_emb, DD, V, start, tokens, n, s.step, s.x, B, S, st, pos, pos_scale));
+        if (fuse_ln0) DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, 0, s0.st_xr, s.y, h->dec.self_[0].ln_g, B, DD, st));
+        return DIMX_OK;
     }
     // Every projection whose output is a small [B, N] f32 matrix is a split-K GEMM writing per-split slabs;
     // the consumer (LayerNorm / attention / sampler) adds the slabs in order: deterministic, no atomics, and
@@ -1576,6 +1581,12 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         gemm_lin(h, A, lda, L, B, g);
         g.out_dtype = DIMX_F32;
         g.out_slabs = 1;
+        // round 4: the f32 parity mode splits K too.  Slabs are plain stores added in slab order by the consumer -- deterministic,
+        // no atomics -- which is all "fixed summation order" asks for; without the split the mode's 64 x 64 tiles left most of
+        // the chip idle (M = 256: 72 blocks for the 1152-wide projections, 48 for cross-q, 32 for the logits; the K = 4608
+        // feed-forward projection ran 144 k-tiles on 72 CUs = 70 us): 261 of the mode's 505 ms per batch (profiles/r04_parity_*).
+        static const bool f32_split = getenv("DIMX_F32_NO_SPLIT") == nullptr;
+        if (f32_split) g.allow_splitk = 1;
         g.slab_stride = stride;
         gemm_set_plain_out(g, out, L.N);
         *nsl = gemm_plan_splits(g);
@@ -1634,7 +1645,8 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         GemmArgs g;
         DecodeAttnArgs a;
         int ns = 0;
-        DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.self_[l].ln_g, B, DD, st));
+        if (l > 0 || !fuse_ln0)
+            DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.self_[l].ln_g, B, DD, st));
         DIMX_TRY(slab_gemm(s.y, DD, h->dec.self_[l].qkv, s.qkv, s0.st_qkv, &ns));
         memset(&a, 0, sizeof(a));
         a.dtype = h->at;
@@ -1718,7 +1730,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     }
     DIMX_TRY(launch_sample(s.logits, V, B, top_k, temperature, noise, seed, s.step, 0, tokens, n, 1, nlg, s0.st_lg,
                            logits_out, n, row0, Btot, h->dec.tok_emb, DD, s.x, s.step, (unsigned*)(s.step + 8), st, pos,
-                           pos_scale, n, s.step + 2));
+                           pos_scale, n, s.step + 2, fuse_ln0 ? s.y : nullptr, h->dec.self_[0].ln_g, h->at));
     return DIMX_OK;
 }
 

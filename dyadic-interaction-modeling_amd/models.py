@@ -43,6 +43,7 @@ class _EngineOwner(nn.Module):
         self.numeric_mode = numeric_mode
         self._engine = None
         self._engine_version = None
+        self._engine_pin = 0          # > 0: inside a forward whose first engine() call already checked the weights
 
     def _weights_version(self):
         return tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict(keep_vars=True).items())
@@ -50,7 +51,36 @@ class _EngineOwner(nn.Module):
     def _engine_state_dict(self):
         raise NotImplementedError
 
+    def engine_pinned(self):
+        """Context manager for a forward pass made of several engine() calls (forward_vq -> forward_decoder ->
+        forward_vq_decoder): the weights are compared with the packed copy ONCE, at the first call inside the block -- the
+        comparison walks the state dict (505 tensors, ~1.5 ms), and repeated behind the generate call's host synchronisation it
+        ran with the GPU idle.  Parameters must not be modified inside the block."""
+        owner = self
+
+        class _Pin:
+            def __enter__(self_inner):
+                owner._engine_pin += 1
+                owner._engine_pin_checked = owner._engine_pin > 1 and getattr(owner, "_engine_pin_checked", False)
+                return owner
+
+            def __exit__(self_inner, *exc):
+                owner._engine_pin -= 1
+                if owner._engine_pin == 0:
+                    owner._engine_pin_checked = False
+                return False
+        return _Pin()
+
     def engine(self, device=None):
+        if self._engine_pin > 0 and getattr(self, "_engine_pin_checked", False) and self._engine is not None and (
+                device is None or self._engine.device == torch.device(device)):
+            return self._engine
+        eng = self._engine_checked(device)
+        if self._engine_pin > 0:
+            self._engine_pin_checked = True
+        return eng
+
+    def _engine_checked(self, device=None):
         if device is None:
             p = next(self.parameters())
             device = p.device

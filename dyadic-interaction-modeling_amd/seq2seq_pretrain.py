@@ -227,10 +227,11 @@ class SLMFT(_EngineOwner):
         if self._wants_grad(mode):
             return self._forward_autograd(v_speaker, v_listener, v_audio, mask, kv_mask=kv_mask, z_l=z_l,
                                           return_tokens=return_tokens)
-        return self._forward_nograd(v_speaker, v_listener, v_audio, mask, mode=mode, noise=noise, kv_mask=kv_mask,
-                                    greedy=greedy, seed=seed, temperature=temperature,
-                                    batch_row_offset=batch_row_offset, return_tokens=return_tokens,
-                                    n_samples=n_samples, shard=shard)
+        with self.engine_pinned():     # one weights check per forward, not one per stage
+            return self._forward_nograd(v_speaker, v_listener, v_audio, mask, mode=mode, noise=noise, kv_mask=kv_mask,
+                                        greedy=greedy, seed=seed, temperature=temperature,
+                                        batch_row_offset=batch_row_offset, return_tokens=return_tokens,
+                                        n_samples=n_samples, shard=shard)
 
     @torch.no_grad()
     def _forward_nograd(self, v_speaker, v_listener, v_audio, mask, mode="train", speaker_ids=None, listener_ids=None,
