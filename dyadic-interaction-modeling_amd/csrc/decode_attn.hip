@@ -197,6 +197,10 @@ int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s) {
     int nsplit = 1;
     if (pairs * 2 <= 3072) nsplit = 2;
     if (pairs * 4 <= 3072) nsplit = 4;
+    // f32 parity mode: the wave count decides the summation order, and a rank's shard of a batch must reproduce the rows of the
+    // whole batch bit for bit -- so it may depend on the cache length only, never on the batch (round 4; until then
+    // a 128-clip shard ran 2 waves per pair, the 256-clip batch 1, and equal tokens were a matter of no near-tie being hit)
+    if (a.dtype != DIMX_BF16) nsplit = a.Tmax >= 1024 ? 4 : (a.Tmax >= 512 ? 2 : 1);
     if (a.force_nsplit == 1 || a.force_nsplit == 2 || a.force_nsplit == 4) nsplit = a.force_nsplit;
     dim3 grid(ceil_div(pairs, 4 / nsplit)), block(256);
     const bool self = a.knew != nullptr;

@@ -1305,8 +1305,36 @@ int gemm_plan_splits(const GemmArgs& a) {
     if (cfg == 0) cfg = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) >= 512 ? 14 : 4;
     cfg_tile(cfg, bm, bn);
     const int tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
-    if (tiles >= 256) return 1;
     const int nk = kext / bk;
+    if (a.in_dtype != DIMX_BF16) {
+        // f32 (exact-f32 MFMA at the vector rate): a 64 x 64 tile's k-tile is 16 dependent 32x32x2 MFMAs per wave = 0.49 us of
+        // matrix time (0.6 - 0.73 us measured with the hand-off) -- the block is MFMA-bound, two blocks on a CU take twice as
+        // long, and the launch lasts ceil(blocks / CUs) rounds of ceil(nk / splits) k-tiles.  288 blocks (the bf16 sweet spot,
+        // where co-resident blocks overlap their latencies for free) is the WORST choice here: 1.125 rounds cost two.  Pick the
+        // split count that minimises rounds x k-tiles (+ a quarter k-tile per slab for its write and the consumer's read);
+        // tools/bench_f32_decode_gemm.py: qkv 25.6 -> 19.5 us at 3 splits, K = 4608 45 -> 36.6 us at 8, 768-wide q 11.1 -> ~6.
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+                n_cu <= 0)
+                n_cu = 256;
+        }
+        // The count must NOT depend on M: a rank's shard of a batch has to reproduce the rows of the whole batch bit for bit
+        // (test_c4_*), and the split decides the summation order.  It is planned for the design point M = 256.
+        const int tiles_ref = ceil_div(256, bm) * ceil_div(a.N, bn);
+        int best = 1;
+        float best_cost = 1e30f;
+        for (int sp = 1; sp <= 8 && sp <= nk; ++sp) {
+            const float cost = (float)(ceil_div(tiles_ref * sp, n_cu) * ceil_div(nk, sp)) + 0.25f * (float)sp;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = sp;
+            }
+        }
+        return best;
+    }
+    if (tiles >= 256) return 1;
     // measured (tools/bench_gemm.py under rocprofv3): ~288 blocks (one per CU + a few) is the sweet spot
     static const int target = getenv("DIMX_SPLIT_TARGET") ? atoi(getenv("DIMX_SPLIT_TARGET")) : 288;
     static const int min_nk = getenv("DIMX_SPLIT_MINNK") ? atoi(getenv("DIMX_SPLIT_MINNK")) : 6;  // k-tiles per split at least (swept 3..9)
