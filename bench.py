@@ -127,31 +127,40 @@ def cpu_baseline(T, timeout_s=300):
                 "sample": "cpu worker exceeded %d s on 8 clips x T=%d" % (timeout_s, T)}
 
 
-def train_step_line(device, T, B=16, warm=2, steps=8):
+def train_step_line(device, T, batches=(16, 4, 64), warm=2, steps=8):
     """SURVEY 8 row f3 next to the headline: one optimisation step of SLMFT (forward + backward + clip 1.0 + AdamW, the
     reference's train_epoch body, code/x_engine_pt.py:9-60) on the hand-written HIP training step, bf16 operands with f32
-    accumulation and f32 master weights; B clips of T frames, listener codes from the frozen VQ-VAE precomputed (they do
-    not depend on the trained weights).  Reported beside the metric, never part of ``value``."""
+    accumulation and f32 master weights; B clips of T frames (B = 16 is the line's own figure, B = 4 is the reference's ViCo
+    batch, code/finetune_s2s_pretrain.py:121, B = 64 shows the MFMA-bound end), listener codes from the frozen VQ-VAE
+    precomputed (they do not depend on the trained weights).  Reported beside the metric, never part of ``value``."""
     from dimx.train_hip import HipTrainer
     torch.cuda.empty_cache()
     m = SLMFT(synthetic_seed=SEED, numeric_mode=L.MODE_PERF_BF16).to(device)
-    v_s, v_l, v_a, mask = synth_batch(B, T, device, salt=7)
-    _, z = m.forward_vq(v_s, v_l, mask, with_speaker=False)
     tr = HipTrainer(m, lr=1e-5, clip=1.0)
-    for _ in range(warm):
-        tr.train_step(v_s, v_l, v_a, mask, kv_mask=False, z_l=z)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tr.train_step(v_s, v_l, v_a, mask, kv_mask=False, z_l=z)
-    torch.cuda.synchronize(device)
-    dt = (time.perf_counter() - t0) / steps
-    assert torch.isfinite(loss)
+    out = None
+    by_batch = {}
+    for B in batches:
+        v_s, v_l, v_a, mask = synth_batch(B, T, device, salt=7)
+        _, z = m.forward_vq(v_s, v_l, mask, with_speaker=False)
+        for _ in range(warm):
+            tr.train_step(v_s, v_l, v_a, mask, kv_mask=False, z_l=z)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.train_step(v_s, v_l, v_a, mask, kv_mask=False, z_l=z)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / steps
+        assert torch.isfinite(loss)
+        by_batch[str(B)] = {"ms_per_step": dt * 1e3, "clips_per_s": B / dt}
+        if out is None:
+            out = {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "batch": B, "frames": T, "dtype": "bf16",
+                   "steps": steps, "warmup": warm,
+                   "note": "SLMFT training step (forward + backward + clip + AdamW) on the HIP kernels of csrc/train*.hip; "
+                           "PyTorch autograd on rocBLAS for the same step: tools/bench_train.py"}
+    out["by_batch"] = by_batch
     del tr, m
     torch.cuda.empty_cache()
-    return {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "batch": B, "frames": T, "dtype": "bf16", "steps": steps,
-            "warmup": warm, "note": "SLMFT training step (forward + backward + clip + AdamW) on the HIP kernels of "
-                                    "csrc/train*.hip; PyTorch autograd on rocBLAS for the same step: tools/bench_train.py"}
+    return out
 
 
 def _free_port():

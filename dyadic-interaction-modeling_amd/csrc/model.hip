@@ -799,6 +799,7 @@ int dimx_destroy(dimx_handle h) {
     if (h->chain_stats_dev) (void)hipFree(h->chain_stats_dev);
     if (h->chain_err_host) (void)hipHostFree(h->chain_err_host);
     free_packed(h);
+    train_forget(h);   // the training plan cached for this handle (a later handle may reuse the address)
     delete h;
     return DIMX_OK;
 }
@@ -1915,8 +1916,25 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
         fprintf(stderr, "dimx: a residual row's mean exceeds 8 standard deviations; this batch is regenerated with the row-phase "
                         "LayerNorm and the deferred form stays off for this handle (DIMX_NO_DEFER_LN=1 avoids it from the start)\n");
     }
-    return generate_impl(h, start, ctx_mask, B, T, n_samples, temperature, top_k, exp_noise, seed, tokens, logits_out, ws,
-                         ws_bytes, stream, &chain_used);
+    DIMX_TRY(generate_impl(h, start, ctx_mask, B, T, n_samples, temperature, top_k, exp_noise, seed, tokens, logits_out, ws,
+                           ws_bytes, stream, &chain_used));
+    if (!chain_used) return DIMX_OK;
+    // the regeneration may still have run chain kernels (the bit-2 case keeps them on): it answers for its own flags too
+    //  -- a second fault takes the chain path off and regenerates once more on the one-kernel-per-op step
+    DIMX_HIP(hipEventSynchronize(h->chain_err_ev));
+    const unsigned e2 = *h->chain_err_host;
+    if (!e2) return DIMX_OK;
+    *h->chain_err_host = 0;
+    DIMX_HIP(hipMemsetAsync(h->chain_err_dev, 0, 64, (hipStream_t)stream));
+    h->graph_valid = false;
+    ++h->chain_faults;
+    h->use_chain = 0;
+    fprintf(stderr, "dimx: the regenerated batch reported chain flags 0x%x again; regenerating on the one-kernel-per-op step, the "
+                    "chain path stays off for this handle\n", e2);
+    DIMX_TRY(generate_impl(h, start, ctx_mask, B, T, n_samples, temperature, top_k, exp_noise, seed, tokens, logits_out, ws,
+                           ws_bytes, stream, &chain_used));
+    DIMX_REQUIRE(!chain_used, DIMX_ERR_STATE, "generate: the chain path is still active after it was switched off");
+    return DIMX_OK;
 }
 
 int dimx_chain_faults(dimx_handle h) { return h ? h->chain_faults : 0; }

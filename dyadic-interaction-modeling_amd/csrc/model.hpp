@@ -115,6 +115,10 @@ struct GraphKey {
 
 }  // namespace dimx
 
+namespace dimx {
+void train_forget(dimx_ctx* h);   // train.hip: drop the training plan cached for a handle (dimx_destroy)
+}
+
 struct dimx_ctx {
     int device = 0;
     dimx_dims d;

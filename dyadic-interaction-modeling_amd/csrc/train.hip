@@ -18,6 +18,7 @@
 // Activations needed by the backward pass are kept in the caller's workspace (dimx_train_workspace_bytes).
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -114,8 +115,14 @@ int build_plan(dimx_handle h, TrainPlan& p) {
     return DIMX_OK;
 }
 
+std::mutex g_plans_mu;
+std::map<dimx_handle, TrainPlan>& plans_map() {
+    static std::map<dimx_handle, TrainPlan> plans;  // handles are few and long-lived; erased by dimx_destroy (train_forget)
+    return plans;
+}
 TrainPlan* plan_of(dimx_handle h, int* rc) {
-    static std::map<dimx_handle, TrainPlan> plans;  // handles are few and long-lived
+    std::lock_guard<std::mutex> lock(g_plans_mu);
+    auto& plans = plans_map();
     auto it = plans.find(h);
     if (it == plans.end()) {
         TrainPlan p;
@@ -513,6 +520,12 @@ int enc_bwd(Step& s, EncSave& e, const float* d_out, float* dx_in) {
 }
 
 }  // namespace
+
+void train_forget(dimx_handle h) {
+    std::lock_guard<std::mutex> lock(g_plans_mu);
+    plans_map().erase(h);
+}
+
 }  // namespace dimx
 
 using namespace dimx;
@@ -687,6 +700,16 @@ int dimx_train_forward_backward(dimx_handle h, const float* params, float* grads
     DIMX_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0, DIMX_ERR_ARG,
                  "train: workspace must be 256-byte aligned, arenas 16-byte aligned");
     DIMX_HIP(hipSetDevice(h->device));
+    // the arena is planned while kernels are being launched: check the caller's workspace against the sizing pass FIRST (a pure
+    // host walk of the same allocation sequence) -- an undersized workspace used to be reported only after kernels had written
+    // past its end
+    {
+        size_t need = 0;
+        const uint8_t* some_mask = (const uint8_t*)0x100;
+        DIMX_TRY(train_run(h, nullptr, nullptr, nullptr, nullptr, some_mask, nullptr, kv_mask ? some_mask : nullptr, B, T, nullptr,
+                           logits_out ? (float*)0x100 : nullptr, nullptr, 0, nullptr, &need));
+        DIMX_REQUIRE(ws_bytes >= need, DIMX_ERR_WORKSPACE, "train: workspace %zu < required %zu (dimx_train_workspace_bytes)", ws_bytes, need);
+    }
     return train_run(h, params, grads, v_speaker, v_audio, mask, z_l, kv_mask, B, T, loss_out, logits_out, ws, ws_bytes, (hipStream_t)stream,
                      nullptr);
 }

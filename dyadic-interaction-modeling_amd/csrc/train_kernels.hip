@@ -205,8 +205,11 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnShape a, const floa
     for (int d = 0; d < 64; ++d) acc[d] = 0.f;
     for (int j = lane; j < a.Lk; j += 64) {
         const float* kr = kb + (size_t)j * a.ldk;
-        const float s = key_kept(a, b, i, j) ? dot64(qr, kr) * a.scale : kNegMax;
-        const float p = expf(s - L);
+        // a masked key carries probability 0 and receives no gradient (autograd through masked_fill; the matrix-core kernels
+        // do the same) -- expf(kNegMax - L) would be 1 for a row whose keys are ALL masked (L = -FLT_MAX + log n rounds to -FLT_MAX)
+        const bool kept = key_kept(a, b, i, j);
+        const float s = kept ? dot64(qr, kr) * a.scale : kNegMax;
+        const float p = kept ? expf(s - L) : 0.f;
         const float dp = dot64(gr, vb + (size_t)j * a.ldv);
         const float ds = p * (dp - dl) * a.scale;
 #pragma unroll
@@ -250,8 +253,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnShape a, const flo
     for (int i = lane; i < a.Lq; i += 64) {
         const float* qp = q + ((size_t)b * a.Lq + i) * a.ldq + h * 64;
         const float* gp = d_o + ((size_t)b * a.Lq + i) * a.ldo + h * 64;
-        const float s = key_kept(a, b, i, j) ? dot64(kr, qp) * a.scale : kNegMax;
-        const float p = expf(s - lp[i]);
+        const bool kept = key_kept(a, b, i, j);
+        const float s = kept ? dot64(kr, qp) * a.scale : kNegMax;
+        const float p = kept ? expf(s - lp[i]) : 0.f;   // masked: probability 0, no gradient (see attn_bwd_dq_kernel)
         const float dpv = dot64(vr, gp);
         const float ds = p * (dpv - dp_[i]) * a.scale;
 #pragma unroll
