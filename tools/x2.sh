@@ -1,4 +1,9 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_s2s.py tests/test_gpu_configs.py tests/test_gpu_fullsize.py tests/test_gpu_legacy.py tests/test_gpu_slm.py tests/test_gpu_kernels.py -x -q 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
-python bench.py --mode f32 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+O=gpurun_out/r04f; mkdir -p $O
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/p1 -- python tools/bench_attn.py > /dev/null 2>&1
+python tools/pmc_summary.py $O/p1 | grep -A9 "attn_tr_kernel<64"
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/p2 -- python tools/bench_attn.py > /dev/null 2>&1
+python tools/pmc_summary.py $O/p2 | grep -A9 "attn_tr_kernel<64"
+rocprofv3 --pmc SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_WAVES SQ_INSTS_MFMA SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/p3 -- python tools/bench_attn.py > /dev/null 2>&1
+python tools/pmc_summary.py $O/p3 | grep -A9 "attn_tr_kernel<64"
+rm -rf $O/p1 $O/p2 $O/p3
