@@ -144,7 +144,21 @@ struct Step {
     hipStream_t st;
     int at;          // operand type of the GEMMs
     int bk;          // k-tile of the operand type (64 bf16 / 32 f32)
-    float* part;     // column-reduction scratch [2 * kTrSlabs * maxC]
+    float* part;     // column-reduction scratch: max(2 * kLnBlocks * 1152, 2 * kTrSlabs * maxC) floats
+    FinTable fin;    // column reductions whose partial rows are added by ONE launch at the end of the backward pass
+    float* pool = nullptr;   // their partial rows: a region of its own (they outlive the sublayers' rolled-back scratch)
+    size_t pool_off = 0, pool_cap = 0;
+    bool pool_overflow = false;
+    float* pool_f32(size_t n_) {
+        n_ = (n_ + 63) / 64 * 64;
+        if (pool_off + n_ > pool_cap) {
+            pool_overflow = true;
+            return pool;
+        }
+        float* q = pool + pool_off;
+        pool_off += n_;
+        return q;
+    }
     int B, T, M, n, Md;
 
     size_t peak = 0;  // high-water mark of the arena: the sizing pass (ws == NULL) walks the same allocation sequence
@@ -181,6 +195,44 @@ struct Step {
         if (s.live()) DIMX_TRY(expr);     \
     } while (0)
 
+int flush_fin(Step& s) {
+    if (s.live() && s.fin.n > 0) DIMX_TRY(tr_multi_finish(s.fin, s.st));
+    s.fin.n = 0;
+    s.fin.total_blocks = 0;
+    return DIMX_OK;
+}
+int queue_fin(Step& s, const float* part, float* out, int C, int nslab) {
+    if (s.fin.n == kFinMax) DIMX_TRY(flush_fin(s));
+    FinDesc& d = s.fin.d[s.fin.n++];
+    d.part = part;
+    d.out = out;
+    d.C = C;
+    d.nslab = nslab;
+    d.blk0 = s.fin.total_blocks;
+    s.fin.total_blocks += ceil_div(C, 64);
+    return DIMX_OK;
+}
+// dx (+)= LN'(x) dy, d gamma (and d beta) queued; the partial rows come from the step's pool (read at the end of the backward pass).
+int ln_adjoint(Step& s, const float* x, const float* gamma, const float* dy, float* dx, int accumulate, int M, int C, float* dg, float* db) {
+    int rows = ceil_div(M, kLnBlocks);
+    rows = (rows + 3) / 4 * 4;
+    const int blocks = ceil_div(M, rows);
+    float* pg = s.pool_f32((size_t)blocks * C);
+    float* pb = db ? s.pool_f32((size_t)blocks * C) : nullptr;
+    int n = blocks;
+    if (s.live()) DIMX_TRY(tr_layernorm_bwd_fused(x, gamma, dy, dx, accumulate, M, C, pg, pb, &n, s.st));
+    DIMX_TRY(queue_fin(s, pg, dg, C, n));
+    if (db) DIMX_TRY(queue_fin(s, pb, db, C, n));
+    return DIMX_OK;
+}
+int bias_adjoint(Step& s, const float* dy, float* out, int M, int C) {
+    const int slabs = M < kTrSlabs * 8 ? 1 : kTrSlabs;
+    float* part = s.pool_f32((size_t)slabs * C);
+    int n = slabs;
+    if (s.live()) DIMX_TRY(tr_colsum_partial(dy, M, C, part, &n, s.st));
+    return queue_fin(s, part, out, C, n);
+}
+
 Lin make_lin(const Step& s, const std::string& wname, const std::string& bname = std::string()) {
     Lin l;
     const PInfo& pi = s.plan->params[s.plan->index.at(wname)];
@@ -213,6 +265,7 @@ int prep_lin(Step& s, Lin& l) {
     d.Kp = Kp;
     d.Np = Np;
     d.lds = l.K;
+    d.gelu = 0;
     d.tile0 = s.prep.total_tiles;
     d.tiles_k = ceil_div(Kp, 32);
     s.prep.total_tiles += ceil_div(Np, 32) * d.tiles_k;
@@ -242,7 +295,7 @@ int gemm_f32(Step& s, const void* A_op, int Kp, const void* W_op, int M, int N, 
 }
 
 // the cached operand pair of a forward input (made on first use; see Step::ops)
-int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpCopy** out) {
+int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpCopy** out, int gelu = 0) {
     const auto key = std::make_tuple(x, ldx, M, K);
     auto it = s.ops.find(key);
     if (it == s.ops.end()) {
@@ -251,7 +304,7 @@ int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpC
         c.Mp = pad_to(M, s.bk);
         c.o = s.take((size_t)M * c.Kp * s.es());
         c.t = s.take((size_t)K * c.Mp * s.es());
-        TR(tr_prep_pair(s.at, x, ldx, M, K, c.o, c.Kp, c.t, c.Mp, s.st));
+        TR(tr_prep_pair(s.at, x, ldx, M, K, c.o, c.Kp, c.t, c.Mp, s.st, gelu));
         it = s.ops.emplace(key, c).first;
     }
     if (out) *out = &it->second;
@@ -259,14 +312,18 @@ int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpC
 }
 
 // y = x . W^T (+ b) (+ residual)
-int lin_fwd(Step& s, const Lin& l, const float* x, int ldx, int M, float* y, int ldy, const float* residual = nullptr, int ldr = 0) {
+// (gelu: the operand is erf-GELU(x) -- applied inside the operand copy, the activation itself is never stored in f32)
+int lin_fwd(Step& s, const Lin& l, const float* x, int ldx, int M, float* y, int ldy, const float* residual = nullptr, int ldr = 0,
+            int gelu = 0) {
     const Step::OpCopy* c;
-    DIMX_TRY(fwd_operands(s, x, ldx, M, l.K, &c));
+    DIMX_TRY(fwd_operands(s, x, ldx, M, l.K, &c, gelu));
     return gemm_f32(s, c->o, c->Kp, l.w_op, M, l.N, c->Kp, y, ldy, l.b >= 0 ? s.P + l.b : nullptr, residual, ldr);  // K padded with zeros
 }
 
 // dx (+)= dy . W ; dW = dy^T . x ; db = colsum(dy).  x [M,K] (ldx), dy [M,N] (ldy) f32.  dx may be null.
-int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int ldy, int M, float* dx, int lddx, bool accumulate_dx) {
+int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int ldy, int M, float* dx, int lddx, bool accumulate_dx,
+            bool x_from_cache_only = false) {
+    if (l.b >= 0) DIMX_TRY(bias_adjoint(s, dy, s.G + l.b, M, l.N));
     const size_t mark = s.ar->off;
     const int Mp = pad_to(M, s.bk), Np = pad_to(l.N, s.bk);
     void* dyo = s.take((size_t)M * Np * s.es());     // dy and dy^T in the operand type: one pass over dy
@@ -278,12 +335,12 @@ int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int
     if (it != s.ops.end()) {
         xT = it->second.t;                            // made by the forward pass
     } else {
+        DIMX_REQUIRE(!x_from_cache_only, DIMX_ERR_STATE, "train: the forward pass left no operand copy of a transformed input");
         void* t = s.take((size_t)l.K * Mp * s.es());
         TR(tr_transpose_pad(s.at, x, ldx, t, Mp, M, l.K, s.st));
         xT = t;
     }
     TR(gemm_f32(s, dyT, Mp, xT, l.N, l.K, Mp, s.G + l.w, l.K, nullptr, nullptr, 0));  // contraction over the zero-padded rows
-    if (l.b >= 0) TR(tr_colsums(nullptr, dy, nullptr, s.G + l.b, M, l.N, s.part, 0, s.st));
     s.ar->off = mark;
     return DIMX_OK;
 }
@@ -291,9 +348,13 @@ int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int
 // ---------------------------------------------------------------------------------------------------------------- sublayers
 struct AttnSave {
     std::string pre;      // "...layers.N." prefix
-    Lin q, k, v, o;
+    // round 4: to_q / to_k / to_v are consecutive [inner, C] tensors of the flat arenas, so the projections are ONE Linear with
+    // 3 inner rows for self-attention (one forward GEMM, one dX GEMM over K = 3 inner, one dW GEMM, one operand copy of the
+    // joint gradient) and q + a joint k / v Linear for cross-attention (their inputs differ)
+    Lin qkv, q, kv, o;
     const float* h_in;    // residual stream before the sublayer [M, C]
-    float *y, *qb, *kb, *vb, *ob, *lse;  // LN output, projections, attention output, row LSE
+    float *y, *qb, *kb, *vb, *ob, *lse;  // LN output, projections (views of the joint buffers), attention output, row LSE
+    int ldq, ldkv;        // row strides of qb and of kb / vb
     const float* src;     // key/value source rows (y for self-attention, the context for cross-attention)
     int M, Mk, C, Ck;     // query rows, key rows, widths
     TrAttn shape;
@@ -304,19 +365,28 @@ struct FFSave {
     std::string pre;
     Lin f1, f2;
     const float* h_in;
-    float *y, *pre_act, *act;
+    float *y, *pre_act;   // (the activation exists only as the next Linear's operand copies)
     int M, C, F;
 };
 
-int attn_prepare(Step& s, AttnSave& a, const std::string& pre) {
+int attn_prepare(Step& s, AttnSave& a, const std::string& pre, bool cross) {
     a.pre = pre;
-    a.q = make_lin(s, pre + "1.to_q.weight");
-    a.k = make_lin(s, pre + "1.to_k.weight");
-    a.v = make_lin(s, pre + "1.to_v.weight");
+    a.cross = cross;
+    const Lin q = make_lin(s, pre + "1.to_q.weight"), k = make_lin(s, pre + "1.to_k.weight"), v = make_lin(s, pre + "1.to_v.weight");
+    DIMX_REQUIRE(k.w == q.w + (long)q.N * q.K && v.w == k.w + (long)k.N * k.K && q.K == k.K && k.K == v.K, DIMX_ERR_STATE,
+                 "train: to_q / to_k / to_v of %s are not consecutive in the arena", pre.c_str());
     a.o = make_lin(s, pre + "1.to_out.weight");
-    DIMX_TRY(prep_lin(s, a.q));
-    DIMX_TRY(prep_lin(s, a.k));
-    DIMX_TRY(prep_lin(s, a.v));
+    if (!cross) {
+        a.qkv = q;
+        a.qkv.N = q.N + k.N + v.N;
+        DIMX_TRY(prep_lin(s, a.qkv));
+    } else {
+        a.q = q;
+        a.kv = k;
+        a.kv.N = k.N + v.N;
+        DIMX_TRY(prep_lin(s, a.q));
+        DIMX_TRY(prep_lin(s, a.kv));
+    }
     DIMX_TRY(prep_lin(s, a.o));
     return DIMX_OK;
 }
@@ -332,78 +402,84 @@ int ff_prepare(Step& s, FFSave& f, const std::string& pre) {
 // h_out = h_in + to_out(attn(LN(h_in) Wq, src Wk, src Wv)); src = LN(h_in) (self) or ctx (cross, Mk rows of width Ck)
 int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C, bool cross, const float* ctx, int Mk, int Ck,
              const TrAttn& shape, const uint8_t* qmask) {
-    const int inner = a.q.N;
+    const int inner = a.o.K;
+    DIMX_REQUIRE(a.cross == cross, DIMX_ERR_STATE, "train: attention sublayer prepared for the other kind");
     a.h_in = h_in;
     a.M = M;
     a.C = C;
-    a.cross = cross;  // (not "ctx != NULL": the sizing pass walks this code with null arena pointers)
     a.Mk = cross ? Mk : M;
     a.Ck = cross ? Ck : C;
     a.qmask = qmask;
     a.y = s.f32((size_t)M * C);
-    a.qb = s.f32((size_t)M * inner);
-    a.kb = s.f32((size_t)a.Mk * inner);
-    a.vb = s.f32((size_t)a.Mk * inner);
+    if (!cross) {
+        a.qb = s.f32((size_t)M * 3 * inner);     // [M][q | k | v]
+        a.kb = a.qb + inner;
+        a.vb = a.qb + 2 * inner;
+        a.ldq = a.ldkv = 3 * inner;
+    } else {
+        a.qb = s.f32((size_t)M * inner);
+        a.kb = s.f32((size_t)a.Mk * 2 * inner);  // [Mk][k | v]
+        a.vb = a.kb + inner;
+        a.ldq = inner;
+        a.ldkv = 2 * inner;
+    }
     a.ob = s.f32((size_t)M * inner);
     a.lse = s.f32((size_t)shape.B * shape.H * shape.Lq);
     a.src = cross ? ctx : a.y;
     a.shape = shape;
-    a.shape.ldq = a.shape.ldk = a.shape.ldv = a.shape.ldo = inner;
+    a.shape.ldq = a.ldq;
+    a.shape.ldk = a.shape.ldv = a.ldkv;
+    a.shape.ldo = inner;
     // attention and its adjoints on the matrix cores (train_attn.hip): bf16 MFMA in the perf mode, exact-f32 MFMA in the parity
     // mode; DIMX_TRAIN_ATTN_VALU=1 keeps the one-wave-per-row f32 VALU kernels (the plain form both are checked against)
     static const bool valu_only = getenv("DIMX_TRAIN_ATTN_VALU") && atoi(getenv("DIMX_TRAIN_ATTN_VALU")) != 0;
     a.shape.mfma = valu_only ? 0 : (s.at == DIMX_BF16 ? 1 : 2);
     TR(launch_layernorm(DIMX_F32, h_in, a.y, s.p(a.pre + "0.0.weight"), nullptr, M, C, s.st));
-    DIMX_TRY(lin_fwd(s, a.q, a.y, C, M, a.qb, inner));
-    DIMX_TRY(lin_fwd(s, a.k, a.src, a.Ck, a.Mk, a.kb, inner));
-    DIMX_TRY(lin_fwd(s, a.v, a.src, a.Ck, a.Mk, a.vb, inner));
-    TR(tr_attn_fwd(a.shape, a.qb, a.kb, a.vb, a.ob, a.lse, s.st));
-    if (qmask) {  // out = to_out(o) with padded query rows zero-filled, then the residual
-        DIMX_TRY(fwd_operands(s, a.ob, inner, M, inner, nullptr));  // persistent: before the mark
-        const size_t mark = s.ar->off;
-        float* tmp = s.f32((size_t)M * C);
-        DIMX_TRY(lin_fwd(s, a.o, a.ob, inner, M, tmp, C));
-        TR(tr_zero_rows(tmp, qmask, M, C, s.st));
-        TR(tr_copy_cols(h_in, C, h_out, C, M, C, 0, s.st));
-        TR(tr_add(h_out, tmp, (long)M * C, s.st));
-        s.ar->off = mark;
+    if (!cross) {
+        DIMX_TRY(lin_fwd(s, a.qkv, a.y, C, M, a.qb, 3 * inner));
     } else {
-        DIMX_TRY(lin_fwd(s, a.o, a.ob, inner, M, h_out, C, h_in, C));
+        DIMX_TRY(lin_fwd(s, a.q, a.y, C, M, a.qb, inner));
+        DIMX_TRY(lin_fwd(s, a.kv, a.src, a.Ck, a.Mk, a.kb, 2 * inner));
     }
+    TR(tr_attn_fwd(a.shape, a.qb, a.kb, a.vb, a.ob, a.lse, s.st));
+    // encoders: to_out(o) with the padded query rows zero-filled, then the residual.  to_out has no bias, so zero rows of o give
+    // zero rows of to_out(o): the attention output's padded rows are zeroed in place and the projection keeps its residual epilogue
+    // (before round 4: projection into a temporary, zero_rows, copy, add)
+    if (qmask) TR(tr_zero_rows(a.ob, qmask, M, inner, s.st));
+    DIMX_TRY(lin_fwd(s, a.o, a.ob, inner, M, h_out, C, h_in, C));
     return DIMX_OK;
 }
 
 // dh: gradient wrt h_out on entry, wrt h_in on return (in place); dctx (cross-attention) accumulates the context gradient
 int attn_bwd(Step& s, AttnSave& a, float* dh, float* dctx) {
     const size_t mark = s.ar->off;
-    const int inner = a.q.N, M = a.M, C = a.C;
-    float* dout = dh;
-    if (a.qmask) {
-        dout = s.f32((size_t)M * C);
-        TR(tr_copy_cols(dh, C, dout, C, M, C, 0, s.st));
-        TR(tr_zero_rows(dout, a.qmask, M, C, s.st));
-    }
+    const int inner = a.o.K, M = a.M, C = a.C;
+    // the padded query rows of o are zero (forward), so dW_out = dh^T . o needs no masked copy of dh; the gradient that reaches
+    // the attention through those rows is zeroed after the projection's dX instead
     float* d_o = s.f32((size_t)M * inner);
-    DIMX_TRY(lin_bwd(s, a.o, a.ob, inner, dout, C, M, d_o, inner, false));
-    float* dq = s.f32((size_t)M * inner);
-    float* dk = s.f32((size_t)a.Mk * inner);
-    float* dv = s.f32((size_t)a.Mk * inner);
-    float* delta = s.f32((size_t)a.shape.B * a.shape.H * a.shape.Lq);
-    TR(tr_attn_bwd(a.shape, a.qb, a.kb, a.vb, a.ob, d_o, a.lse, delta, dq, inner, dk, inner, dv, inner, s.st));
-    float* dy = s.f32((size_t)M * C);
-    DIMX_TRY(lin_bwd(s, a.q, a.y, C, dq, inner, M, dy, C, false));
+    DIMX_TRY(lin_bwd(s, a.o, a.ob, inner, dh, C, M, d_o, inner, false));
+    if (a.qmask) TR(tr_zero_rows(d_o, a.qmask, M, inner, s.st));
+    float *dq, *dk, *dv;     // the same joint layouts as the forward projections
     if (!a.cross) {
-        DIMX_TRY(lin_bwd(s, a.k, a.y, C, dk, inner, M, dy, C, true));
-        DIMX_TRY(lin_bwd(s, a.v, a.y, C, dv, inner, M, dy, C, true));
+        dq = s.f32((size_t)M * 3 * inner);
+        dk = dq + inner;
+        dv = dq + 2 * inner;
     } else {
-        DIMX_TRY(lin_bwd(s, a.k, a.src, a.Ck, dk, inner, a.Mk, dctx, a.Ck, true));
-        DIMX_TRY(lin_bwd(s, a.v, a.src, a.Ck, dv, inner, a.Mk, dctx, a.Ck, true));
+        dq = s.f32((size_t)M * inner);
+        dk = s.f32((size_t)a.Mk * 2 * inner);
+        dv = dk + inner;
+    }
+    float* delta = s.f32((size_t)a.shape.B * a.shape.H * a.shape.Lq);
+    TR(tr_attn_bwd(a.shape, a.qb, a.kb, a.vb, a.ob, d_o, a.lse, delta, dq, a.ldq, dk, a.ldkv, dv, a.ldkv, s.st));
+    float* dy = s.f32((size_t)M * C);
+    if (!a.cross) {
+        DIMX_TRY(lin_bwd(s, a.qkv, a.y, C, dq, 3 * inner, M, dy, C, false));
+    } else {
+        DIMX_TRY(lin_bwd(s, a.q, a.y, C, dq, inner, M, dy, C, false));
+        DIMX_TRY(lin_bwd(s, a.kv, a.src, a.Ck, dk, 2 * inner, a.Mk, dctx, a.Ck, true));
     }
     // LayerNorm: d gamma = colsum(dy o xhat), dh += LN'(h_in) dy
-    float* xh = s.f32((size_t)M * C);
-    TR(tr_xhat(a.h_in, xh, M, C, s.st));
-    TR(tr_colsums(xh, dy, s.g(a.pre + "0.0.weight"), nullptr, M, C, s.part, 0, s.st));
-    TR(tr_layernorm_bwd(a.h_in, s.p(a.pre + "0.0.weight"), dy, dh, 1, M, C, s.st));
+    DIMX_TRY(ln_adjoint(s, a.h_in, s.p(a.pre + "0.0.weight"), dy, dh, 1, M, C, s.g(a.pre + "0.0.weight"), nullptr));
     s.ar->off = mark;
     return DIMX_OK;
 }
@@ -415,38 +491,27 @@ int ff_fwd(Step& s, FFSave& f, const float* h_in, float* h_out, int M, int C) {
     f.F = f.f1.N;
     f.y = s.f32((size_t)M * C);
     f.pre_act = s.f32((size_t)M * f.F);
-    f.act = s.f32((size_t)M * f.F);
     TR(launch_layernorm(DIMX_F32, h_in, f.y, s.p(f.pre + "0.0.weight"), nullptr, M, C, s.st));
     DIMX_TRY(lin_fwd(s, f.f1, f.y, C, M, f.pre_act, f.F));
-    TR(tr_gelu_fwd(f.pre_act, f.act, (long)M * f.F, s.st));
-    DIMX_TRY(lin_fwd(s, f.f2, f.act, f.F, M, h_out, C, h_in, C));
+    DIMX_TRY(lin_fwd(s, f.f2, f.pre_act, f.F, M, h_out, C, h_in, C, 1));
     return DIMX_OK;
 }
 int ff_bwd(Step& s, FFSave& f, float* dh) {
     const size_t mark = s.ar->off;
     const int M = f.M, C = f.C, F = f.F;
     float* da = s.f32((size_t)M * F);
-    DIMX_TRY(lin_bwd(s, f.f2, f.act, F, dh, C, M, da, F, false));
+    DIMX_TRY(lin_bwd(s, f.f2, f.pre_act, F, dh, C, M, da, F, false, true));   // x^T = gelu(pre_act)^T from the forward pass
     TR(tr_gelu_bwd(f.pre_act, da, da, (long)M * F, s.st));  // da becomes d pre-activation in place
     float* dy = s.f32((size_t)M * C);
     DIMX_TRY(lin_bwd(s, f.f1, f.y, C, da, F, M, dy, C, false));
-    float* xh = s.f32((size_t)M * C);
-    TR(tr_xhat(f.h_in, xh, M, C, s.st));
-    TR(tr_colsums(xh, dy, s.g(f.pre + "0.0.weight"), nullptr, M, C, s.part, 0, s.st));
-    TR(tr_layernorm_bwd(f.h_in, s.p(f.pre + "0.0.weight"), dy, dh, 1, M, C, s.st));
+    DIMX_TRY(ln_adjoint(s, f.h_in, s.p(f.pre + "0.0.weight"), dy, dh, 1, M, C, s.g(f.pre + "0.0.weight"), nullptr));
     s.ar->off = mark;
     return DIMX_OK;
 }
 
 // final / stand-alone LayerNorm: y = LN(x) gamma (+ beta)
 int ln_bwd_full(Step& s, const float* x, const std::string& gname, const std::string& bname, const float* dy, float* dx, int M, int C) {
-    const size_t mark = s.ar->off;
-    float* xh = s.f32((size_t)M * C);
-    TR(tr_xhat(x, xh, M, C, s.st));
-    TR(tr_colsums(xh, dy, s.g(gname), bname.empty() ? nullptr : s.g(bname), M, C, s.part, 0, s.st));
-    TR(tr_layernorm_bwd(x, s.p(gname), dy, dx, 0, M, C, s.st));
-    s.ar->off = mark;
-    return DIMX_OK;
+    return ln_adjoint(s, x, s.p(gname), dy, dx, 0, M, C, s.g(gname), bname.empty() ? nullptr : s.g(bname));
 }
 
 // ---------------------------------------------------------------------------------------------------------------- encoder
@@ -472,7 +537,7 @@ int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int 
     e.attn.resize(d.enc_depth);
     e.ff.resize(d.enc_depth);
     for (int i = 0; i < d.enc_depth; ++i) {
-        DIMX_TRY(attn_prepare(s, e.attn[i], pre + "attn_layers.layers." + std::to_string(2 * i) + "."));
+        DIMX_TRY(attn_prepare(s, e.attn[i], pre + "attn_layers.layers." + std::to_string(2 * i) + ".", false));
         DIMX_TRY(ff_prepare(s, e.ff[i], pre + "attn_layers.layers." + std::to_string(2 * i + 1) + "."));
     }
     DIMX_TRY(flush_prep(s));
@@ -583,6 +648,15 @@ static int train_run(dimx_handle h, const float* params, float* grads, const flo
     s.prep.total_tiles = 0;
     const int DD = d.dim + d.dim_a, F = DD * d.ff_mult, inner = d.heads * d.dim_head;
     s.part = s.f32((size_t)2 * kTrSlabs * F);
+    {   // partial rows of the deferred column reductions: LayerNorm adjoints (<= kLnBlocks + 3 rows of <= DD each, two for norm_s) and
+        // bias / patch-embedding gradients (<= kTrSlabs rows of <= F)
+        const size_t n_ln = (size_t)(4 * d.enc_depth + 3 * d.dec_depth + 12), n_b = (size_t)(4 * d.enc_depth + 2 * d.dec_depth + 4);
+        s.pool_cap = n_ln * (kLnBlocks + 4) * (size_t)DD + n_b * kTrSlabs * (size_t)F + 4096;
+        s.pool = s.f32(s.pool_cap);
+        s.pool_off = 0;
+        s.fin.n = 0;
+        s.fin.total_blocks = 0;
+    }
     const bool live = ws != nullptr;
     if (live) DIMX_HIP(hipMemsetAsync(grads, 0, (size_t)plan->total * sizeof(float), st));
 
@@ -607,8 +681,8 @@ static int train_run(dimx_handle h, const float* params, float* grads, const flo
     std::vector<AttnSave> sa(d.dec_depth), ca(d.dec_depth);
     std::vector<FFSave> ff(d.dec_depth);
     for (int i = 0; i < d.dec_depth; ++i) {
-        DIMX_TRY(attn_prepare(s, sa[i], dn + "attn_layers.layers." + std::to_string(3 * i) + "."));
-        DIMX_TRY(attn_prepare(s, ca[i], dn + "attn_layers.layers." + std::to_string(3 * i + 1) + "."));
+        DIMX_TRY(attn_prepare(s, sa[i], dn + "attn_layers.layers." + std::to_string(3 * i) + ".", false));
+        DIMX_TRY(attn_prepare(s, ca[i], dn + "attn_layers.layers." + std::to_string(3 * i + 1) + ".", true));
         DIMX_TRY(ff_prepare(s, ff[i], dn + "attn_layers.layers." + std::to_string(3 * i + 2) + "."));
     }
     Lin lg = make_lin(s, dn + "to_logits.weight");
@@ -670,13 +744,15 @@ static int train_run(dimx_handle h, const float* params, float* grads, const flo
     }
     // context -> x_s (+ patch_embed_dec_s) ; the audio half has no parameters behind it
     TR(tr_copy_cols(dctx, DD, dx_s, d.dim, s.M, d.dim, 0, st));
-    TR(tr_colsums(nullptr, dx_s, nullptr, s.g("patch_embed_dec_s"), s.M, d.dim, s.part, 0, st));
+    DIMX_TRY(bias_adjoint(s, dx_s, s.g("patch_embed_dec_s"), s.M, d.dim));
     DIMX_TRY(ln_bwd_full(s, ej.out, "norm_s.weight", "norm_s.bias", dx_s, d_ej, s.M, d.dim));
     DIMX_TRY(enc_bwd(s, ej, d_ej, d_es));
     DIMX_TRY(enc_bwd(s, es, d_es, d_x0));
-    TR(tr_colsums(nullptr, d_x0, nullptr, s.g("patch_embed_s"), s.M, d.dim_in, s.part, 0, st));
+    DIMX_TRY(bias_adjoint(s, d_x0, s.g("patch_embed_s"), s.M, d.dim_in));
+    DIMX_TRY(flush_fin(s));   // every queued column reduction: one launch
     (void)inner;
     if (need) *need = s.peak + 256;
+    DIMX_REQUIRE(!s.pool_overflow, DIMX_ERR_STATE, "train: the partial-row pool of the column reductions is too small");
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "train: workspace %zu < required %zu", ws_bytes, s.peak);
     return DIMX_OK;
 }

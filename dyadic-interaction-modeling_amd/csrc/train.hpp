@@ -5,6 +5,7 @@
 namespace dimx {
 
 constexpr int kTrSlabs = 32;  // row slabs of the deterministic column reductions
+constexpr int kLnBlocks = 600; // blocks (= partial rows) of the fused LayerNorm adjoint
 
 struct TrAttn {
     int B, H, Lq, Lk;
@@ -27,6 +28,7 @@ struct PrepDesc {
     int lds;      // row stride of src (elements)
     int tile0;    // first 32 x 32 tile of this matrix in the launch
     int tiles_k;  // tiles along K
+    int gelu;     // 1: the copies hold erf-GELU(src) (the feed-forward activation as the next Linear's operand)
 };
 struct PrepTable {
     PrepDesc d[kPrepMax];
@@ -35,7 +37,7 @@ struct PrepTable {
 };
 int tr_prep_weights(int out_dtype, const PrepTable& t, hipStream_t s);
 // the same pair of copies for ONE matrix (an activation [rows][cols] with row stride lds): o [rows][Kp], t [cols][Mp]
-int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, void* o, int Kp, void* t, int Mp, hipStream_t s);
+int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, void* o, int Kp, void* t, int Mp, hipStream_t s, int gelu = 0);
 int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s);
 int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
 int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
@@ -45,7 +47,23 @@ int tr_attn_bwd_mfma(const TrAttn& t, const float* q, const float* k, const floa
                      const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, hipStream_t s);
 int tr_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, int accumulate, int M, int C, hipStream_t s);
 int tr_xhat(const float* x, float* xh, int M, int C, hipStream_t s);
-int tr_colsums(const float* xh, const float* dy, float* dg, float* db, int M, int C, float* part, int accumulate, hipStream_t s);
+int tr_layernorm_bwd_fused(const float* x, const float* gamma, const float* dy, float* dx, int accumulate, int M, int C, float* part_g,
+                           float* part_b, int* nrows, hipStream_t s);
+int tr_colsum_partial(const float* dy, int M, int C, float* part, int* nrows, hipStream_t s);
+// deferred column reductions: out[c] = sum_i part[i][c], i < nslab, for up to kFinMax entries in one launch
+constexpr int kFinMax = 96;
+struct FinDesc {
+    const float* part;
+    float* out;
+    int C, nslab;
+    int blk0;     // first block of this entry in the launch (one block per 64 columns)
+};
+struct FinTable {
+    FinDesc d[kFinMax];
+    int n;
+    int total_blocks;
+};
+int tr_multi_finish(const FinTable& t, hipStream_t s);
 int tr_gelu_fwd(const float* pre, float* out, long n, hipStream_t s);
 int tr_gelu_bwd(const float* pre, const float* dh, float* dpre, long n, hipStream_t s);
 int tr_add(float* y, const float* a, long n, hipStream_t s);

@@ -54,7 +54,8 @@ template <typename OutT> __device__ __forceinline__ void prep_tile(const PrepDes
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = tn * 32 + ty + 8 * r, k = tk * 32 + tx;
-        const float v = (n < d.N && k < d.K) ? d.src[(size_t)n * d.lds + k] : 0.f;
+        float v = (n < d.N && k < d.K) ? d.src[(size_t)n * d.lds + k] : 0.f;
+        if (d.gelu) v = 0.5f * v * (1.0f + erff(v * 0.7071067811865476f));   // the copies hold gelu(src): the f32 activation is never stored
         tile[ty + 8 * r][tx] = v;
         if (n < d.N && k < d.Kp) store_from_f32<OutT>(w + (size_t)n * d.Kp + k, v);
     }
@@ -347,6 +348,97 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, float* __re
     out[c] = accumulate ? out[c] + s * scale : s * scale;
 }
 
+// Round 4: ONE launch per LayerNorm adjoint.  dx (+)= LN'(x) dy as layernorm_bwd_kernel, and the same pass leaves the column
+// sums of dy o xhat (d gamma) and dy (d beta): a wave owns one row at a time and keeps its columns' partial sums in registers over
+// the rows of its block; the four waves of a block are added in wave order into partial row [block][C]; the partial rows of ALL the
+// step's column reductions are added, in row order, by one multi_finish launch at the end of the backward pass (a fixed
+// summation order, no float atomics).  (Before: xhat_kernel + ln_colsums_kernel + colsum_finish_kernel + layernorm_bwd_kernel = 4-5 launches, 2 extra passes.)
+// NC = C / 64 columns per lane (6: the 384-wide encoders, 18: the 1152-wide decoder)
+template <bool ACCUM, int kLnCols>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int M, int C, int rows_per_block, float* __restrict__ part_g,
+                                                           float* __restrict__ part_b) {
+    __shared__ float sm[2][4][64 * kLnCols];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    constexpr int nc = kLnCols;
+    float pg[kLnCols], pb[kLnCols];
+#pragma unroll
+    for (int i = 0; i < kLnCols; ++i) pg[i] = pb[i] = 0.f;
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float* xr = x + (size_t)row * C;
+        const float* gy = dy + (size_t)row * C;
+        float xv[kLnCols], gv[kLnCols];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnCols; ++i)
+            if (i < nc) {
+                xv[i] = xr[lane + 64 * i];
+                gv[i] = gy[lane + 64 * i];
+                s += xv[i];
+            }
+        const float mean = wave_sum(s) / C;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnCols; ++i)
+            if (i < nc) {
+                const float d = xv[i] - mean;
+                v += d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(v) / C + 1e-5f);
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnCols; ++i)
+            if (i < nc) {
+                const float xh = (xv[i] - mean) * rstd;
+                const float g = gamma[lane + 64 * i] * gv[i];
+                a1 += g;
+                a2 += g * xh;
+                pg[i] += gv[i] * xh;
+                pb[i] += gv[i];
+                xv[i] = xh;
+            }
+        a1 = wave_sum(a1) / C;
+        a2 = wave_sum(a2) / C;
+        float* dr = dx + (size_t)row * C;
+#pragma unroll
+        for (int i = 0; i < kLnCols; ++i)
+            if (i < nc) {
+                const float t = (gamma[lane + 64 * i] * gv[i] - a1 - xv[i] * a2) * rstd;
+                dr[lane + 64 * i] = ACCUM ? dr[lane + 64 * i] + t : t;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < kLnCols; ++i)
+        if (i < nc) {
+            sm[0][wave][lane + 64 * i] = pg[i];
+            sm[1][wave][lane + 64 * i] = pb[i];
+        }
+    __syncthreads();
+    float* pgrow = part_g + (size_t)blockIdx.x * C;
+    float* pbrow = part_b ? part_b + (size_t)blockIdx.x * C : nullptr;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        pgrow[c] = (sm[0][0][c] + sm[0][1][c]) + (sm[0][2][c] + sm[0][3][c]);
+        if (pbrow) pbrow[c] = (sm[1][0][c] + sm[1][1][c]) + (sm[1][2][c] + sm[1][3][c]);
+    }
+}
+
+// every pending column reduction of the step in one launch: block -> (entry, 64 columns); out[c] = sum over the entry's partial rows
+__global__ __launch_bounds__(256) void multi_finish_kernel(FinTable t) {
+    __shared__ float sm[4][64];
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.d[e + 1].blk0) ++e;
+    const FinDesc d = t.d[e];
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - d.blk0) * 64 + l;
+    float s0 = 0.f;
+    if (c < d.C)
+        for (int i = rl; i < d.nslab; i += 4) s0 += d.part[(size_t)i * d.C + c];
+    sm[rl][l] = s0;
+    __syncthreads();
+    if (rl == 0 && c < d.C) d.out[c] = (sm[0][l] + sm[1][l]) + (sm[2][l] + sm[3][l]);
+}
+
 // xhat[row] = (x - mean) * rstd (needed once per LayerNorm for d gamma)
 __global__ __launch_bounds__(256) void xhat_kernel(const float* __restrict__ x, float* __restrict__ xh, int M, int C) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -567,9 +659,10 @@ int tr_prep_weights(int out_dtype, const PrepTable& t, hipStream_t s) {
     return DIMX_OK;
 }
 
-int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, void* o, int Kp, void* t, int Mp, hipStream_t s) {
+int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, void* o, int Kp, void* t, int Mp, hipStream_t s, int gelu) {
     DIMX_REQUIRE(src && o && t && rows > 0 && cols > 0 && Kp >= cols && Mp >= rows, DIMX_ERR_ARG, "prep_pair: bad arguments");
     PrepDesc d;
+    d.gelu = gelu;
     d.src = src;
     d.w = o;
     d.wt = t;
@@ -615,6 +708,46 @@ int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v,
 int tr_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, int accumulate, int M, int C, hipStream_t s) {
     if (accumulate) hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(ceil_div(M, 4)), dim3(256), 0, s, x, gamma, dy, dx, M, C);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(ceil_div(M, 4)), dim3(256), 0, s, x, gamma, dy, dx, M, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+// dx (+)= LN'(x) dy; partial rows of colsum(dy o xhat) -> part_g [blocks][C], of colsum(dy) -> part_b (optional).  Returns the
+// number of partial rows in *nrows (the caller queues them for tr_multi_finish).
+int tr_layernorm_bwd_fused(const float* x, const float* gamma, const float* dy, float* dx, int accumulate, int M, int C, float* part_g,
+                           float* part_b, int* nrows, hipStream_t s) {
+    DIMX_REQUIRE((C == 384 || C == 512 || C == 768 || C == 1152) && part_g && nrows, DIMX_ERR_ARG, "layernorm_bwd_fused: C=%d", C);
+    int rows = ceil_div(M, kLnBlocks);
+    rows = (rows + 3) / 4 * 4;
+    const int blocks = ceil_div(M, rows);
+    *nrows = blocks;
+    if (!x) return DIMX_OK;   // sizing pass
+#define LNB(AC, NC) hipLaunchKernelGGL((ln_bwd_fused_kernel<AC, NC>), dim3(blocks), dim3(256), 0, s, x, gamma, dy, dx, M, C, rows, part_g, part_b)
+#define LNB_C(AC)                    \
+    do {                             \
+        if (C == 384) LNB(AC, 6);    \
+        else if (C == 512) LNB(AC, 8); \
+        else if (C == 768) LNB(AC, 12); \
+        else LNB(AC, 18);            \
+    } while (0)
+    if (accumulate) LNB_C(true); else LNB_C(false);
+#undef LNB_C
+#undef LNB
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+// partial rows of colsum(dy) -> part [slabs][C] (bias gradients); *nrows = slabs
+int tr_colsum_partial(const float* dy, int M, int C, float* part, int* nrows, hipStream_t s) {
+    const int slabs = M < kTrSlabs * 8 ? 1 : kTrSlabs;
+    const int rows = ceil_div(M, slabs);
+    *nrows = slabs;
+    if (!dy) return DIMX_OK;  // sizing pass
+    hipLaunchKernelGGL(ln_colsums_kernel, dim3(ceil_div(C, 64), slabs), dim3(256), 0, s, (const float*)nullptr, dy, (float*)nullptr, part, M, C, rows);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_multi_finish(const FinTable& t, hipStream_t s) {
+    if (t.n == 0) return DIMX_OK;
+    hipLaunchKernelGGL(multi_finish_kernel, dim3(t.total_blocks), dim3(256), 0, s, t);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
