@@ -223,7 +223,8 @@ def test_train_epoch_on_the_hip_training_step_matches_the_autograd_restatement()
     l_hip = x_engine_pt.train_epoch(m_hip, loader, tr, dev, log=lambda *_: None)
     with torch.enable_grad():
         opt = T.make_optimizer(m_ref, lr=1e-4)
-        l_ref = x_engine_pt.train_epoch(m_ref, loader, opt, dev, clip=1.0, log=lambda *_: None)
+        l_ref = x_engine_pt.train_epoch(m_ref, loader, opt, dev, clip=1.0, log=lambda *_: None, backward="autograd")
+    assert getattr(m_ref, "_dimx_hip_trainer", None) is None                    # the checker really ran on autograd
     assert np.isfinite(l_hip) and abs(l_hip - l_ref) < 5e-3 * max(1.0, abs(l_ref)), (l_hip, l_ref)   # CE + continuous loss
     sd_h, sd_r = m_hip.state_dict(), m_ref.state_dict()
     moved, worst = 0.0, 0.0
@@ -244,6 +245,49 @@ def test_train_epoch_on_the_hip_training_step_matches_the_autograd_restatement()
     with torch.no_grad():
         _, _, after = m_hip(v_s.to(dev), v_l.to(dev), v_a.to(dev), mask.to(dev), mode="val", greedy=True)
     assert torch.isfinite(after).all()
+
+
+def test_train_epoch_with_a_torch_adamw_runs_on_the_hip_step():
+    """the reference's own call shape -- train_epoch(model, loader, torch.optim.AdamW(model.parameters(),
+    lr), device, clip=1.0) (code/finetune_s2s_pretrain.py:118-132) -- lands on the hand-written HIP training step: a HipTrainer
+    stands in for the AdamW (hyper-parameters from its param_groups at every step, so a torch scheduler drives it; moments and
+    step count exported to optimizer.state), and the result equals the PyTorch-autograd epoch to optimiser rounding."""
+    from dimx import x_engine_pt
+    from dimx.seq2seq_pretrain import SLMFT
+    from dimx.train_hip import HipTrainer
+    dev = torch.device("cuda:0")
+    B, Tn, lens = 4, 32, [32, 32, 20, 11]
+    v_s, v_l, v_a, mask = _clips(B, Tn, lens, seed=33)
+    src = torch.cat([v_s, v_a], -1) * mask[..., None]
+    loader = [(src, v_l * mask[..., None], lens, None, ["a", "b", "c", "d"])] * 3
+    m_hip, m_ref = SLMFT().to(dev), SLMFT().to(dev)
+    m_hip.mask_prob = m_ref.mask_prob = 0.0
+    opt = torch.optim.AdamW(m_hip.parameters(), lr=1e-4)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)          # lr 1e-4, 5e-5, 2.5e-5 over the three batches
+    logs = []
+    l_hip = x_engine_pt.train_epoch(m_hip, loader, opt, dev, scheduler=sched, clip=1.0, log=logs.append)
+    owner, tr = m_hip._dimx_hip_trainer
+    assert owner is opt and isinstance(tr, HipTrainer) and tr.step_count == 3 and abs(tr.lr - 2.5e-5) < 1e-12 and tr.clip == 1.0
+    assert not any("autograd" in ln for ln in logs)
+    named = dict(m_hip.named_parameters())
+    st = opt.state[named["decoder_joint.net.to_logits.weight"]]
+    assert int(st["step"]) == 3 and float(st["exp_avg"].abs().max()) > 0 and float(st["exp_avg_sq"].abs().max()) > 0
+    with torch.enable_grad():
+        opt_r = torch.optim.AdamW(m_ref.parameters(), lr=1e-4)
+        sched_r = torch.optim.lr_scheduler.StepLR(opt_r, step_size=1, gamma=0.5)
+        l_ref = x_engine_pt.train_epoch(m_ref, loader, opt_r, dev, scheduler=sched_r, clip=1.0, log=lambda *_: None, backward="autograd")
+    assert abs(l_hip - l_ref) < 5e-3 * max(1.0, abs(l_ref)), (l_hip, l_ref)
+    sd_h, sd_r = m_hip.state_dict(), m_ref.state_dict()
+    close = torch.cat([(sd_h[n].cpu() - sd_r[n].cpu()).abs().reshape(-1) for n, _, _ in tr.layout])
+    assert (close < 2e-5).float().mean().item() > 0.99
+    # a second epoch continues with the same trainer (moments kept), an SLM / other optimiser falls back with a log line
+    x_engine_pt.train_epoch(m_hip, loader[:1], opt, dev, clip=1.0, log=lambda *_: None)
+    assert m_hip._dimx_hip_trainer[1] is tr and tr.step_count == 4
+    sgd = torch.optim.SGD(m_ref.parameters(), lr=1e-5)
+    logs2 = []
+    with torch.enable_grad():
+        x_engine_pt.train_epoch(m_ref, loader[:1], sgd, dev, clip=1.0, log=logs2.append)
+    assert any("not torch.optim.AdamW" in ln for ln in logs2)
 
 
 def test_reference_sub_apis_with_the_reference_call_shapes(model, full_sd):
