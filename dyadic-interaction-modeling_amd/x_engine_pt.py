@@ -338,6 +338,7 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoc
         src_s_v, src_s_a, tgt, mask, _, _ = _prepare(batch, device)
         if optimizer is not None:
             _adopt_hyperparameters(trainer, optimizer)
+            optimizer._opt_called = True      # the trainer steps in its place (silences torch's scheduler-before-optimizer warning)
         loss, d_step = trainer.train_step(src_s_v, tgt, src_s_a, mask, with_cont_loss=True)   # the reference's total loss
         if scheduler is not None:
             scheduler.step()
