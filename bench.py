@@ -127,7 +127,7 @@ def cpu_baseline(T, timeout_s=300):
                 "sample": "cpu worker exceeded %d s on 8 clips x T=%d" % (timeout_s, T)}
 
 
-def train_step_line(device, T, batches=(16, 4, 64), warm=2, steps=8):
+def train_step_line(device, T, batches=(16, 4, 64), warm=3, steps=8):
     """SURVEY 8 row f3 next to the headline: one optimisation step of SLMFT (forward + backward + clip 1.0 + AdamW, the
     reference's train_epoch body, code/x_engine_pt.py:9-60) on the hand-written HIP training step, bf16 operands with f32
     accumulation and f32 master weights; B clips of T frames (B = 16 is the line's own figure, B = 4 is the reference's ViCo
@@ -151,13 +151,16 @@ def train_step_line(device, T, batches=(16, 4, 64), warm=2, steps=8):
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t0) / steps
         assert torch.isfinite(loss)
-        by_batch[str(B)] = {"ms_per_step": dt * 1e3, "clips_per_s": B / dt}
+        g = tr.graph_stats()
+        by_batch[str(B)] = {"ms_per_step": dt * 1e3, "clips_per_s": B / dt, "graph_nodes": g[2]}
         if out is None:
             out = {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "batch": B, "frames": T, "dtype": "bf16",
                    "steps": steps, "warmup": warm,
                    "note": "SLMFT training step (forward + backward + clip + AdamW) on the HIP kernels of csrc/train*.hip; "
                            "PyTorch autograd on rocBLAS for the same step: tools/bench_train.py"}
     out["by_batch"] = by_batch
+    g = tr.graph_stats()
+    out["hip_graph"] = {"steps_replayed": g[0], "steps_kernel_by_kernel": g[1]}
     del tr, m
     torch.cuda.empty_cache()
     return out

@@ -115,12 +115,48 @@ int build_plan(dimx_handle h, TrainPlan& p) {
     return DIMX_OK;
 }
 
+// Per-handle training state: the parameter plan, the side stream the weight-gradient GEMMs run on, and the captured step.
+constexpr int kSideSlots = 3;
+struct StepGraphKey {
+    const void *params, *grads, *v_speaker, *v_audio, *mask, *z_l, *kv_mask, *loss_out, *logits_out, *ws;
+    size_t ws_bytes;
+    int B, T, at, side;
+    bool operator==(const StepGraphKey& o) const {
+        return params == o.params && grads == o.grads && v_speaker == o.v_speaker && v_audio == o.v_audio && mask == o.mask && z_l == o.z_l &&
+               kv_mask == o.kv_mask && loss_out == o.loss_out && logits_out == o.logits_out && ws == o.ws && ws_bytes == o.ws_bytes &&
+               B == o.B && T == o.T && at == o.at && side == o.side;
+    }
+};
+struct TrainState {
+    TrainPlan plan;
+    hipStream_t side = nullptr, cap = nullptr;
+    hipEvent_t ev_main[kSideSlots] = {}, ev_side[kSideSlots] = {}, ev_join = nullptr;
+    StepGraphKey last_key{}, graph_key{};
+    bool have_last = false;
+    hipGraphExec_t exec = nullptr;
+    long graph_launches = 0, eager_runs = 0, graph_nodes = 0;
+    void drop_graph() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        exec = nullptr;
+    }
+    ~TrainState() {
+        drop_graph();
+        for (int i = 0; i < kSideSlots; ++i) {
+            if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
+            if (ev_side[i]) (void)hipEventDestroy(ev_side[i]);
+        }
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+        if (cap) (void)hipStreamDestroy(cap);
+    }
+};
+
 std::mutex g_plans_mu;
-std::map<dimx_handle, TrainPlan>& plans_map() {
-    static std::map<dimx_handle, TrainPlan> plans;  // handles are few and long-lived; erased by dimx_destroy (train_forget)
+std::map<dimx_handle, TrainState>& plans_map() {
+    static std::map<dimx_handle, TrainState> plans;  // handles are few and long-lived; erased by dimx_destroy (train_forget)
     return plans;
 }
-TrainPlan* plan_of(dimx_handle h, int* rc) {
+TrainState* state_of(dimx_handle h, int* rc) {
     std::lock_guard<std::mutex> lock(g_plans_mu);
     auto& plans = plans_map();
     auto it = plans.find(h);
@@ -128,10 +164,26 @@ TrainPlan* plan_of(dimx_handle h, int* rc) {
         TrainPlan p;
         *rc = build_plan(h, p);
         if (*rc != DIMX_OK) return nullptr;
-        it = plans.emplace(h, std::move(p)).first;
+        it = plans.emplace(std::piecewise_construct, std::forward_as_tuple(h), std::forward_as_tuple()).first;
+        it->second.plan = std::move(p);
     }
     *rc = DIMX_OK;
     return &it->second;
+}
+TrainPlan* plan_of(dimx_handle h, int* rc) {
+    TrainState* ts = state_of(h, rc);
+    return ts ? &ts->plan : nullptr;
+}
+// the side stream and its events (first live step of a handle)
+int side_ready(TrainState& ts) {
+    if (ts.side) return DIMX_OK;
+    DIMX_HIP(hipStreamCreateWithFlags(&ts.side, hipStreamNonBlocking));
+    for (int i = 0; i < kSideSlots; ++i) {
+        DIMX_HIP(hipEventCreateWithFlags(&ts.ev_main[i], hipEventDisableTiming));
+        DIMX_HIP(hipEventCreateWithFlags(&ts.ev_side[i], hipEventDisableTiming));
+    }
+    DIMX_HIP(hipEventCreateWithFlags(&ts.ev_join, hipEventDisableTiming));
+    return DIMX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- step context
@@ -160,6 +212,14 @@ struct Step {
         return q;
     }
     int B, T, M, n, Md;
+    // weight gradients on a side stream: dW = dy^T . x^T^T does not feed the rest of the backward pass, and at 4 800 rows most of
+    // these GEMMs leave CUs idle (81 tiles for a 1152 x 1152 weight), so they run beside the dX chain.  The transposed dy operand
+    // lives in one of kSideSlots rotating buffers (the sublayer scratch is rolled back while the side stream may still read it);
+    // events order slot reuse.  The same calls build the fork / join edges of the captured graph.
+    TrainState* ts = nullptr;
+    bool use_side = false;
+    void* slot_buf[kSideSlots] = {};
+    int slot_n = 0;
 
     size_t peak = 0;  // high-water mark of the arena: the sizing pass (ws == NULL) walks the same allocation sequence
     PrepTable prep;   // weight operand copies queued by prep_lin, made by ONE launch in flush_prep
@@ -274,7 +334,7 @@ int prep_lin(Step& s, Lin& l) {
 
 // C[M,N] f32 = A_op[M,Kp] . W_op[N,Kp]^T (+ bias) (+ residual, which may be C itself)
 int gemm_f32(Step& s, const void* A_op, int Kp, const void* W_op, int M, int N, int K, float* C, int ldc, const float* bias,
-             const float* residual, int ldr) {
+             const float* residual, int ldr, hipStream_t on = nullptr) {
     if (!s.live()) return DIMX_OK;
     GemmArgs g;
     gemm_args_init(g);
@@ -291,11 +351,14 @@ int gemm_f32(Step& s, const void* A_op, int Kp, const void* W_op, int M, int N, 
     g.residual = residual;
     g.ldr = ldr;
     gemm_set_plain_out(g, C, ldc);
-    return launch_gemm(g, s.st);
+    return launch_gemm(g, on ? on : s.st);
 }
 
-// the cached operand pair of a forward input (made on first use; see Step::ops)
-int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpCopy** out, int gelu = 0) {
+// the cached operand pair of a forward input (made on first use; see Step::ops).  mode 1: the operand is erf-GELU(x); mode 2: the
+// operand is LayerNorm(ln_src) * ln_gamma and x is only the NAME of that tensor (an arena buffer that is never written: the f32
+// pre-norm output is not stored, the backward pass finds the copies through the same name)
+int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpCopy** out, int mode = 0, const float* ln_src = nullptr,
+                 const float* ln_gamma = nullptr) {
     const auto key = std::make_tuple(x, ldx, M, K);
     auto it = s.ops.find(key);
     if (it == s.ops.end()) {
@@ -304,7 +367,7 @@ int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpC
         c.Mp = pad_to(M, s.bk);
         c.o = s.take((size_t)M * c.Kp * s.es());
         c.t = s.take((size_t)K * c.Mp * s.es());
-        TR(tr_prep_pair(s.at, x, ldx, M, K, c.o, c.Kp, c.t, c.Mp, s.st, gelu));
+        TR(tr_prep_fused(s.at, mode, mode == 2 ? ln_src : x, ldx, nullptr, 0, ln_gamma, M, K, c.o, c.Kp, c.t, c.Mp, nullptr, nullptr, s.st));
         it = s.ops.emplace(key, c).first;
     }
     if (out) *out = &it->second;
@@ -312,35 +375,52 @@ int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpC
 }
 
 // y = x . W^T (+ b) (+ residual)
-// (gelu: the operand is erf-GELU(x) -- applied inside the operand copy, the activation itself is never stored in f32)
+// (mode 1: the operand is erf-GELU(x) -- applied inside the operand copy, the activation itself is never stored in f32;
+//  mode 2: the operand is the pre-norm LayerNorm(ln_src) * ln_gamma, x names it)
 int lin_fwd(Step& s, const Lin& l, const float* x, int ldx, int M, float* y, int ldy, const float* residual = nullptr, int ldr = 0,
-            int gelu = 0) {
+            int mode = 0, const float* ln_src = nullptr, const float* ln_gamma = nullptr) {
     const Step::OpCopy* c;
-    DIMX_TRY(fwd_operands(s, x, ldx, M, l.K, &c, gelu));
+    DIMX_TRY(fwd_operands(s, x, ldx, M, l.K, &c, mode, ln_src, ln_gamma));
     return gemm_f32(s, c->o, c->Kp, l.w_op, M, l.N, c->Kp, y, ldy, l.b >= 0 ? s.P + l.b : nullptr, residual, ldr);  // K padded with zeros
 }
 
 // dx (+)= dy . W ; dW = dy^T . x ; db = colsum(dy).  x [M,K] (ldx), dy [M,N] (ldy) f32.  dx may be null.
+// gelu_pre: the gradient that enters is dy * GELU'(gelu_pre) (ff1's adjoint: d pre-activation is formed inside the operand copy)
 int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int ldy, int M, float* dx, int lddx, bool accumulate_dx,
-            bool x_from_cache_only = false) {
-    if (l.b >= 0) DIMX_TRY(bias_adjoint(s, dy, s.G + l.b, M, l.N));
+            bool x_from_cache_only = false, const float* gelu_pre = nullptr, int ld_pre = 0) {
+    float* bias_part = nullptr;   // d bias = column sums of the gradient: partial rows from the operand copy's pass over dy
+    if (l.b >= 0) bias_part = s.pool_f32((size_t)ceil_div(M, 32) * l.N);
     const size_t mark = s.ar->off;
     const int Mp = pad_to(M, s.bk), Np = pad_to(l.N, s.bk);
-    void* dyo = s.take((size_t)M * Np * s.es());     // dy and dy^T in the operand type: one pass over dy
-    void* dyT = s.take((size_t)l.N * Mp * s.es());
-    TR(tr_prep_pair(s.at, dy, ldy, M, l.N, dyo, Np, dyT, Mp, s.st));
-    if (dx) DIMX_TRY(gemm_f32(s, dyo, Np, l.wt_op, M, l.K, Np, dx, lddx, nullptr, accumulate_dx ? dx : nullptr, lddx));
-    const void* xT;
     const auto it = s.ops.find(std::make_tuple(x, ldx, M, l.K));
-    if (it != s.ops.end()) {
-        xT = it->second.t;                            // made by the forward pass
-    } else {
-        DIMX_REQUIRE(!x_from_cache_only, DIMX_ERR_STATE, "train: the forward pass left no operand copy of a transformed input");
-        void* t = s.take((size_t)l.K * Mp * s.es());
-        TR(tr_transpose_pad(s.at, x, ldx, t, Mp, M, l.K, s.st));
-        xT = t;
+    const bool side = s.use_side && it != s.ops.end();
+    const int k = s.slot_n % kSideSlots;
+    void* dyo = s.take((size_t)M * Np * s.es());     // dy and dy^T in the operand type: one pass over dy
+    void* dyT = side ? s.slot_buf[k] : s.take((size_t)l.N * Mp * s.es());
+    if (side && s.live() && s.slot_n >= kSideSlots) DIMX_HIP(hipStreamWaitEvent(s.st, s.ts->ev_side[k], 0));  // the slot's last reader
+    int n_part = ceil_div(M, 32);
+    TR(tr_prep_fused(s.at, gelu_pre ? 3 : 0, dy, ldy, gelu_pre, ld_pre, nullptr, M, l.N, dyo, Np, dyT, Mp, bias_part, &n_part, s.st));
+    if (bias_part) DIMX_TRY(queue_fin(s, bias_part, s.G + l.b, l.N, n_part));
+    if (side && s.live()) {
+        DIMX_HIP(hipEventRecord(s.ts->ev_main[k], s.st));
+        DIMX_HIP(hipStreamWaitEvent(s.ts->side, s.ts->ev_main[k], 0));
+        DIMX_TRY(gemm_f32(s, dyT, Mp, it->second.t, l.N, l.K, Mp, s.G + l.w, l.K, nullptr, nullptr, 0, s.ts->side));
+        DIMX_HIP(hipEventRecord(s.ts->ev_side[k], s.ts->side));
     }
-    TR(gemm_f32(s, dyT, Mp, xT, l.N, l.K, Mp, s.G + l.w, l.K, nullptr, nullptr, 0));  // contraction over the zero-padded rows
+    if (side) ++s.slot_n;
+    if (dx) DIMX_TRY(gemm_f32(s, dyo, Np, l.wt_op, M, l.K, Np, dx, lddx, nullptr, accumulate_dx ? dx : nullptr, lddx));
+    if (!side) {
+        const void* xT;
+        if (it != s.ops.end()) {
+            xT = it->second.t;                            // made by the forward pass
+        } else {
+            DIMX_REQUIRE(!x_from_cache_only, DIMX_ERR_STATE, "train: the forward pass left no operand copy of a transformed input");
+            void* t = s.take((size_t)l.K * Mp * s.es());
+            TR(tr_transpose_pad(s.at, x, ldx, t, Mp, M, l.K, s.st));
+            xT = t;
+        }
+        TR(gemm_f32(s, dyT, Mp, xT, l.N, l.K, Mp, s.G + l.w, l.K, nullptr, nullptr, 0));  // contraction over the zero-padded rows
+    }
     s.ar->off = mark;
     return DIMX_OK;
 }
@@ -434,11 +514,11 @@ int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C
     // mode; DIMX_TRAIN_ATTN_VALU=1 keeps the one-wave-per-row f32 VALU kernels (the plain form both are checked against)
     static const bool valu_only = getenv("DIMX_TRAIN_ATTN_VALU") && atoi(getenv("DIMX_TRAIN_ATTN_VALU")) != 0;
     a.shape.mfma = valu_only ? 0 : (s.at == DIMX_BF16 ? 1 : 2);
-    TR(launch_layernorm(DIMX_F32, h_in, a.y, s.p(a.pre + "0.0.weight"), nullptr, M, C, s.st));
+    // the pre-norm is formed inside the operand copy of its projection (a.y only names it)
     if (!cross) {
-        DIMX_TRY(lin_fwd(s, a.qkv, a.y, C, M, a.qb, 3 * inner));
+        DIMX_TRY(lin_fwd(s, a.qkv, a.y, C, M, a.qb, 3 * inner, nullptr, 0, 2, h_in, s.p(a.pre + "0.0.weight")));
     } else {
-        DIMX_TRY(lin_fwd(s, a.q, a.y, C, M, a.qb, inner));
+        DIMX_TRY(lin_fwd(s, a.q, a.y, C, M, a.qb, inner, nullptr, 0, 2, h_in, s.p(a.pre + "0.0.weight")));
         DIMX_TRY(lin_fwd(s, a.kv, a.src, a.Ck, a.Mk, a.kb, 2 * inner));
     }
     TR(tr_attn_fwd(a.shape, a.qb, a.kb, a.vb, a.ob, a.lse, s.st));
@@ -491,8 +571,7 @@ int ff_fwd(Step& s, FFSave& f, const float* h_in, float* h_out, int M, int C) {
     f.F = f.f1.N;
     f.y = s.f32((size_t)M * C);
     f.pre_act = s.f32((size_t)M * f.F);
-    TR(launch_layernorm(DIMX_F32, h_in, f.y, s.p(f.pre + "0.0.weight"), nullptr, M, C, s.st));
-    DIMX_TRY(lin_fwd(s, f.f1, f.y, C, M, f.pre_act, f.F));
+    DIMX_TRY(lin_fwd(s, f.f1, f.y, C, M, f.pre_act, f.F, nullptr, 0, 2, h_in, s.p(f.pre + "0.0.weight")));
     DIMX_TRY(lin_fwd(s, f.f2, f.pre_act, f.F, M, h_out, C, h_in, C, 1));
     return DIMX_OK;
 }
@@ -501,9 +580,8 @@ int ff_bwd(Step& s, FFSave& f, float* dh) {
     const int M = f.M, C = f.C, F = f.F;
     float* da = s.f32((size_t)M * F);
     DIMX_TRY(lin_bwd(s, f.f2, f.pre_act, F, dh, C, M, da, F, false, true));   // x^T = gelu(pre_act)^T from the forward pass
-    TR(tr_gelu_bwd(f.pre_act, da, da, (long)M * F, s.st));  // da becomes d pre-activation in place
     float* dy = s.f32((size_t)M * C);
-    DIMX_TRY(lin_bwd(s, f.f1, f.y, C, da, F, M, dy, C, false));
+    DIMX_TRY(lin_bwd(s, f.f1, f.y, C, da, F, M, dy, C, false, false, f.pre_act, F));   // d pre-activation = da * GELU'(pre_act), in the copy
     DIMX_TRY(ln_adjoint(s, f.h_in, s.p(f.pre + "0.0.weight"), dy, dh, 1, M, C, s.g(f.pre + "0.0.weight"), nullptr));
     s.ar->off = mark;
     return DIMX_OK;
@@ -622,10 +700,11 @@ int dimx_train_param_info(dimx_handle h, int i, const char** name, int64_t* offs
 
 static int train_run(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_audio, const uint8_t* mask,
                      const int32_t* z_l, const uint8_t* kv_mask, int B, int T, float* loss_out, float* logits_out, void* ws,
-                     size_t ws_bytes, hipStream_t st, size_t* need) {
+                     size_t ws_bytes, hipStream_t st, size_t* need, bool use_side) {
     int rc;
-    TrainPlan* plan = plan_of(h, &rc);
-    if (!plan) return rc;
+    TrainState* ts = state_of(h, &rc);
+    if (!ts) return rc;
+    TrainPlan* plan = &ts->plan;
     const dimx_dims& d = h->d;
     DIMX_REQUIRE(h->variant == 0, DIMX_ERR_ARG, "train: only the SLMFT variant is trained");
     DIMX_REQUIRE(B >= 1 && T >= 2 && T <= d.max_seq_len, DIMX_ERR_ARG, "train: B=%d T=%d out of range", B, T);
@@ -648,10 +727,17 @@ static int train_run(dimx_handle h, const float* params, float* grads, const flo
     s.prep.total_tiles = 0;
     const int DD = d.dim + d.dim_a, F = DD * d.ff_mult, inner = d.heads * d.dim_head;
     s.part = s.f32((size_t)2 * kTrSlabs * F);
+    s.ts = ts;
+    s.use_side = use_side;
+    if (use_side) {   // the widest dy^T of the step: ff1's [F][rows]
+        const size_t slot = (size_t)std::max(F, 3 * inner) * pad_to(s.M, s.bk) * s.es();
+        for (int i = 0; i < kSideSlots; ++i) s.slot_buf[i] = s.take(slot);
+        if (ws != nullptr) DIMX_TRY(side_ready(*ts));
+    }
     {   // partial rows of the deferred column reductions: LayerNorm adjoints (<= kLnBlocks + 3 rows of <= DD each, two for norm_s) and
         // bias / patch-embedding gradients (<= kTrSlabs rows of <= F)
         const size_t n_ln = (size_t)(4 * d.enc_depth + 3 * d.dec_depth + 12), n_b = (size_t)(4 * d.enc_depth + 2 * d.dec_depth + 4);
-        s.pool_cap = n_ln * (kLnBlocks + 4) * (size_t)DD + n_b * kTrSlabs * (size_t)F + 4096;
+        s.pool_cap = n_ln * (kLnBlocks + 4) * (size_t)DD + n_b * (size_t)std::max(kTrSlabs, ceil_div(s.M, 32) + 1) * (size_t)F + 4096;
         s.pool = s.f32(s.pool_cap);
         s.pool_off = 0;
         s.fin.n = 0;
@@ -750,11 +836,34 @@ static int train_run(dimx_handle h, const float* params, float* grads, const flo
     DIMX_TRY(enc_bwd(s, es, d_es, d_x0));
     DIMX_TRY(bias_adjoint(s, d_x0, s.g("patch_embed_s"), s.M, d.dim_in));
     DIMX_TRY(flush_fin(s));   // every queued column reduction: one launch
+    if (use_side && live && s.slot_n > 0) {   // join: the side stream is in order, its last event covers every weight gradient
+        DIMX_HIP(hipEventRecord(ts->ev_join, ts->side));
+        DIMX_HIP(hipStreamWaitEvent(st, ts->ev_join, 0));
+    }
     (void)inner;
     if (need) *need = s.peak + 256;
     DIMX_REQUIRE(!s.pool_overflow, DIMX_ERR_STATE, "train: the partial-row pool of the column reductions is too small");
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "train: workspace %zu < required %zu", ws_bytes, s.peak);
     return DIMX_OK;
+}
+
+// How a step is launched (measured on MI355X, profiles/r04_train_step.txt): the step is GPU-bound at every batch size (B = 2: 5.2 ms
+// for ~450 dependent kernels), so replaying it from a hipGraph costs the same GPU time as launching it kernel by kernel and only
+// frees the host thread; the weight-gradient side stream buys 3-5 % from 4 096 rows up and costs as much below (its event
+// edges), and as parallel BRANCHES of a captured graph it is slower than either (12.5 vs 11.8 / 12.1 ms at B = 16).  Hence:
+//   rows >= 4096: kernel by kernel, weight gradients on the side stream;   rows < 4096: captured graph, one stream.
+// DIMX_TRAIN_GRAPH=0|1 and DIMX_TRAIN_SIDE=0|1 force either choice (read per call: tests flip them).
+static int env_flag(const char* name) {
+    const char* v = getenv(name);
+    return (v && v[0]) ? (atoi(v) != 0 ? 1 : 0) : -1;
+}
+static bool train_use_graph(int rows) {
+    const int f = env_flag("DIMX_TRAIN_GRAPH");
+    return f >= 0 ? f == 1 : rows < 4096;
+}
+static bool train_use_side(int rows) {
+    const int f = env_flag("DIMX_TRAIN_SIDE");
+    return f >= 0 ? f == 1 : !train_use_graph(rows);
 }
 
 size_t dimx_train_workspace_bytes(dimx_handle h, int B, int T) {
@@ -763,12 +872,17 @@ size_t dimx_train_workspace_bytes(dimx_handle h, int B, int T) {
     // the sizing pass walks the allocation sequence of a live call without launching anything: optional inputs are given as
     // non-null sentinels (never dereferenced) so that it takes the branches that allocate the most
     const uint8_t* some_mask = (const uint8_t*)0x100;
-    if (train_run(h, nullptr, nullptr, nullptr, nullptr, some_mask, nullptr, some_mask, B, T, nullptr, nullptr, nullptr, 0, nullptr, &need) !=
-        DIMX_OK)
+    if (train_run(h, nullptr, nullptr, nullptr, nullptr, some_mask, nullptr, some_mask, B, T, nullptr, nullptr, nullptr, 0, nullptr, &need,
+                  true) != DIMX_OK)   // sized with the side stream's slots: the choice may differ between calls
         return 0;
     return need;
 }
 
+// The step as a hipGraph.  Shapes are static per (B, T) and the step reads nothing from the host, so a call whose arguments
+// (every pointer, B, T) equal the previous call's is captured once -- the caller's stream forks into the side stream inside the
+// capture, so the graph keeps the dX chain and the weight-gradient GEMMs as parallel branches -- and replayed from then on: one
+// hipGraphLaunch instead of ~540 kernel launches.  A caller that hands over new buffers every step (or DIMX_TRAIN_NO_GRAPH=1)
+// stays on the kernel-by-kernel path; dimx.train_hip.HipTrainer stages its batch in persistent buffers for this reason.
 int dimx_train_forward_backward(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_audio,
                                 const uint8_t* mask, const int32_t* z_l, const uint8_t* kv_mask, int B, int T, float* loss_out,
                                 float* logits_out, void* ws, size_t ws_bytes, void* stream) {
@@ -776,6 +890,7 @@ int dimx_train_forward_backward(dimx_handle h, const float* params, float* grads
     DIMX_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0, DIMX_ERR_ARG,
                  "train: workspace must be 256-byte aligned, arenas 16-byte aligned");
     DIMX_HIP(hipSetDevice(h->device));
+    const bool side = train_use_side(B * T);
     // the arena is planned while kernels are being launched: check the caller's workspace against the sizing pass FIRST (a pure
     // host walk of the same allocation sequence) -- an undersized workspace used to be reported only after kernels had written
     // past its end
@@ -783,11 +898,64 @@ int dimx_train_forward_backward(dimx_handle h, const float* params, float* grads
         size_t need = 0;
         const uint8_t* some_mask = (const uint8_t*)0x100;
         DIMX_TRY(train_run(h, nullptr, nullptr, nullptr, nullptr, some_mask, nullptr, kv_mask ? some_mask : nullptr, B, T, nullptr,
-                           logits_out ? (float*)0x100 : nullptr, nullptr, 0, nullptr, &need));
+                           logits_out ? (float*)0x100 : nullptr, nullptr, 0, nullptr, &need, side));
         DIMX_REQUIRE(ws_bytes >= need, DIMX_ERR_WORKSPACE, "train: workspace %zu < required %zu (dimx_train_workspace_bytes)", ws_bytes, need);
     }
-    return train_run(h, params, grads, v_speaker, v_audio, mask, z_l, kv_mask, B, T, loss_out, logits_out, ws, ws_bytes, (hipStream_t)stream,
-                     nullptr);
+    int rc;
+    TrainState* ts = state_of(h, &rc);
+    if (!ts) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const StepGraphKey key{params, grads, v_speaker, v_audio, mask, z_l, kv_mask, loss_out, logits_out, ws, ws_bytes, B, T, h->at, side ? 1 : 0};
+    if (train_use_graph(B * T)) {
+        if (ts->exec && ts->graph_key == key) {
+            ++ts->graph_launches;
+            DIMX_HIP(hipGraphLaunch(ts->exec, st));
+            return DIMX_OK;
+        }
+        if (ts->have_last && ts->last_key == key) {   // second call in a row with these arguments: capture (the first one warmed every kernel up)
+            ts->drop_graph();
+            if (!ts->cap) DIMX_HIP(hipStreamCreateWithFlags(&ts->cap, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            DIMX_HIP(hipStreamBeginCapture(ts->cap, hipStreamCaptureModeThreadLocal));
+            const int rc2 = train_run(h, params, grads, v_speaker, v_audio, mask, z_l, kv_mask, B, T, loss_out, logits_out, ws, ws_bytes, ts->cap,
+                                      nullptr, side);
+            const hipError_t ce = hipStreamEndCapture(ts->cap, &graph);
+            if (rc2 != DIMX_OK || ce != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+                ts->have_last = false;   // do not try again with these arguments
+                if (rc2 != DIMX_OK) return rc2;
+                fprintf(stderr, "dimx: the training step could not be captured (%s); it stays on the kernel-by-kernel path\n", hipGetErrorString(ce));
+            } else {
+                size_t nodes = 0;
+                (void)hipGraphGetNodes(graph, nullptr, &nodes);
+                ts->graph_nodes = (long)nodes;
+                const hipError_t ie = hipGraphInstantiate(&ts->exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                DIMX_HIP(ie);
+                ts->graph_key = key;
+                ++ts->graph_launches;
+                DIMX_HIP(hipGraphLaunch(ts->exec, st));
+                return DIMX_OK;
+            }
+        }
+    }
+    ts->last_key = key;
+    ts->have_last = true;
+    ++ts->eager_runs;
+    return train_run(h, params, grads, v_speaker, v_audio, mask, z_l, kv_mask, B, T, loss_out, logits_out, ws, ws_bytes, st, nullptr, side);
+}
+
+// {graph launches, kernel-by-kernel runs, nodes of the captured step} of this handle's training steps
+int dimx_train_graph_stats(dimx_handle h, int64_t* out3) {
+    DIMX_REQUIRE(h && out3, DIMX_ERR_ARG, "train_graph_stats: null argument");
+    int rc;
+    TrainState* ts = state_of(h, &rc);
+    if (!ts) return rc;
+    out3[0] = ts->graph_launches;
+    out3[1] = ts->eager_runs;
+    out3[2] = ts->graph_nodes;
+    return DIMX_OK;
 }
 
 int dimx_train_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,

@@ -38,6 +38,17 @@ struct PrepTable {
 int tr_prep_weights(int out_dtype, const PrepTable& t, hipStream_t s);
 // the same pair of copies for ONE matrix (an activation [rows][cols] with row stride lds): o [rows][Kp], t [cols][Mp]
 int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, void* o, int Kp, void* t, int Mp, hipStream_t s, int gelu = 0);
+struct PrepFused {
+    const float* src;
+    const float* src2;
+    const float* gamma;
+    void* o;
+    void* t;
+    float* colpart;
+    int lds, lds2, Kp, Mp, rows, cols, mode, chunk;
+};
+int tr_prep_fused(int out_dtype, int mode, const float* src, int lds, const float* src2, int lds2, const float* gamma, int rows, int cols,
+                  void* o, int Kp, void* t, int Mp, float* colpart, int* n_part, hipStream_t s);
 int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s);
 int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
 int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,

@@ -80,6 +80,129 @@ __global__ __launch_bounds__(256) void prep_pair_kernel(PrepDesc d) {
     prep_tile<OutT>(d, blockIdx.x, tile);
 }
 
+// Round 4: the operand copies of an ACTIVATION, with the producer's elementwise work inside.  One pass over the f32 source yields the
+// cast [rows][Kp], the transposed cast [cols][Mp] and (optionally) the column sums of what was cast -- what used to be up to four
+// launches (LayerNorm | GELU' | bias column sums, then prep_pair) with an f32 round trip between them:
+//   mode 0  v = src                              (gradients arriving from an attention / LayerNorm adjoint)
+//   mode 1  v = erf-GELU(src)                    (the feed-forward activation as ff2's operand)
+//   mode 2  v = LayerNorm(src) * gamma           (the pre-norm of a sublayer as its projection's operand; the f32 y is never stored)
+//   mode 3  v = src * GELU'(src2)                (d pre-activation as ff1's adjoint operand; colpart gives d bias of ff1)
+// Block = 32 rows x `chunk` columns, 64 columns at a time: float4 loads, 8 / 16-byte stores on both copies (prep_tile moved 4 and 2
+// bytes per thread).  Rows in [rows, Mp) of the transposed copy are written as zeros (the dW contraction runs over them).
+template <typename OutT> struct Out4;
+template <> struct Out4<bf16> {
+    static __device__ __forceinline__ void store(bf16* p, float a, float b, float c, float d) {
+        *(uint2*)p = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+    }
+};
+template <> struct Out4<float> {
+    static __device__ __forceinline__ void store(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
+};
+template <typename OutT>
+__global__ __launch_bounds__(256) void prep_fused_kernel(PrepFused d) {
+    __shared__ float tile[32][65];
+    __shared__ float mean_s[32], rstd_s[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 32;
+    const int c_begin = blockIdx.y * d.chunk, c_end = min(d.Kp, c_begin + d.chunk);
+    if (d.mode == 2) {   // row statistics of this block's rows: two passes over the row (the form layernorm_kernel uses)
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = wave * 8 + rr, row = r0 + r;
+            if (row >= d.rows) break;
+            const float4* x4 = (const float4*)(d.src + (size_t)row * d.lds);
+            const int n4 = d.cols >> 2;
+            float sm = 0.f;
+            for (int i = lane; i < n4; i += 64) {
+                const float4 v = x4[i];
+                sm += (v.x + v.y) + (v.z + v.w);
+            }
+            const float mean = wave_sum(sm) / (float)d.cols;
+            float q = 0.f;
+            for (int i = lane; i < n4; i += 64) {
+                const float4 v = x4[i];
+                const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+                q += (a * a + b * b) + (c * c + e * e);
+            }
+            const float rstd = rsqrtf(wave_sum(q) / (float)d.cols + 1e-5f);
+            if (lane == 0) {
+                mean_s[r] = mean;
+                rstd_s[r] = rstd;
+            }
+        }
+        __syncthreads();
+    }
+    OutT* o = (OutT*)d.o;
+    OutT* t = (OutT*)d.t;
+    const int ty = tid >> 4, tx = tid & 15;
+    // the next 64 columns are requested before the current ones are worked on (a block walks its columns in order: without the
+    // prefetch every step paid a full memory round trip -- 18 of them for a 1152-wide LayerNorm row)
+    float4 xa[2], za[2], xb[2], zb[2];
+    auto fetch = [&](int c0, float4 (&x)[2], float4 (&z)[2]) {
+        const int col = c0 + 4 * tx;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = r0 + ty + 16 * h;
+            x[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[h] = x[h];
+            if (c0 < c_end && row < d.rows && col < d.cols) {   // cols % 4 == 0 (checked by the launcher): whole groups only
+                x[h] = *(const float4*)(d.src + (size_t)row * d.lds + col);
+                if (d.mode == 3) z[h] = *(const float4*)(d.src2 + (size_t)row * d.lds2 + col);
+            }
+        }
+    };
+    fetch(c_begin, xa, za);
+    for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+        const int col = c0 + 4 * tx;
+        fetch(c0 + 64, xb, zb);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = ty + 16 * h, row = r0 + r;
+            float v[4] = {xa[h].x, xa[h].y, xa[h].z, xa[h].w};
+            if (row < d.rows && col < d.cols) {
+                if (d.mode == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.7071067811865476f));
+                } else if (d.mode == 2) {
+                    const float4 g = *(const float4*)(d.gamma + col);
+                    const float m = mean_s[r], rs = rstd_s[r];
+                    v[0] = (v[0] - m) * rs * g.x; v[1] = (v[1] - m) * rs * g.y; v[2] = (v[2] - m) * rs * g.z; v[3] = (v[3] - m) * rs * g.w;
+                } else if (d.mode == 3) {
+                    const float z[4] = {za[h].x, za[h].y, za[h].z, za[h].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {   // d/dz [0.5 z (1 + erf(z / sqrt 2))] = 0.5 (1 + erf(z / sqrt 2)) + z exp(-z^2 / 2) / sqrt(2 pi)
+                        const float cdf = 0.5f * (1.0f + erff(z[e] * 0.7071067811865476f));
+                        v[e] *= cdf + z[e] * 0.3989422804014327f * expf(-0.5f * z[e] * z[e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][4 * tx + e] = v[e];
+            if (row < d.rows && col < d.Kp) Out4<OutT>::store(o + (size_t)row * d.Kp + col, v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        if (d.colpart && tid < 64 && c0 + tid < d.cols && r0 < d.rows) {   // fixed order: rows 0..31 of the block
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) a += tile[r][tid];
+            d.colpart[(size_t)blockIdx.x * d.cols + c0 + tid] = a;
+        }
+        {
+            const int c = tid >> 2, part = tid & 3, colT = c0 + c;
+            if (colT < d.cols) {
+                OutT* dst = t + (size_t)colT * d.Mp + r0 + 8 * part;   // r0 + 32 <= Mp (grid.x = Mp / 32)
+                Out4<OutT>::store(dst, tile[8 * part][c], tile[8 * part + 1][c], tile[8 * part + 2][c], tile[8 * part + 3][c]);
+                Out4<OutT>::store(dst + 4, tile[8 * part + 4][c], tile[8 * part + 5][c], tile[8 * part + 6][c], tile[8 * part + 7][c]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xa[h] = xb[h];
+            za[h] = zb[h];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ attention
 // One wave per (clip, head, query row).  Keys are dealt to the lanes (j = lane, lane + 64, ...); q, the output row and
 // the gradient rows live in registers, K / V rows stream from L2 (a head's K and V are 2 x Lk x 256 B).
@@ -588,11 +711,29 @@ __global__ __launch_bounds__(256) void onehot_t_kernel(const int32_t* __restrict
 // partial sums of squares over the flat gradient arena (fixed block partition -> deterministic), then the norm
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ part) {
     __shared__ double sm[256];
-    const long per = (n + gridDim.x - 1) / gridDim.x;
-    const long lo = (long)blockIdx.x * per, hi = min(n, lo + per);
-    double s = 0.0;  // 1e8 squares: f64 partial sums keep the norm (and with it the clip factor) exact to f32 rounding
-    for (long i = lo + threadIdx.x; i < hi; i += 256) s += (double)g[i] * (double)g[i];
-    sm[threadIdx.x] = s;
+    // 16-byte loads, four of them in flight per thread (the scalar-load form ran at 1.2 TB/s: 312 us for 93 M gradients);
+    // 1e8 squares: f64 partial sums keep the norm (and with it the clip factor) exact to f32 rounding
+    const long n4 = n >> 2;
+    const float4* __restrict__ g4 = (const float4*)g;
+    const long stride = (long)gridDim.x * 256;
+    double s0 = 0.0, s1 = 0.0;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
+        s0 += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+        s1 += (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z + (double)b.w * b.w;
+        s0 += (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z + (double)c.w * c.w;
+        s1 += (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w;
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = g4[i];
+        s0 += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float t = g[(n4 << 2) + threadIdx.x];
+        s1 += (double)t * t;
+    }
+    sm[threadIdx.x] = s0 + s1;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
         if (threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
@@ -618,17 +759,40 @@ __global__ __launch_bounds__(256) void norm_finish_kernel(const double* __restri
     }
 }
 // torch.optim.AdamW: p *= 1 - lr wd; m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ clip) {
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    const float* __restrict__ clip) {
     const float cf = clip ? clip[1] : 1.0f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * cf;
-        float pi = p[i] * (1.0f - lr * wd);
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    const float decay = 1.0f - lr * wd, step = lr / bc1;
+    auto one = [&](float gi, float& pi, float& mi, float& vi) {
+        gi *= cf;
+        pi *= decay;
+        mi = b1 * mi + (1.0f - b1) * gi;
+        vi = b2 * vi + (1.0f - b2) * gi * gi;
+        pi -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    };
+    const long n4 = n >> 2;   // the arenas are 16-byte aligned (dimx_train_forward_backward checks it)
+    float4* __restrict__ p4 = (float4*)p;
+    float4* __restrict__ m4 = (float4*)m;
+    float4* __restrict__ v4 = (float4*)v;
+    const float4* __restrict__ g4 = (const float4*)g;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 gi = g4[i];
+        float4 pi = p4[i], mi = m4[i], vi = v4[i];
+        one(gi.x, pi.x, mi.x, vi.x);
+        one(gi.y, pi.y, mi.y, vi.y);
+        one(gi.z, pi.z, mi.z, vi.z);
+        one(gi.w, pi.w, mi.w, vi.w);
+        m4[i] = mi;
+        v4[i] = vi;
+        p4[i] = pi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        float pi = p[i], mi = m[i], vi = v[i];
+        one(g[i], pi, mi, vi);
         m[i] = mi;
         v[i] = vi;
-        pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
         p[i] = pi;
     }
 }
@@ -676,6 +840,37 @@ int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, v
     const int tiles = ceil_div(Mp, 32) * d.tiles_k;
     if (out_dtype == DIMX_BF16) hipLaunchKernelGGL(prep_pair_kernel<bf16>, dim3(tiles), dim3(256), 0, s, d);
     else hipLaunchKernelGGL(prep_pair_kernel<float>, dim3(tiles), dim3(256), 0, s, d);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+// see prep_fused_kernel.  colpart: [*n_part][cols] partial column sums (n_part = ceil(rows / 32) rows are written), or null
+int tr_prep_fused(int out_dtype, int mode, const float* src, int lds, const float* src2, int lds2, const float* gamma, int rows, int cols,
+                  void* o, int Kp, void* t, int Mp, float* colpart, int* n_part, hipStream_t s) {
+    DIMX_REQUIRE(src && o && t && rows > 0 && cols > 0 && Kp >= cols && Mp >= rows && mode >= 0 && mode <= 3, DIMX_ERR_ARG, "prep_fused: bad arguments");
+    DIMX_REQUIRE(cols % 4 == 0 && lds % 4 == 0 && Kp % 4 == 0 && Mp % 32 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)o % 16) == 0 &&
+                     ((uintptr_t)t % 16) == 0,
+                 DIMX_ERR_ARG, "prep_fused: 16-byte groups (cols=%d lds=%d Kp=%d Mp=%d)", cols, lds, Kp, Mp);
+    DIMX_REQUIRE(mode != 2 || (gamma && ((uintptr_t)gamma % 16) == 0), DIMX_ERR_ARG, "prep_fused: LayerNorm mode needs gamma");
+    DIMX_REQUIRE(mode != 3 || (src2 && lds2 % 4 == 0 && ((uintptr_t)src2 % 16) == 0), DIMX_ERR_ARG, "prep_fused: GELU' mode needs the pre-activation");
+    PrepFused d;
+    d.src = src; d.lds = lds; d.src2 = src2; d.lds2 = lds2; d.gamma = gamma;
+    d.o = o; d.Kp = Kp; d.t = t; d.Mp = Mp; d.rows = rows; d.cols = cols; d.mode = mode; d.colpart = colpart;
+    // LayerNorm: the block that owns 32 rows computes their statistics once, so it walks the whole row; otherwise 256-column chunks
+    // columns per block: enough blocks to fill the chip (>= ~512) when there are few rows, at most 256 columns (LayerNorm mode: the
+    // row statistics are recomputed by every column chunk of a row block, so its chunks stay >= 128 wide)
+    {
+        static const int force = getenv("DIMX_PREP_CHUNK") ? atoi(getenv("DIMX_PREP_CHUNK")) : 0;
+        int c = (int)((long)Kp * (Mp / 32) / 512) / 64 * 64;
+        c = c < 64 ? 64 : (c > 256 ? 256 : c);
+        if (mode == 2 && c < 128) c = 128;
+        if (mode == 2 && force > 0) c = force;
+        d.chunk = c;
+    }
+    if (n_part) *n_part = ceil_div(rows, 32);
+    const dim3 grid(Mp / 32, ceil_div(Kp, d.chunk));
+    if (out_dtype == DIMX_BF16) hipLaunchKernelGGL(prep_fused_kernel<bf16>, grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(prep_fused_kernel<float>, grid, dim3(256), 0, s, d);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
@@ -821,8 +1016,8 @@ int tr_onehot_t(int out_dtype, const int32_t* tokens, void* out, int ld_out, int
 }
 // norm_out[0] = ||g||_2, norm_out[1] = clip coefficient; part: >= 1024 floats of 8-byte aligned scratch (512 f64 partial sums)
 int tr_grad_norm(const float* g, long n, float max_norm, float* part, float* norm_out, hipStream_t s) {
-    const int nb = 512;
-    DIMX_REQUIRE(((uintptr_t)part % 8) == 0, DIMX_ERR_ARG, "grad_norm: scratch must be 8-byte aligned");
+    const int nb = 512;   // 2 blocks per CU
+    DIMX_REQUIRE(((uintptr_t)part % 8) == 0 && ((uintptr_t)g % 16) == 0, DIMX_ERR_ARG, "grad_norm: scratch must be 8-byte aligned");
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, (double*)part);
     hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nb, max_norm, norm_out);
     DIMX_HIP(hipGetLastError());
@@ -831,7 +1026,7 @@ int tr_grad_norm(const float* g, long n, float max_norm, float* part, float* nor
 int tr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
              const float* clip, hipStream_t s) {
     const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), clip);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), clip);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

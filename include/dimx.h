@@ -227,6 +227,12 @@ size_t dimx_train_workspace_bytes(dimx_handle h, int B, int T);
 int dimx_train_forward_backward(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_audio,
                                 const uint8_t* mask, const int32_t* z_l, const uint8_t* kv_mask, int B, int T, float* loss_out,
                                 float* logits_out, void* ws, size_t ws_bytes, void* stream);
+/* How this handle's training steps were launched: out3 = {steps replayed from the captured hipGraph, steps launched kernel by
+ * kernel, nodes of the captured graph}.  Below 4 096 rows (B x T) a call whose arguments (every pointer, B, T) equal the
+ * previous call's is captured once and replayed afterwards; from 4 096 rows up the step is launched kernel by kernel with its
+ * weight-gradient GEMMs on a side stream (the faster choice there: csrc/train.hip).  DIMX_TRAIN_GRAPH=0|1 / DIMX_TRAIN_SIDE=0|1
+ * force either; results are bit-identical in every combination. */
+int dimx_train_graph_stats(dimx_handle h, int64_t* out3);
 /* Gradient clipping (torch.nn.utils.clip_grad_norm_, max_norm <= 0: none) + one torch.optim.AdamW step over a flat arena.
  * step: 1-based step count (bias correction).  scratch: >= 1026 device floats; scratch[1024] = gradient norm before clipping,
  * scratch[1025] = the clip coefficient applied. */

@@ -135,6 +135,67 @@ def test_hip_training_reduces_the_loss_and_bf16_mode_agrees():
     assert abs(lb - lf) < 2e-2 and rel < 0.05
 
 
+@pytest.mark.parametrize("mode_name", ["f32", "bf16"])
+def test_captured_training_step_replays_the_kernel_by_kernel_step_bit_for_bit(mode_name):
+    """round 4: a step whose arguments equal the previous step's is captured as a hipGraph (dX chain and weight-gradient GEMMs as
+    parallel branches) and replayed.  The backward pass has no float atomics, so the replayed gradients must EQUAL those of the
+    kernel-by-kernel launch -- also after the batch in the staging buffers changed, and through a full optimisation step."""
+    from dimx import lib
+    mode = lib.MODE_PARITY_F32 if mode_name == "f32" else lib.MODE_PERF_BF16
+    v_s, v_l, v_a, z, mask = _inputs(B=3, T=44, seed=23)
+    v_s2, v_l2, v_a2, z2, _ = _inputs(B=3, T=44, seed=29)
+    kv = torch.ones(3, 43, dtype=torch.bool)
+    kv[0, 5:9] = False
+    a1 = dict(kv_mask=kv.cuda(), z_l=z.cuda())
+    a2 = dict(kv_mask=kv.cuda(), z_l=torch.where(mask, z2, torch.full_like(z2, -100)).cuda())
+    model, tr = _trainer(mode)
+    l_e1 = tr.forward_backward(v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda(), **a1).item()     # kernel by kernel
+    g_e1 = tr.grads.clone()
+    assert tr.graph_stats()[:2] == (0, 1)
+    l_c1 = tr.forward_backward(v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda(), **a1).item()     # captured + launched
+    replayed, eager, nodes = tr.graph_stats()
+    assert (replayed, eager) == (1, 1) and nodes > 100, (replayed, eager, nodes)
+    assert l_c1 == l_e1 and torch.equal(tr.grads, g_e1)
+    l_r2 = tr.forward_backward(v_s2.cuda(), v_l2.cuda(), v_a2.cuda(), mask.cuda(), **a2).item()  # replay on another batch
+    g_r2 = tr.grads.clone()
+    assert tr.graph_stats()[:2] == (2, 1)
+    assert l_r2 != l_e1
+    model_b, tr_b = _trainer(mode)                                                                # same batch, never captured
+    l_e2 = tr_b.forward_backward(v_s2.cuda(), v_l2.cuda(), v_a2.cuda(), mask.cuda(), **a2).item()
+    assert l_r2 == l_e2 and torch.equal(g_r2, tr_b.grads)
+    # a different (B, T) leaves the captured step alone and runs kernel by kernel
+    v_s3, v_l3, v_a3, z3, mask3 = _inputs(B=2, T=48, seed=31)
+    tr.forward_backward(v_s3.cuda(), v_l3.cuda(), v_a3.cuda(), mask3.cuda(), kv_mask=False, z_l=z3.cuda())
+    assert tr.graph_stats()[:2] == (2, 2)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_weight_gradients_on_the_side_stream_change_no_bit(graph, monkeypatch):
+    """from 4 096 rows up the weight-gradient GEMMs run on a side stream (rotating dy^T slots ordered by events); as branches of
+    the captured graph when both are forced on.  Same bits as the one-stream step, step after step (slot reuse: > 3 Linears)."""
+    from dimx import lib
+    v_s, v_l, v_a, z, mask = _inputs(B=2, T=48, seed=37)
+    args = (v_s.cuda(), v_l.cuda(), v_a.cuda(), mask.cuda())
+    monkeypatch.setenv("DIMX_TRAIN_GRAPH", "0")
+    monkeypatch.setenv("DIMX_TRAIN_SIDE", "0")
+    _, tr0 = _trainer(lib.MODE_PERF_BF16)
+    l0 = tr0.forward_backward(*args, kv_mask=False, z_l=z.cuda()).item()
+    monkeypatch.setenv("DIMX_TRAIN_GRAPH", str(graph))
+    monkeypatch.setenv("DIMX_TRAIN_SIDE", "1")
+    _, tr1 = _trainer(lib.MODE_PERF_BF16)
+    for it in range(3):
+        l1 = tr1.forward_backward(*args, kv_mask=False, z_l=z.cuda()).item()
+        assert l1 == l0 and torch.equal(tr1.grads, tr0.grads), it
+    assert tr1.graph_stats()[:2] == ((2, 1) if graph else (0, 3))
+    # the default at this size (96 rows) is the captured one-stream step; at 4 800 rows it is the side stream without a graph
+    monkeypatch.delenv("DIMX_TRAIN_GRAPH")
+    monkeypatch.delenv("DIMX_TRAIN_SIDE")
+    _, tr2 = _trainer(lib.MODE_PERF_BF16)
+    for _ in range(3):
+        tr2.forward_backward(*args, kv_mask=False, z_l=z.cuda())
+    assert tr2.graph_stats()[:2] == (2, 1) and torch.equal(tr2.grads, tr0.grads)
+
+
 def _attend_reference(q, k, v, d_o, scale, causal, kmask, kmask2, H):
     """x-transformers' Attend in float64 with autograd: masked_fill(-max of float32) before the softmax."""
     B, Lq, _ = q.shape

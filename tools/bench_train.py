@@ -27,7 +27,8 @@ mask = torch.ones(B, Tn, dtype=torch.bool, device=dev)
 
 
 def timed(fn):
-    fn()
+    for _ in range(3):   # kernel by kernel, capture of the step graph, first replay
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -44,7 +45,8 @@ for mode, name in ((L.MODE_PERF_BF16, "bf16"), (L.MODE_PARITY_F32, "f32")):
         _, z = m.forward_vq(v_s, v_l, mask, with_speaker=False)
     tr = HipTrainer(m, lr=1e-5, clip=1.0)
     ms = timed(lambda: tr.train_step(v_s, v_l, v_a, mask, kv_mask=False, z_l=z))
-    print("HIP training step  %-4s B=%d T=%d: %8.1f ms  (%.1f clips/s)" % (name, B, Tn, ms, B / ms * 1e3), flush=True)
+    print("HIP training step  %-4s B=%d T=%d: %8.1f ms  (%.1f clips/s)   [graph replays %d, kernel-by-kernel steps %d, graph nodes %d]"
+          % ((name, B, Tn, ms, B / ms * 1e3) + tr.graph_stats()), flush=True)
     del tr, m
     torch.cuda.empty_cache()
 if which != "all":
