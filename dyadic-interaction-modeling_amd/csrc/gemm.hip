@@ -1383,6 +1383,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.w_tiled)
         DIMX_REQUIRE(a.N % 8 == 0 && a.conv_T == 0 && !a.force_simple && a.K % bk == 0 && a.M < 4096 && a.kloop == 0, DIMX_ERR_ARG,
                      "gemm: block-tiled W needs N %% 8 == 0, K %% %d == 0 and a decode-sized M (N=%d K=%d M=%d)", bk, a.N, a.K, a.M);
+    {   // DIMX_GEMM_LOG=1: one line per launch (tools/gemm_in_situ.py pairs them with a kernel trace)
+        static const bool log = getenv("DIMX_GEMM_LOG") != nullptr;
+        if (log)
+            fprintf(stderr, "dimx-gemm M=%d N=%d K=%d in=%d out=%d bias=%d res=%d act=%d rowadd=%d nseg=%d slabs=%d big=%d\n", a.M, a.N, a.K,
+                    a.in_dtype, a.out_dtype, a.bias ? 1 : 0, a.residual ? 1 : 0, a.act, a.rowadd_mode, a.nseg, a.out_slabs ? 1 : 0,
+                    (a.in_dtype == DIMX_BF16 && a.cfg == 0 && gemm256_eligible(a)) ? 1 : 0);
+    }
     if (a.in_dtype == DIMX_BF16) {
         if (a.cfg == 0 && gemm256_eligible(a)) return launch_gemm256(a, s);
         if (a.out_dtype == DIMX_BF16) return launch_typed<bf16, bf16>(a, s);

@@ -159,9 +159,32 @@ __device__ __forceinline__ EpiTile<OutT> epi_tile(const Big& a, int ncol0, int l
     return e;
 }
 
+// The residual of one chunk of an f32 destination, requested ahead of the chunk's transpose (round 4): eight 16-byte pieces per lane
+// (two column passes x four row groups, the pieces store_chunk adds after its read-back).  Loaded inside store_chunk, each pass
+// stalled on its own four loads -- eight HBM round trips per tile and wave, 190-225 us for every 384-wide out / ff2 projection of
+// the prefill whatever its K; one chunk ahead, the round trip hides behind the previous chunk's transpose and stores.
+struct ResPiece {
+    float4 v[8];
+};
+template <typename OutT, bool PLAIN>
+__device__ __forceinline__ void load_residual(const Big& a, const EpiTile<OutT>& e, int mrow0, int ncol0, int lane, ResPiece& rp) {
+    if (PLAIN || sizeof(OutT) == 2) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rp.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!a.residual || mrow0 >= a.M || ncol0 >= a.N) return;
+    const int r = lane >> 3;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mrow0 + r + 8 * i, n = e.n + ps * 32;
+            if (m < a.M && n < a.N) rp.v[ps * 4 + i] = *(const float4*)(a.residual + (size_t)m * a.ldr + n);
+        }
+}
+
 template <typename OutT, int ACT, bool PLAIN>
 __device__ __forceinline__ void store_chunk(const Big& a, const EpiTile<OutT>& e, const f32x16_t& acc0, const f32x16_t& acc1,
-                                            int mrow0, int ncol0, unsigned char* scratch, int lane) {
+                                            int mrow0, int ncol0, unsigned char* scratch, int lane, const ResPiece& rp) {
     const int half = lane >> 5, l31 = lane & 31;
     constexpr bool BF = sizeof(OutT) == 2;
     constexpr int PASSES = BF ? 1 : 2;
@@ -286,7 +309,7 @@ __device__ __forceinline__ void store_chunk(const Big& a, const EpiTile<OutT>& e
                     v.x += q4.x * a.rowadd_scale; v.y += q4.y * a.rowadd_scale; v.z += q4.z * a.rowadd_scale; v.w += q4.w * a.rowadd_scale;
                 }
                 if (!PLAIN && a.residual) {
-                    const float4 q4 = *(const float4*)(a.residual + (size_t)m * a.ldr + n);
+                    const float4 q4 = rp.v[ps * 4 + i];   // requested one chunk ahead (load_residual)
                     v.x += q4.x; v.y += q4.y; v.z += q4.z; v.w += q4.w;
                 }
                 *(float4*)p = v;
@@ -585,18 +608,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Big a) {
             // closing barrier, then group 0 waits for group 1's).
             if (kOverlapEpi && wr == 0) raw_barrier();
             const EpiTile<OutT> et = epi_tile<OutT>(a, cu_n0 + wc * 64, lane);
+            ResPiece res[2];
+            load_residual<OutT, PLAIN>(a, et, cu_m0 + wr * 64, cu_n0 + wc * 64, lane, res[0]);
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
+            for (int ch = 0; ch < 4; ++ch) {
+                const int mh = ch >> 1, rb = ch & 1;
+                if (ch < 3)
+                    load_residual<OutT, PLAIN>(a, et, cu_m0 + ((ch + 1) >> 1) * 128 + wr * 64 + ((ch + 1) & 1) * 32, cu_n0 + wc * 64, lane,
+                                               res[(ch + 1) & 1]);
+                store_chunk<OutT, ACT, PLAIN>(a, et, acc[mh][0][rb], acc[mh][1][rb], cu_m0 + mh * 128 + wr * 64 + rb * 32,
+                                              cu_n0 + wc * 64, scratch, lane, res[ch & 1]);
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    store_chunk<OutT, ACT, PLAIN>(a, et, acc[mh][0][rb], acc[mh][1][rb], cu_m0 + mh * 128 + wr * 64 + rb * 32,
-                                                  cu_n0 + wc * 64, scratch, lane);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        acc[mh][0][rb][r] = 0.f;
-                        acc[mh][1][rb][r] = 0.f;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    acc[mh][0][rb][r] = 0.f;
+                    acc[mh][1][rb][r] = 0.f;
                 }
+            }
             cu_kt = 0;
             cu_q += nb;
             int tm, tn;
@@ -856,18 +883,22 @@ __global__ __launch_bounds__(512) void gemm256p2_kernel(const Big a) {
             unsigned char* scratch = smem + kLds + wave * 4096;
             if (kOverlapEpi && wr == 0) raw_barrier();
             const EpiTile<OutT> et = epi_tile<OutT>(a, cu_n0 + wc * 64, lane);
+            ResPiece res[2];
+            load_residual<OutT, PLAIN>(a, et, cu_m0 + wr * 64, cu_n0 + wc * 64, lane, res[0]);
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
+            for (int ch = 0; ch < 4; ++ch) {
+                const int mh = ch >> 1, rb = ch & 1;
+                if (ch < 3)
+                    load_residual<OutT, PLAIN>(a, et, cu_m0 + ((ch + 1) >> 1) * 128 + wr * 64 + ((ch + 1) & 1) * 32, cu_n0 + wc * 64, lane,
+                                               res[(ch + 1) & 1]);
+                store_chunk<OutT, ACT, PLAIN>(a, et, acc[mh][0][rb], acc[mh][1][rb], cu_m0 + mh * 128 + wr * 64 + rb * 32,
+                                              cu_n0 + wc * 64, scratch, lane, res[ch & 1]);
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    store_chunk<OutT, ACT, PLAIN>(a, et, acc[mh][0][rb], acc[mh][1][rb], cu_m0 + mh * 128 + wr * 64 + rb * 32,
-                                                  cu_n0 + wc * 64, scratch, lane);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        acc[mh][0][rb][r] = 0.f;
-                        acc[mh][1][rb][r] = 0.f;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    acc[mh][0][rb][r] = 0.f;
+                    acc[mh][1][rb][r] = 0.f;
                 }
+            }
             cu_kt = 0;
             cu_q += nb;
             int tm, tn;
