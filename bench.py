@@ -192,7 +192,7 @@ def ensure_ranks(args, argv):
         return
     if want == 1:
         return
-    if not args.stub:
+    if not args.stub and not args.rehearse_shared_gpu:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < want:
             raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible on this node" % (want, have))
@@ -271,10 +271,15 @@ def main():
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--no-shard-check", action="store_true")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher self-test on CPU / gloo, no kernels
+    # rehearsal of the N-rank path with the REAL model on a 1-GPU box: every rank on cuda:0, collectives on gloo (RCCL refuses
+    # two ranks on one device).  Its line says so and is not a measurement (tools/scale_check.sh rehearse).
+    ap.add_argument("--rehearse-shared-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     ensure_ranks(args, sys.argv[1:])          # N > 1 from plain python: re-executes under torch.distributed.run
-    rank, world, local = ddist.init_from_env("gloo" if args.stub else None)
+    rank, world, local = ddist.init_from_env("gloo" if (args.stub or args.rehearse_shared_gpu) else None)
+    if args.rehearse_shared_gpu:
+        local = 0
     if world != max(1, args.gpus):
         raise SystemExit("bench.py: %d rank(s) initialised for --gpus %d" % (world, args.gpus))
     if args.stub:
@@ -324,7 +329,7 @@ def main():
     check = None
     if world > 1:
         import torch.distributed as tdist
-        one = torch.ones(1, device=device)
+        one = torch.ones(1, device="cpu" if tdist.get_backend() == "gloo" else device)
         tdist.all_reduce(one)                 # the collective library (RCCL on GPUs) saw this many ranks
         rccl_ranks = int(one.item())
         if not args.no_shard_check:
@@ -359,6 +364,9 @@ def main():
     if args.stub:
         out["metric"] = "LAUNCHER SELF-TEST (--stub: CPU stand-in on gloo, no kernels) -- not a measurement"
         out["data"] = "stub"
+    if args.rehearse_shared_gpu:
+        out["metric"] = "REHEARSAL (%d ranks sharing ONE GPU, collectives on gloo) -- not a measurement" % world
+        out["data"] = "synthetic (rehearsal)"
     if check is not None:
         out["shard_check"] = check
     if rccl_ranks != world or (check is not None and not check["identical"]):

@@ -59,10 +59,18 @@ def all_gather_counts(n_rows, device):
     return [int(c.item()) for c in counts]
 
 
+def _via_host(t):
+    """gloo moves host memory: a GPU tensor on a gloo group (CPU tests with a GPU present, bench.py's one-GPU rehearsal) takes the
+    collective on the host and comes back; on RCCL ("nccl") tensors stay where they are."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def all_gather_rows(t):
     """Concatenate every rank's rows along dim 0 (shards may differ in length, empty shards included)."""
     if world_size() == 1:
         return t
+    if _via_host(t):
+        return all_gather_rows(t.cpu()).to(t.device)
     t = t.contiguous()
     w = world_size()
     counts = all_gather_counts(t.shape[0], t.device)
@@ -81,6 +89,8 @@ def all_gather_rows(t):
 def max_over_ranks(x: float, device=None) -> float:
     if world_size() == 1:
         return x
+    if device is not None and torch.device(device).type == "cuda" and dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([x], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -40,6 +40,8 @@ DIMX_ATTN_OLD=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pari
 python bench.py --steps 2 --warmup 1 --samples 10 --no-cpu-baseline --no-parity-mode --no-roofline --no-train-step > $O/r04_bench_samples10.json 2>/dev/null
 python bench.py --steps 2 --warmup 1 --batch 64 --frames 1500 --no-cpu-baseline --no-parity-mode --no-roofline --no-train-step > $O/r04_bench_c5_shard.json 2>/dev/null
 python bench.py --gpus 2 --steps 1 --warmup 0 > $O/r04_bench_gpus2_on_one_gpu.txt 2>&1; echo "exit code $?" >> $O/r04_bench_gpus2_on_one_gpu.txt
+# the 2-rank path with the real model on this 1-GPU box: both ranks on cuda:0, collectives on gloo (a rehearsal, not a measurement)
+python bench.py --gpus 2 --rehearse-shared-gpu --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/r04_bench_rehearsal_2ranks_one_gpu.json 2> $O/r04_bench_rehearsal_2ranks_one_gpu.err; echo "exit code $?" >> $O/r04_bench_rehearsal_2ranks_one_gpu.err
 # 6. training step
 python tools/bench_train.py 16 300 5 all 2>&1 | grep -v amdgpu > $O/r04_train_step.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -- python tools/bench_train.py 16 300 3 bf16 > /dev/null 2>&1
