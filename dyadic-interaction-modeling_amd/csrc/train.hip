@@ -40,6 +40,10 @@ struct Lin {          // one Linear of the stack
     int N = 0, K = 0;
     void* w_op = nullptr;   // [N][Kp] operand copy (this step)
     void* wt_op = nullptr;  // [K][Np] transposed operand copy
+    // head-padded weights of the VQ attention: the operand copies are made from an f32 scratch copy of the weight (src) and the
+    // weight gradient lands in a scratch of the same shape (gdst) before it is compacted into the arena
+    const float* src = nullptr;
+    float* gdst = nullptr;
 };
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -54,6 +58,14 @@ struct TrainPlan {
 // stack (deterministic: the caller's arenas are laid out by it)
 int build_plan(dimx_handle h, TrainPlan& p) {
     const dimx_dims& d = h->d;
+    // a tensor the engine itself does not hold (the id-conditioning tables of the legacy generator are training-only): fixed shape
+    auto add_free = [&](const std::string& name, int rows, int cols) -> int {
+        PInfo pi{name, p.total, (long)rows * cols, rows, cols};
+        p.index[name] = (int)p.params.size();
+        p.params.push_back(pi);
+        p.total += ((long)rows * cols + 3) / 4 * 4;
+        return DIMX_OK;
+    };
     auto add = [&](const std::string& name, int rows, int cols) -> int {
         auto it = h->host.find(name);
         DIMX_REQUIRE(it != h->host.end(), DIMX_ERR_WEIGHT, "train: weight %s was not loaded", name.c_str());
@@ -67,6 +79,75 @@ int build_plan(dimx_handle h, TrainPlan& p) {
         return DIMX_OK;
     };
     const int inner = d.heads * d.dim_head;
+    if (d.variant == 1) {
+        // legacy ListenerGenerator (code/seq2seq.py:165-176): the generator, the listener VQ-VAE's DECODER and the id-conditioning
+        // layers train; both VQ encoders / codebooks are frozen
+        const std::string e = "generator.encoder.", dn = "generator.decoder.net.", c = "listener_vq.decoder.";
+        const int DDl = d.dim + d.dim_a, H = d.vq_hidden, I = d.vq_inter;
+        DIMX_TRY(add(e + "project_in.weight", d.dim, d.spk_face_quan_num * d.vq_zdim));
+        DIMX_TRY(add(e + "pos_emb.emb.weight", d.max_seq_len, d.dim));
+        for (int i = 0; i < d.enc_depth; ++i) {
+            const std::string la = e + "attn_layers.layers." + std::to_string(2 * i) + ".";
+            const std::string lf = e + "attn_layers.layers." + std::to_string(2 * i + 1) + ".";
+            DIMX_TRY(add(la + "0.0.weight", 1, d.dim));
+            DIMX_TRY(add(la + "1.to_q.weight", inner, d.dim));
+            DIMX_TRY(add(la + "1.to_k.weight", inner, d.dim));
+            DIMX_TRY(add(la + "1.to_v.weight", inner, d.dim));
+            DIMX_TRY(add(la + "1.to_out.weight", d.dim, inner));
+            DIMX_TRY(add(lf + "0.0.weight", 1, d.dim));
+            DIMX_TRY(add(lf + "1.ff.0.0.weight", d.dim * d.ff_mult, d.dim));
+            DIMX_TRY(add(lf + "1.ff.0.0.bias", 1, d.dim * d.ff_mult));
+            DIMX_TRY(add(lf + "1.ff.2.weight", d.dim, d.dim * d.ff_mult));
+            DIMX_TRY(add(lf + "1.ff.2.bias", 1, d.dim));
+        }
+        DIMX_TRY(add(e + "attn_layers.final_norm.weight", 1, d.dim));
+        DIMX_TRY(add(dn + "token_emb.emb.weight", d.num_tokens, DDl));
+        DIMX_TRY(add(dn + "pos_emb.emb.weight", d.max_seq_len, DDl));
+        for (int i = 0; i < d.dec_depth; ++i) {
+            for (int k = 0; k < 2; ++k) {
+                const std::string la = dn + "attn_layers.layers." + std::to_string(3 * i + k) + ".";
+                DIMX_TRY(add(la + "0.0.weight", 1, DDl));
+                DIMX_TRY(add(la + "1.to_q.weight", inner, DDl));
+                DIMX_TRY(add(la + "1.to_k.weight", inner, DDl));
+                DIMX_TRY(add(la + "1.to_v.weight", inner, DDl));
+                DIMX_TRY(add(la + "1.to_out.weight", DDl, inner));
+            }
+            const std::string lf = dn + "attn_layers.layers." + std::to_string(3 * i + 2) + ".";
+            DIMX_TRY(add(lf + "0.0.weight", 1, DDl));
+            DIMX_TRY(add(lf + "1.ff.0.0.weight", DDl * d.ff_mult, DDl));
+            DIMX_TRY(add(lf + "1.ff.0.0.bias", 1, DDl * d.ff_mult));
+            DIMX_TRY(add(lf + "1.ff.2.weight", DDl, DDl * d.ff_mult));
+            DIMX_TRY(add(lf + "1.ff.2.bias", 1, DDl));
+        }
+        DIMX_TRY(add(dn + "attn_layers.final_norm.weight", 1, DDl));
+        DIMX_TRY(add(dn + "to_logits.weight", d.num_tokens, DDl));
+        DIMX_TRY(add(c + "decoder_linear_embedding_pre.net.weight", H, d.vq_zdim));
+        DIMX_TRY(add(c + "decoder_linear_embedding_pre.net.bias", 1, H));
+        DIMX_TRY(add(c + "expander.0.0.weight", H, 5 * H));   // [out][in][5]: rows of in * 5 + tap
+        DIMX_TRY(add(c + "expander.0.0.bias", 1, H));
+        DIMX_TRY(add(c + "decoder_linear_embedding.net.weight", H, H));
+        DIMX_TRY(add(c + "decoder_linear_embedding.net.bias", 1, H));
+        for (int i = 0; i < d.vq_layers; ++i) {
+            const std::string a = c + "decoder_transformer.net." + std::to_string(2 * i) + ".fn.";
+            const std::string m = c + "decoder_transformer.net." + std::to_string(2 * i + 1) + ".fn.";
+            DIMX_TRY(add(a + "norm.weight", 1, H));
+            DIMX_TRY(add(a + "norm.bias", 1, H));
+            DIMX_TRY(add(a + "fn.to_qkv.weight", 3 * H, H));
+            DIMX_TRY(add(a + "fn.to_out.weight", H, H));
+            DIMX_TRY(add(a + "fn.to_out.bias", 1, H));
+            DIMX_TRY(add(m + "norm.weight", 1, H));
+            DIMX_TRY(add(m + "norm.bias", 1, H));
+            DIMX_TRY(add(m + "fn.l1.weight", I, H));
+            DIMX_TRY(add(m + "fn.l1.bias", 1, I));
+            DIMX_TRY(add(m + "fn.l2.weight", H, I));
+            DIMX_TRY(add(m + "fn.l2.bias", 1, H));
+        }
+        DIMX_TRY(add(c + "vertice_map_reverse.weight", d.vq_in_dim, H));
+        DIMX_TRY(add_free("listener_embeddings.weight", 100, 256));   // code/seq2seq.py:205-210
+        DIMX_TRY(add_free("fc_listener.weight", d.dim, 256));
+        DIMX_TRY(add_free("fc_listener.bias", 1, d.dim));
+        return DIMX_OK;
+    }
     DIMX_TRY(add("patch_embed_s", 1, d.dim_in));
     DIMX_TRY(add("patch_embed_dec_s", 1, d.dim));
     DIMX_TRY(add("norm_s.weight", 1, d.dim));
@@ -317,7 +398,7 @@ int prep_lin(Step& s, Lin& l) {
     l.wt_op = s.take((size_t)l.K * Np * s.es());
     if (s.prep.n == kPrepMax) DIMX_TRY(flush_prep(s));
     PrepDesc& d = s.prep.d[s.prep.n++];
-    d.src = s.P + l.w;
+    d.src = l.src ? l.src : s.P + l.w;
     d.w = l.w_op;
     d.wt = l.wt_op;
     d.N = l.N;
@@ -358,7 +439,7 @@ int gemm_f32(Step& s, const void* A_op, int Kp, const void* W_op, int M, int N, 
 // operand is LayerNorm(ln_src) * ln_gamma and x is only the NAME of that tensor (an arena buffer that is never written: the f32
 // pre-norm output is not stored, the backward pass finds the copies through the same name)
 int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpCopy** out, int mode = 0, const float* ln_src = nullptr,
-                 const float* ln_gamma = nullptr) {
+                 const float* ln_gamma = nullptr, const float* ln_beta = nullptr) {
     const auto key = std::make_tuple(x, ldx, M, K);
     auto it = s.ops.find(key);
     if (it == s.ops.end()) {
@@ -367,7 +448,7 @@ int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpC
         c.Mp = pad_to(M, s.bk);
         c.o = s.take((size_t)M * c.Kp * s.es());
         c.t = s.take((size_t)K * c.Mp * s.es());
-        TR(tr_prep_fused(s.at, mode, mode == 2 ? ln_src : x, ldx, nullptr, 0, ln_gamma, M, K, c.o, c.Kp, c.t, c.Mp, nullptr, nullptr, s.st));
+        TR(tr_prep_fused(s.at, mode, mode == 2 ? ln_src : x, ldx, nullptr, 0, ln_gamma, M, K, c.o, c.Kp, c.t, c.Mp, nullptr, nullptr, s.st, ln_beta));
         it = s.ops.emplace(key, c).first;
     }
     if (out) *out = &it->second;
@@ -378,33 +459,34 @@ int fwd_operands(Step& s, const float* x, int ldx, int M, int K, const Step::OpC
 // (mode 1: the operand is erf-GELU(x) -- applied inside the operand copy, the activation itself is never stored in f32;
 //  mode 2: the operand is the pre-norm LayerNorm(ln_src) * ln_gamma, x names it)
 int lin_fwd(Step& s, const Lin& l, const float* x, int ldx, int M, float* y, int ldy, const float* residual = nullptr, int ldr = 0,
-            int mode = 0, const float* ln_src = nullptr, const float* ln_gamma = nullptr) {
+            int mode = 0, const float* ln_src = nullptr, const float* ln_gamma = nullptr, const float* ln_beta = nullptr) {
     const Step::OpCopy* c;
-    DIMX_TRY(fwd_operands(s, x, ldx, M, l.K, &c, mode, ln_src, ln_gamma));
+    DIMX_TRY(fwd_operands(s, x, ldx, M, l.K, &c, mode, ln_src, ln_gamma, ln_beta));
     return gemm_f32(s, c->o, c->Kp, l.w_op, M, l.N, c->Kp, y, ldy, l.b >= 0 ? s.P + l.b : nullptr, residual, ldr);  // K padded with zeros
 }
 
 // dx (+)= dy . W ; dW = dy^T . x ; db = colsum(dy).  x [M,K] (ldx), dy [M,N] (ldy) f32.  dx may be null.
 // gelu_pre: the gradient that enters is dy * GELU'(gelu_pre) (ff1's adjoint: d pre-activation is formed inside the operand copy)
 int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int ldy, int M, float* dx, int lddx, bool accumulate_dx,
-            bool x_from_cache_only = false, const float* gelu_pre = nullptr, int ld_pre = 0) {
+            bool x_from_cache_only = false, const float* gelu_pre = nullptr, int ld_pre = 0, bool gelu_tanh = false) {
+    float* const dW = l.gdst ? l.gdst : s.G + l.w;
     float* bias_part = nullptr;   // d bias = column sums of the gradient: partial rows from the operand copy's pass over dy
     if (l.b >= 0) bias_part = s.pool_f32((size_t)ceil_div(M, 32) * l.N);
     const size_t mark = s.ar->off;
     const int Mp = pad_to(M, s.bk), Np = pad_to(l.N, s.bk);
     const auto it = s.ops.find(std::make_tuple(x, ldx, M, l.K));
-    const bool side = s.use_side && it != s.ops.end();
+    const bool side = s.use_side && it != s.ops.end() && !l.gdst;   // a padded weight's gradient is compacted on this stream right after
     const int k = s.slot_n % kSideSlots;
     void* dyo = s.take((size_t)M * Np * s.es());     // dy and dy^T in the operand type: one pass over dy
     void* dyT = side ? s.slot_buf[k] : s.take((size_t)l.N * Mp * s.es());
     if (side && s.live() && s.slot_n >= kSideSlots) DIMX_HIP(hipStreamWaitEvent(s.st, s.ts->ev_side[k], 0));  // the slot's last reader
     int n_part = ceil_div(M, 32);
-    TR(tr_prep_fused(s.at, gelu_pre ? 3 : 0, dy, ldy, gelu_pre, ld_pre, nullptr, M, l.N, dyo, Np, dyT, Mp, bias_part, &n_part, s.st));
+    TR(tr_prep_fused(s.at, gelu_pre ? (gelu_tanh ? 5 : 3) : 0, dy, ldy, gelu_pre, ld_pre, nullptr, M, l.N, dyo, Np, dyT, Mp, bias_part, &n_part, s.st));
     if (bias_part) DIMX_TRY(queue_fin(s, bias_part, s.G + l.b, l.N, n_part));
     if (side && s.live()) {
         DIMX_HIP(hipEventRecord(s.ts->ev_main[k], s.st));
         DIMX_HIP(hipStreamWaitEvent(s.ts->side, s.ts->ev_main[k], 0));
-        DIMX_TRY(gemm_f32(s, dyT, Mp, it->second.t, l.N, l.K, Mp, s.G + l.w, l.K, nullptr, nullptr, 0, s.ts->side));
+        DIMX_TRY(gemm_f32(s, dyT, Mp, it->second.t, l.N, l.K, Mp, dW, l.K, nullptr, nullptr, 0, s.ts->side));
         DIMX_HIP(hipEventRecord(s.ts->ev_side[k], s.ts->side));
     }
     if (side) ++s.slot_n;
@@ -419,7 +501,7 @@ int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int
             TR(tr_transpose_pad(s.at, x, ldx, t, Mp, M, l.K, s.st));
             xT = t;
         }
-        TR(gemm_f32(s, dyT, Mp, xT, l.N, l.K, Mp, s.G + l.w, l.K, nullptr, nullptr, 0));  // contraction over the zero-padded rows
+        TR(gemm_f32(s, dyT, Mp, xT, l.N, l.K, Mp, dW, l.K, nullptr, nullptr, 0));  // contraction over the zero-padded rows
     }
     s.ar->off = mark;
     return DIMX_OK;
@@ -604,7 +686,8 @@ struct EncSave {
     float* out;             // final norm output
 };
 
-int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int Cin, const uint8_t* mask_rows, const uint8_t* mask_bt) {
+int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int Cin, const uint8_t* mask_rows, const uint8_t* mask_bt,
+            int causal = 1) {
     const dimx_dims& d = s.h->d;
     const int M = s.M, C = d.dim;
     e.pre = pre;
@@ -634,7 +717,7 @@ int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int 
     memset(&sh, 0, sizeof(sh));
     sh.B = s.B; sh.H = d.heads; sh.Lq = s.T; sh.Lk = s.T;
     sh.scale = 1.0f / sqrtf((float)d.dim_head);
-    sh.causal = 1;
+    sh.causal = causal;
     sh.kmask = mask_bt;
     for (int i = 0; i < d.enc_depth; ++i) {
         DIMX_TRY(attn_fwd(s, e.attn[i], e.h[2 * i], e.h[2 * i + 1], M, C, false, nullptr, 0, 0, sh, mask_rows));
@@ -659,6 +742,235 @@ int enc_bwd(Step& s, EncSave& e, const float* d_out, float* dx_in) {
     TR(tr_pos_grad(dh, s.g(e.pre + "pos_emb.emb.weight"), s.B, s.T, C, 1.0f / sqrtf((float)C), s.st));
     DIMX_TRY(lin_bwd(s, e.pin, e.x_in, e.Cin, dh, C, M, dx_in, e.Cin, false));
     s.ar->off = mark;
+    return DIMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- decoder stack
+// TransformerWrapper(num_tokens, Decoder(cross_attend = True)) on a token prefix, teacher-forced: token (+ positional) embedding,
+// depth x {causal self-attention, cross-attention over the context, feed-forward}, final norm, logits.
+struct DecSave {
+    std::string pre;
+    std::vector<AttnSave> sa, ca;
+    std::vector<FFSave> ff;
+    std::vector<float*> hd;
+    Lin lg;
+    float* yf;
+    const int32_t* inp;
+    int B, n, Md, DD, depth;
+    bool pos_emb;
+};
+int dec_prepare(Step& s, DecSave& D, const std::string& pre, int depth) {
+    D.pre = pre;
+    D.depth = depth;
+    D.sa.resize(depth);
+    D.ca.resize(depth);
+    D.ff.resize(depth);
+    for (int i = 0; i < depth; ++i) {
+        DIMX_TRY(attn_prepare(s, D.sa[i], pre + "attn_layers.layers." + std::to_string(3 * i) + ".", false));
+        DIMX_TRY(attn_prepare(s, D.ca[i], pre + "attn_layers.layers." + std::to_string(3 * i + 1) + ".", true));
+        DIMX_TRY(ff_prepare(s, D.ff[i], pre + "attn_layers.layers." + std::to_string(3 * i + 2) + "."));
+    }
+    D.lg = make_lin(s, pre + "to_logits.weight");
+    DIMX_TRY(prep_lin(s, D.lg));
+    return DIMX_OK;
+}
+// inp [B, n] token ids; ctx [B * Lk, Ck] with key keep-mask ctx_mask [B, Lk]; logits [B * n, num_tokens]
+int dec_fwd(Step& s, DecSave& D, const int32_t* inp, int B, int n, const float* ctx, int Lk, int Ck, const uint8_t* ctx_mask,
+            const uint8_t* kv_mask, bool pos_emb, float* logits) {
+    const dimx_dims& d = s.h->d;
+    const int DD = d.dim + d.dim_a, Md = B * n;
+    D.B = B; D.n = n; D.Md = Md; D.DD = DD; D.inp = inp; D.pos_emb = pos_emb;
+    D.hd.assign(3 * D.depth + 1, nullptr);
+    for (auto& p : D.hd) p = s.f32((size_t)Md * DD);
+    TR(launch_gather_rows(DIMX_F32, s.p(D.pre + "token_emb.emb.weight"), DD, d.num_tokens, inp, D.hd[0], DD, Md, DD, s.st));
+    if (pos_emb)   // AbsolutePositionalEmbedding: + emb[:n] * dim^-0.5
+        TR(tr_add_rows(D.hd[0], DD, nullptr, s.p(D.pre + "pos_emb.emb.weight"), 1.0f / sqrtf((float)DD), n, D.hd[0], DD, Md, DD, s.st));
+    TrAttn self_sh, cross_sh;
+    memset(&self_sh, 0, sizeof(self_sh));
+    self_sh.B = B; self_sh.H = d.heads; self_sh.Lq = n; self_sh.Lk = n;
+    self_sh.scale = 1.0f / sqrtf((float)d.dim_head);
+    self_sh.causal = 1;
+    self_sh.kmask2 = kv_mask;
+    cross_sh = self_sh;
+    cross_sh.Lk = Lk;
+    cross_sh.causal = 0;
+    cross_sh.kmask = ctx_mask;
+    cross_sh.kmask2 = nullptr;
+    for (int i = 0; i < D.depth; ++i) {
+        DIMX_TRY(attn_fwd(s, D.sa[i], D.hd[3 * i], D.hd[3 * i + 1], Md, DD, false, nullptr, 0, 0, self_sh, nullptr));
+        DIMX_TRY(attn_fwd(s, D.ca[i], D.hd[3 * i + 1], D.hd[3 * i + 2], Md, DD, true, ctx, B * Lk, Ck, cross_sh, nullptr));
+        DIMX_TRY(ff_fwd(s, D.ff[i], D.hd[3 * i + 2], D.hd[3 * i + 3], Md, DD));
+    }
+    D.yf = s.f32((size_t)Md * DD);   // names the final norm's output (formed inside the logits projection's operand copy)
+    DIMX_TRY(lin_fwd(s, D.lg, D.yf, DD, Md, logits, d.num_tokens, nullptr, 0, 2, D.hd[3 * D.depth], s.p(D.pre + "attn_layers.final_norm.weight")));
+    return DIMX_OK;
+}
+// dlogits -> every decoder gradient; dctx [B * Lk, Ck] accumulates the context gradient (zeroed by the caller)
+int dec_bwd(Step& s, DecSave& D, const float* dlogits, float* dctx) {
+    const dimx_dims& d = s.h->d;
+    const int DD = D.DD, Md = D.Md;
+    float* dyf = s.f32((size_t)Md * DD);
+    float* dh = s.f32((size_t)Md * DD);
+    DIMX_TRY(lin_bwd(s, D.lg, D.yf, DD, dlogits, d.num_tokens, Md, dyf, DD, false));
+    DIMX_TRY(ln_bwd_full(s, D.hd[3 * D.depth], D.pre + "attn_layers.final_norm.weight", "", dyf, dh, Md, DD));
+    for (int i = D.depth - 1; i >= 0; --i) {
+        DIMX_TRY(ff_bwd(s, D.ff[i], dh));
+        DIMX_TRY(attn_bwd(s, D.ca[i], dh, dctx));
+        DIMX_TRY(attn_bwd(s, D.sa[i], dh, nullptr));
+    }
+    if (D.pos_emb) TR(tr_pos_grad(dh, s.g(D.pre + "pos_emb.emb.weight"), D.B, D.n, DD, 1.0f / sqrtf((float)DD), s.st));
+    {   // d token_emb = onehot(inp)^T . dh on the library GEMM
+        const size_t mark = s.ar->off;
+        const int Mp = pad_to(Md, s.bk);
+        void* ohT = s.take((size_t)d.num_tokens * Mp * s.es());
+        void* dhT = s.take((size_t)DD * Mp * s.es());
+        TR(tr_onehot_t(s.at, D.inp, ohT, Mp, Md, d.num_tokens, s.st));
+        TR(tr_transpose_pad(s.at, dh, DD, dhT, Mp, Md, DD, s.st));
+        TR(gemm_f32(s, ohT, Mp, dhT, d.num_tokens, DD, Mp, s.g(D.pre + "token_emb.emb.weight"), DD, nullptr, nullptr, 0));
+        s.ar->off = mark;
+    }
+    return DIMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- VQ-VAE decoder
+// TransformerDecoder of the listener VQ-VAE (code/models/stage1_BIWI.py:376-393), trainable in the legacy loop: linear, Conv1d(k 5,
+// replicate) as im2col + GEMM, LeakyReLU(0.2) + InstanceNorm over time, linear, + pe[clip], layers x {pre-LN attention with a
+// packed qkv projection and scale hidden^-0.5, pre-LN tanh-GELU MLP}, bias-free output map.  The 8 heads of 48 run on the
+// 64-wide attention kernels as zero-padded heads: the qkv / out weights are padded into scratch copies per step (zero rows /
+// columns), every padded activation column is then zero by construction, and the weight gradients are compacted back.
+struct VqLayerSave {
+    std::string a, m;   // "...net.2i.fn." / "...net.2i+1.fn."
+    Lin qkv, out, l1, l2;
+    float *h_in, *h_mid;            // residual stream before the attention / before the MLP
+    float *ya, *ym;                 // names of the two pre-norm outputs
+    float *qkvb, *ob, *lse, *pre_act;
+    float *wq_pad, *wo_pad, *gq_pad, *go_pad;
+    TrAttn shape;
+};
+struct VqDecSave {
+    std::string c;
+    Lin pre, conv, emb, rev;
+    std::vector<VqLayerSave> L;
+    float *zq, *h0, *x5, *xc, *yn, *h_out;
+    int B, n, M, H, I;
+};
+int vqdec_fwd(Step& s, VqDecSave& V, const std::string& c, const int32_t* idx, const float* codebook, const float* pe, int B, int n, float* pred) {
+    const dimx_dims& d = s.h->d;
+    const int H = d.vq_hidden, I = d.vq_inter, M = B * n, G = d.vq_heads;
+    DIMX_REQUIRE(H == 8 * 48 && G == 8 && d.vq_zdim == 128, DIMX_ERR_ARG, "train: the VQ decoder step is written for 8 heads of 48, 128-wide codes");
+    V.c = c; V.B = B; V.n = n; V.M = M; V.H = H; V.I = I;
+    V.pre = make_lin(s, c + "decoder_linear_embedding_pre.net.weight", c + "decoder_linear_embedding_pre.net.bias");
+    V.conv = make_lin(s, c + "expander.0.0.weight", c + "expander.0.0.bias");
+    V.emb = make_lin(s, c + "decoder_linear_embedding.net.weight", c + "decoder_linear_embedding.net.bias");
+    V.rev = make_lin(s, c + "vertice_map_reverse.weight");
+    DIMX_TRY(prep_lin(s, V.pre));
+    DIMX_TRY(prep_lin(s, V.conv));
+    DIMX_TRY(prep_lin(s, V.emb));
+    DIMX_TRY(prep_lin(s, V.rev));
+    V.L.resize(d.vq_layers);
+    for (int i = 0; i < d.vq_layers; ++i) {
+        VqLayerSave& l = V.L[i];
+        l.a = c + "decoder_transformer.net." + std::to_string(2 * i) + ".fn.";
+        l.m = c + "decoder_transformer.net." + std::to_string(2 * i + 1) + ".fn.";
+        l.qkv = make_lin(s, l.a + "fn.to_qkv.weight");
+        l.out = make_lin(s, l.a + "fn.to_out.weight", l.a + "fn.to_out.bias");
+        l.l1 = make_lin(s, l.m + "fn.l1.weight", l.m + "fn.l1.bias");
+        l.l2 = make_lin(s, l.m + "fn.l2.weight", l.m + "fn.l2.bias");
+        l.wq_pad = s.f32((size_t)3 * G * 64 * H);
+        l.wo_pad = s.f32((size_t)H * G * 64);
+        TR(tr_pad_head_rows(s.P + l.qkv.w, l.wq_pad, 3 * G, H, 0, s.st));
+        TR(tr_pad_head_cols(s.P + l.out.w, l.wo_pad, H, G, 0, s.st));
+        l.qkv.src = l.wq_pad;
+        l.qkv.N = 3 * G * 64;
+        l.out.src = l.wo_pad;
+        l.out.K = G * 64;
+        DIMX_TRY(prep_lin(s, l.qkv));
+        DIMX_TRY(prep_lin(s, l.out));
+        DIMX_TRY(prep_lin(s, l.l1));
+        DIMX_TRY(prep_lin(s, l.l2));
+    }
+    DIMX_TRY(flush_prep(s));
+    V.zq = s.f32((size_t)M * 128);
+    V.h0 = s.f32((size_t)M * H);
+    V.x5 = s.f32((size_t)M * 5 * H);
+    V.xc = s.f32((size_t)M * H);
+    V.yn = s.f32((size_t)M * H);
+    float* h = s.f32((size_t)M * H);
+    TR(tr_gather128(codebook, idx, V.zq, M, s.st));
+    DIMX_TRY(lin_fwd(s, V.pre, V.zq, 128, M, V.h0, H));
+    TR(tr_im2col5(V.h0, V.x5, B, n, H, s.st));
+    DIMX_TRY(lin_fwd(s, V.conv, V.x5, 5 * H, M, V.xc, H));
+    TR(tr_lrelu_inorm_fwd(V.xc, V.yn, B, n, H, s.st));
+    DIMX_TRY(lin_fwd(s, V.emb, V.yn, H, M, h, H));
+    TR(tr_add_clip_rows(h, pe, h, M, n, H, s.st));
+    for (int i = 0; i < d.vq_layers; ++i) {
+        VqLayerSave& l = V.L[i];
+        l.h_in = h;
+        l.ya = s.f32((size_t)M * H);
+        l.qkvb = s.f32((size_t)M * 3 * G * 64);
+        l.ob = s.f32((size_t)M * G * 64);
+        l.lse = s.f32((size_t)B * G * n);
+        DIMX_TRY(lin_fwd(s, l.qkv, l.ya, H, M, l.qkvb, 3 * G * 64, nullptr, 0, 2, h, s.p(l.a + "norm.weight"), s.p(l.a + "norm.bias")));
+        memset(&l.shape, 0, sizeof(l.shape));
+        l.shape.B = B; l.shape.H = G; l.shape.Lq = n; l.shape.Lk = n;
+        l.shape.ldq = l.shape.ldk = l.shape.ldv = 3 * G * 64;
+        l.shape.ldo = G * 64;
+        l.shape.scale = 1.0f / sqrtf((float)H);   // hidden^-0.5, not head^-0.5 (code/models/lib/base_models.py:131)
+        l.shape.mfma = s.at == DIMX_BF16 ? 1 : 2;
+        TR(tr_attn_fwd(l.shape, l.qkvb, l.qkvb + G * 64, l.qkvb + 2 * G * 64, l.ob, l.lse, s.st));
+        l.h_mid = s.f32((size_t)M * H);
+        DIMX_TRY(lin_fwd(s, l.out, l.ob, G * 64, M, l.h_mid, H, h, H));
+        l.ym = s.f32((size_t)M * H);
+        l.pre_act = s.f32((size_t)M * I);
+        DIMX_TRY(lin_fwd(s, l.l1, l.ym, H, M, l.pre_act, I, nullptr, 0, 2, l.h_mid, s.p(l.m + "norm.weight"), s.p(l.m + "norm.bias")));
+        float* h2 = s.f32((size_t)M * H);
+        DIMX_TRY(lin_fwd(s, l.l2, l.pre_act, I, M, h2, H, l.h_mid, H, 4));
+        h = h2;
+    }
+    V.h_out = h;
+    DIMX_TRY(lin_fwd(s, V.rev, h, H, M, pred, d.vq_in_dim));
+    return DIMX_OK;
+}
+int vqdec_bwd(Step& s, VqDecSave& V, const float* dpred) {
+    const dimx_dims& d = s.h->d;
+    const int H = V.H, I = V.I, M = V.M, B = V.B, n = V.n, G = d.vq_heads;
+    float* dh = s.f32((size_t)M * H);
+    DIMX_TRY(lin_bwd(s, V.rev, V.h_out, H, dpred, d.vq_in_dim, M, dh, H, false));
+    for (int i = d.vq_layers - 1; i >= 0; --i) {
+        VqLayerSave& l = V.L[i];
+        const size_t mark = s.ar->off;
+        float* da = s.f32((size_t)M * I);
+        DIMX_TRY(lin_bwd(s, l.l2, l.pre_act, I, dh, H, M, da, I, false, true));
+        float* dy = s.f32((size_t)M * H);
+        DIMX_TRY(lin_bwd(s, l.l1, l.ym, H, da, I, M, dy, H, false, false, l.pre_act, I, true));
+        DIMX_TRY(ln_adjoint(s, l.h_mid, s.p(l.m + "norm.weight"), dy, dh, 1, M, H, s.g(l.m + "norm.weight"), s.g(l.m + "norm.bias")));
+        // attention sublayer
+        l.go_pad = s.f32((size_t)H * G * 64);
+        l.out.gdst = l.go_pad;
+        float* d_o = s.f32((size_t)M * G * 64);
+        DIMX_TRY(lin_bwd(s, l.out, l.ob, G * 64, dh, H, M, d_o, G * 64, false));
+        TR(tr_pad_head_cols(l.go_pad, s.G + l.out.w, H, G, 1, s.st));
+        float* dqkv = s.f32((size_t)M * 3 * G * 64);
+        float* delta = s.f32((size_t)B * G * n);
+        TR(tr_attn_bwd(l.shape, l.qkvb, l.qkvb + G * 64, l.qkvb + 2 * G * 64, l.ob, d_o, l.lse, delta, dqkv, 3 * G * 64, dqkv + G * 64, 3 * G * 64,
+                       dqkv + 2 * G * 64, 3 * G * 64, s.st));
+        l.gq_pad = s.f32((size_t)3 * G * 64 * H);
+        l.qkv.gdst = l.gq_pad;
+        DIMX_TRY(lin_bwd(s, l.qkv, l.ya, H, dqkv, 3 * G * 64, M, dy, H, false));
+        TR(tr_pad_head_rows(l.gq_pad, s.G + l.qkv.w, 3 * G, H, 1, s.st));
+        DIMX_TRY(ln_adjoint(s, l.h_in, s.p(l.a + "norm.weight"), dy, dh, 1, M, H, s.g(l.a + "norm.weight"), s.g(l.a + "norm.bias")));
+        s.ar->off = mark;
+    }
+    // (+ pe: a buffer, no gradient) -> linear -> InstanceNorm / LeakyReLU -> conv -> linear; the codes carry no gradient (arg-max)
+    float* d_yn = s.f32((size_t)M * H);
+    DIMX_TRY(lin_bwd(s, V.emb, V.yn, H, dh, H, M, d_yn, H, false));
+    float* d_xc = s.f32((size_t)M * H);
+    TR(tr_lrelu_inorm_bwd(V.xc, d_yn, d_xc, B, n, H, s.st));
+    float* d_x5 = s.f32((size_t)M * 5 * H);
+    DIMX_TRY(lin_bwd(s, V.conv, V.x5, 5 * H, d_xc, H, M, d_x5, 5 * H, false));
+    float* d_h0 = s.f32((size_t)M * H);
+    TR(tr_col2im5(d_x5, d_h0, B, n, H, s.st));
+    DIMX_TRY(lin_bwd(s, V.pre, V.zq, 128, d_h0, H, M, nullptr, 0, false));
     return DIMX_OK;
 }
 
@@ -864,6 +1176,164 @@ static bool train_use_graph(int rows) {
 static bool train_use_side(int rows) {
     const int f = env_flag("DIMX_TRAIN_SIDE");
     return f >= 0 ? f == 1 : !train_use_graph(rows);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- legacy generator
+// One forward + backward pass of ListenerGenerator.forward as the reference's loop calls it (code/x_engine.py:8-36 ->
+// code/seq2seq.py:235-278 with Transformer.forward :46-67): bidirectional encoder over the frozen speaker VQ-VAE's features, the
+// listener-id row in front of the context, the teacher-forced decoder with absolute positions, cross entropy + the continuous loss
+// of the decoded arg-max codes, which trains the listener VQ-VAE's DECODER.
+static int legacy_run(dimx_handle h, const float* params, float* grads, const float* x_speaker, const int32_t* z_l, const float* v_listener,
+                      const uint8_t* mask, const int32_t* listener_ids, const float* codebook, const float* pe, int B, int T, float* loss_out,
+                      float* pred_out, float* logits_out, void* ws, size_t ws_bytes, hipStream_t st, size_t* need, bool use_side) {
+    int rc;
+    TrainState* ts = state_of(h, &rc);
+    if (!ts) return rc;
+    TrainPlan* plan = &ts->plan;
+    const dimx_dims& d = h->d;
+    DIMX_REQUIRE(h->variant == 1, DIMX_ERR_ARG, "train_legacy: the handle is not the legacy variant");
+    DIMX_REQUIRE(B >= 1 && T >= 2 && T + 1 <= d.max_seq_len, DIMX_ERR_ARG, "train_legacy: B=%d T=%d out of range", B, T);
+    DIMX_REQUIRE(d.num_tokens == 512 && d.dim_a == 0, DIMX_ERR_ARG, "train_legacy: 512 codes, no audio stream");
+    Arena ar(ws, ws_bytes);
+    Step s;
+    s.h = h; s.plan = plan; s.P = params; s.G = grads; s.ar = &ar; s.st = st;
+    s.at = h->at;
+    s.bk = h->at == DIMX_BF16 ? 64 : 32;
+    s.B = B; s.T = T; s.M = B * T;
+    s.n = T - 1;
+    s.Md = B * (T - 1);
+    s.prep.n = 0;
+    s.prep.total_tiles = 0;
+    const bool ids = listener_ids != nullptr;
+    const int DD = d.dim, F = std::max(DD * d.ff_mult, d.vq_inter), inner = d.heads * d.dim_head, H = d.vq_hidden;
+    const int Lk = ids ? T + 1 : T, nd = ids ? T : T - 1, n = T - 1, E = 256;
+    const int rows_max = B * (T + 1);
+    s.part = s.f32((size_t)2 * kTrSlabs * F);
+    s.ts = ts;
+    s.use_side = use_side;
+    if (use_side) {
+        const size_t slot = (size_t)std::max(F, 3 * inner) * pad_to(rows_max, s.bk) * s.es();
+        for (int i = 0; i < kSideSlots; ++i) s.slot_buf[i] = s.take(slot);
+        if (ws != nullptr) DIMX_TRY(side_ready(*ts));
+    }
+    {
+        const size_t n_ln = (size_t)(2 * d.enc_depth + 3 * d.dec_depth + 4 * d.vq_layers + 8);
+        const size_t n_b = (size_t)(2 * d.enc_depth + 2 * d.dec_depth + 3 * d.vq_layers + 8);
+        s.pool_cap = n_ln * (kLnBlocks + 4) * (size_t)DD + n_b * (size_t)std::max(kTrSlabs, ceil_div(rows_max, 32) + 1) * (size_t)F + 4096;
+        s.pool = s.f32(s.pool_cap);
+        s.pool_off = 0;
+        s.fin.n = 0;
+        s.fin.total_blocks = 0;
+    }
+    const bool live = ws != nullptr;
+    if (live) DIMX_HIP(hipMemsetAsync(grads, 0, (size_t)plan->total * sizeof(float), st));
+
+    // ---------------- encoder (mask-only attention: Encoder, not causal) over x_speaker [B, T, 8 x 128]
+    EncSave e;
+    DIMX_TRY(enc_fwd(s, e, "generator.encoder.", x_speaker, d.spk_face_quan_num * d.vq_zdim, mask, mask, 0));
+    // ---------------- context (+ the listener-id row in front), tokens
+    DecSave D;
+    DIMX_TRY(dec_prepare(s, D, "generator.decoder.net.", d.dec_depth));
+    Lin fc;
+    if (ids) {
+        fc = make_lin(s, "fc_listener.weight", "fc_listener.bias");
+        DIMX_TRY(prep_lin(s, fc));
+    }
+    DIMX_TRY(flush_prep(s));
+    const float* ctx = e.out;
+    const uint8_t* cmask = mask;
+    const int32_t* zsrc = z_l;
+    float *e_relu = nullptr, *lid = nullptr;
+    if (ids) {
+        e_relu = s.f32((size_t)B * E);
+        lid = s.f32((size_t)B * DD);
+        float* cj = s.f32((size_t)B * Lk * DD);
+        int32_t* z_ext = (int32_t*)s.take((size_t)B * Lk * 4);
+        uint8_t* m_ext = (uint8_t*)s.take((size_t)B * Lk);
+        TR(tr_emb_relu(s.p("listener_embeddings.weight"), listener_ids, e_relu, B, E, st));
+        DIMX_TRY(lin_fwd(s, fc, e_relu, E, B, lid, DD));
+        TR(tr_prepend_row(lid, e.out, cj, B, T, DD, 0, st));
+        TR(tr_prepend_tokens(z_l, mask, z_ext, m_ext, B, T, st));
+        ctx = cj;
+        cmask = m_ext;
+        zsrc = z_ext;
+    }
+    int32_t* inp = (int32_t*)s.take((size_t)B * nd * 4);
+    int32_t* tgt = (int32_t*)s.take((size_t)B * nd * 4);
+    TR(launch_shift_tokens(zsrc, inp, tgt, B, nd + 1, st));
+    float* logits = logits_out ? logits_out : s.f32((size_t)B * nd * d.num_tokens);
+    DIMX_TRY(dec_fwd(s, D, inp, B, nd, ctx, Lk, DD, cmask, nullptr, true, logits));
+    float* dlogits = s.f32((size_t)B * nd * d.num_tokens);
+    float* row_loss = s.f32((size_t)B * nd);
+    TR(tr_cross_entropy(logits, tgt, row_loss, dlogits, B * nd, loss_out, st));
+    // ---------------- decoded arg-max codes -> continuous loss (logits[:, 1:] when the id row shifted them)
+    int32_t* idx = (int32_t*)s.take((size_t)B * n * 4);
+    TR(tr_argmax512(logits, idx, B, nd, n, ids ? 1 : 0, st));
+    float* pred = pred_out ? pred_out : s.f32((size_t)B * n * d.vq_in_dim);
+    VqDecSave V;
+    DIMX_TRY(vqdec_fwd(s, V, "listener_vq.decoder.", idx, codebook, pe, B, n, pred));
+    float* rown = s.f32((size_t)2 * B * n);
+    float* dpred = s.f32((size_t)B * n * d.vq_in_dim);
+    DIMX_REQUIRE(d.vq_in_dim == 56, DIMX_ERR_ARG, "train_legacy: the continuous loss is written for 56 coefficients");
+    TR(tr_cont_loss(pred, v_listener, mask, B, T, n, rown, dpred, loss_out ? loss_out + 2 : nullptr, st));
+
+    // ---------------- backward
+    DIMX_TRY(vqdec_bwd(s, V, dpred));
+    float* dctx = s.f32((size_t)B * Lk * DD);
+    if (live) DIMX_HIP(hipMemsetAsync(dctx, 0, (size_t)B * Lk * DD * sizeof(float), st));
+    DIMX_TRY(dec_bwd(s, D, dlogits, dctx));
+    float* d_enc = dctx;
+    if (ids) {
+        float* d_lid = s.f32((size_t)B * DD);
+        d_enc = s.f32((size_t)s.M * DD);
+        TR(tr_prepend_row(d_lid, d_enc, dctx, B, T, DD, 1, st));
+        float* d_e = s.f32((size_t)B * E);
+        DIMX_TRY(lin_bwd(s, fc, e_relu, E, d_lid, DD, B, d_e, E, false));
+        TR(tr_emb_relu_bwd(s.p("listener_embeddings.weight"), listener_ids, d_e, s.g("listener_embeddings.weight"), B, E, st));
+    }
+    DIMX_TRY(enc_bwd(s, e, d_enc, nullptr));
+    DIMX_TRY(flush_fin(s));
+    if (use_side && live && s.slot_n > 0) {
+        DIMX_HIP(hipEventRecord(ts->ev_join, ts->side));
+        DIMX_HIP(hipStreamWaitEvent(st, ts->ev_join, 0));
+    }
+    if (need) *need = s.peak + 256;
+    DIMX_REQUIRE(!s.pool_overflow, DIMX_ERR_STATE, "train_legacy: the partial-row pool of the column reductions is too small");
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "train_legacy: workspace %zu < required %zu", ws_bytes, s.peak);
+    return DIMX_OK;
+}
+
+size_t dimx_train_legacy_workspace_bytes(dimx_handle h, int B, int T) {
+    if (!h || B < 1 || T < 2) return 0;
+    size_t need = 0;
+    const uint8_t* tok = (const uint8_t*)0x100;
+    if (legacy_run(h, nullptr, nullptr, nullptr, nullptr, nullptr, tok, (const int32_t*)tok, nullptr, nullptr, B, T, nullptr, nullptr, nullptr,
+                   nullptr, 0, nullptr, &need, true) != DIMX_OK)
+        return 0;
+    return need;
+}
+
+int dimx_train_legacy_forward_backward(dimx_handle h, const float* params, float* grads, const float* x_speaker, const int32_t* z_l,
+                                       const float* v_listener, const uint8_t* mask, const int32_t* listener_ids, const float* codebook,
+                                       const float* pe, int B, int T, float* loss_out, float* pred_out, float* logits_out, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(h && params && grads && x_speaker && z_l && v_listener && mask && codebook && pe && loss_out && ws, DIMX_ERR_ARG,
+                 "train_legacy: null argument");
+    DIMX_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0 && ((uintptr_t)x_speaker % 16) == 0 &&
+                     ((uintptr_t)codebook % 16) == 0 && ((uintptr_t)pe % 16) == 0,
+                 DIMX_ERR_ARG, "train_legacy: workspace must be 256-byte aligned, arenas / inputs 16-byte aligned");
+    DIMX_HIP(hipSetDevice(h->device));
+    const bool side = train_use_side(B * T);
+    {
+        size_t need = 0;
+        const uint8_t* tok = (const uint8_t*)0x100;
+        DIMX_TRY(legacy_run(h, nullptr, nullptr, nullptr, nullptr, nullptr, tok, listener_ids ? (const int32_t*)tok : nullptr, nullptr, nullptr, B,
+                            T, nullptr, pred_out ? (float*)0x100 : nullptr, logits_out ? (float*)0x100 : nullptr, nullptr, 0, nullptr, &need, side));
+        DIMX_REQUIRE(ws_bytes >= need, DIMX_ERR_WORKSPACE, "train_legacy: workspace %zu < required %zu (dimx_train_legacy_workspace_bytes)",
+                     ws_bytes, need);
+    }
+    return legacy_run(h, params, grads, x_speaker, z_l, v_listener, mask, listener_ids, codebook, pe, B, T, loss_out, pred_out, logits_out, ws,
+                      ws_bytes, (hipStream_t)stream, nullptr, side);
 }
 
 size_t dimx_train_workspace_bytes(dimx_handle h, int B, int T) {

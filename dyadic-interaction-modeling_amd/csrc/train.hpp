@@ -45,10 +45,27 @@ struct PrepFused {
     void* o;
     void* t;
     float* colpart;
+    const float* beta;
     int lds, lds2, Kp, Mp, rows, cols, mode, chunk;
 };
 int tr_prep_fused(int out_dtype, int mode, const float* src, int lds, const float* src2, int lds2, const float* gamma, int rows, int cols,
-                  void* o, int Kp, void* t, int Mp, float* colpart, int* n_part, hipStream_t s);
+                  void* o, int Kp, void* t, int Mp, float* colpart, int* n_part, hipStream_t s, const float* beta = nullptr);
+// VQ-VAE decoder / legacy generator glue (train_kernels.hip)
+int tr_im2col5(const float* x, float* x5, int B, int n, int C, hipStream_t s);
+int tr_col2im5(const float* dx5, float* dx, int B, int n, int C, hipStream_t s);
+int tr_lrelu_inorm_fwd(const float* x, float* y, int B, int n, int C, hipStream_t s);
+int tr_lrelu_inorm_bwd(const float* x, const float* dy, float* dx, int B, int n, int C, hipStream_t s);
+int tr_add_clip_rows(const float* a, const float* rows, float* y, int M, int n, int C, hipStream_t s);
+int tr_argmax512(const float* logits, int32_t* idx, int B, int n_in, int n_out, int t_off, hipStream_t s);
+int tr_cont_loss(const float* pred, const float* v_tgt, const uint8_t* mask, int B, int T, int n, float* rown, float* dpred, float* loss_out,
+                 hipStream_t s);
+int tr_pad_head_rows(const float* src, float* dst, int groups, int cols, int unpad, hipStream_t s);
+int tr_pad_head_cols(const float* src, float* dst, int rows, int groups, int unpad, hipStream_t s);
+int tr_emb_relu(const float* table, const int32_t* ids, float* e, int B, int E, hipStream_t s);
+int tr_emb_relu_bwd(const float* table, const int32_t* ids, const float* de, float* dtable, int B, int E, hipStream_t s);
+int tr_prepend_row(const float* first, const float* rest, float* joint, int B, int T, int C, int split, hipStream_t s);
+int tr_prepend_tokens(const int32_t* z, const uint8_t* mask, int32_t* z_ext, uint8_t* m_ext, int B, int T, hipStream_t s);
+int tr_gather128(const float* book, const int32_t* idx, float* out, int R, hipStream_t s);
 int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s);
 int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
 int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void prep_pair_kernel(PrepDesc d) {
 //   mode 1  v = erf-GELU(src)                    (the feed-forward activation as ff2's operand)
 //   mode 2  v = LayerNorm(src) * gamma           (the pre-norm of a sublayer as its projection's operand; the f32 y is never stored)
 //   mode 3  v = src * GELU'(src2)                (d pre-activation as ff1's adjoint operand; colpart gives d bias of ff1)
+//   mode 4 / 5: modes 1 / 3 with the tanh form of GELU (the VQ-VAE's MLP, code/models/lib/base_models.py:107-123)
+// (mode 2 with beta: LayerNorm with bias, the VQ-VAE's pre-norms)
 // Block = 32 rows x `chunk` columns, 64 columns at a time: float4 loads, 8 / 16-byte stores on both copies (prep_tile moved 4 and 2
 // bytes per thread).  Rows in [rows, Mp) of the transposed copy are written as zeros (the dW contraction runs over them).
 template <typename OutT> struct Out4;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(PrepFused d) {
             z[h] = x[h];
             if (c0 < c_end && row < d.rows && col < d.cols) {   // cols % 4 == 0 (checked by the launcher): whole groups only
                 x[h] = *(const float4*)(d.src + (size_t)row * d.lds + col);
-                if (d.mode == 3) z[h] = *(const float4*)(d.src2 + (size_t)row * d.lds2 + col);
+                if (d.mode == 3 || d.mode == 5) z[h] = *(const float4*)(d.src2 + (size_t)row * d.lds2 + col);
             }
         }
     };
@@ -166,6 +168,25 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(PrepFused d) {
                     const float4 g = *(const float4*)(d.gamma + col);
                     const float m = mean_s[r], rs = rstd_s[r];
                     v[0] = (v[0] - m) * rs * g.x; v[1] = (v[1] - m) * rs * g.y; v[2] = (v[2] - m) * rs * g.z; v[3] = (v[3] - m) * rs * g.w;
+                    if (d.beta) {
+                        const float4 bt = *(const float4*)(d.beta + col);
+                        v[0] += bt.x; v[1] += bt.y; v[2] += bt.z; v[3] += bt.w;
+                    }
+                } else if (d.mode == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = 0.7978845608028654f * (v[e] + 0.044715f * v[e] * v[e] * v[e]);
+                        v[e] = 0.5f * v[e] * (1.0f + tanhf(u));
+                    }
+                } else if (d.mode == 5) {
+                    const float z[4] = {za[h].x, za[h].y, za[h].z, za[h].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {   // d/dz [0.5 z (1 + tanh u)], u = c (z + 0.044715 z^3)
+                        const float u = 0.7978845608028654f * (z[e] + 0.044715f * z[e] * z[e] * z[e]);
+                        const float th = tanhf(u);
+                        const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * z[e] * z[e]);
+                        v[e] *= 0.5f * (1.0f + th) + 0.5f * z[e] * (1.0f - th * th) * du;
+                    }
                 } else if (d.mode == 3) {
                     const float z[4] = {za[h].x, za[h].y, za[h].z, za[h].w};
 #pragma unroll
@@ -797,6 +818,271 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------ VQ-VAE decoder (trainable in
+// the legacy and SLM loops: code/models/stage1_BIWI.py:376-393) and the glue of the legacy generator's loss
+// Conv1d(k = 5, replicate padding) as a GEMM: X5[m][c * 5 + tap] = x[clip(m), clamp(t + tap - 2)][c] -- the column order of the
+// weight's own [out][in][5] layout, so the weight and its gradient are used as they lie in the arena
+__global__ void im2col5_kernel(const float* __restrict__ x, float* __restrict__ x5, int B, int n, int C) {
+    const long total = (long)B * n * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long m = i / C;
+        const int t = (int)(m % n);
+        const long base = m - t;
+#pragma unroll
+        for (int tap = 0; tap < 5; ++tap) {
+            int ts = t + tap - 2;
+            ts = ts < 0 ? 0 : (ts >= n ? n - 1 : ts);
+            x5[(size_t)m * 5 * C + (size_t)c * 5 + tap] = x[(size_t)(base + ts) * C + c];
+        }
+    }
+}
+// its adjoint: dx[t'] = sum over (t, tap) with clamp(t + tap - 2) == t' of dX5[t][c * 5 + tap] (gather form: no atomics)
+__global__ void col2im5_kernel(const float* __restrict__ dx5, float* __restrict__ dx, int B, int n, int C) {
+    const long total = (long)B * n * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long m = i / C;
+        const int tp = (int)(m % n);
+        const long base = m - tp;
+        float a = 0.f;
+        const int lo = tp == 0 ? 0 : tp - 2, hi = tp == n - 1 ? n - 1 : tp + 2;
+        for (int t = (lo < 0 ? 0 : lo); t <= (hi >= n ? n - 1 : hi); ++t)
+#pragma unroll
+            for (int tap = 0; tap < 5; ++tap) {
+                int ts = t + tap - 2;
+                ts = ts < 0 ? 0 : (ts >= n ? n - 1 : ts);
+                if (ts == tp) a += dx5[(size_t)(base + t) * 5 * C + (size_t)c * 5 + tap];
+            }
+        dx[i] = a;
+    }
+}
+// y = InstanceNorm_t(LeakyReLU_0.2(x)) per (clip, channel) over the n frames (biased variance, eps 1e-5, no affine).
+// One thread per channel (rows are channel-contiguous), two passes over time like F.instance_norm.
+__global__ __launch_bounds__(64) void lrelu_inorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C) {
+    const int b = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
+    if (c >= C) return;
+    const float* xp = x + (size_t)b * n * C + c;
+    float sm = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const float v = xp[(size_t)t * C];
+        sm += v > 0.f ? v : 0.2f * v;
+    }
+    const float mean = sm / (float)n;
+    float q = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const float v = xp[(size_t)t * C];
+        const float a = (v > 0.f ? v : 0.2f * v) - mean;
+        q += a * a;
+    }
+    const float rstd = rsqrtf(q / (float)n + 1e-5f);
+    float* yp = y + (size_t)b * n * C + c;
+    for (int t = 0; t < n; ++t) {
+        const float v = xp[(size_t)t * C];
+        yp[(size_t)t * C] = ((v > 0.f ? v : 0.2f * v) - mean) * rstd;
+    }
+}
+// dx = LeakyReLU'(x) * rstd * (dy - mean_t(dy) - yhat * mean_t(dy * yhat))
+__global__ __launch_bounds__(64) void lrelu_inorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int n,
+                                                             int C) {
+    const int b = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
+    if (c >= C) return;
+    const float* xp = x + (size_t)b * n * C + c;
+    const float* gp = dy + (size_t)b * n * C + c;
+    float sm = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const float v = xp[(size_t)t * C];
+        sm += v > 0.f ? v : 0.2f * v;
+    }
+    const float mean = sm / (float)n;
+    float q = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const float v = xp[(size_t)t * C];
+        const float a = (v > 0.f ? v : 0.2f * v) - mean;
+        q += a * a;
+    }
+    const float rstd = rsqrtf(q / (float)n + 1e-5f);
+    float g1 = 0.f, g2 = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const float v = xp[(size_t)t * C], g = gp[(size_t)t * C];
+        const float yh = ((v > 0.f ? v : 0.2f * v) - mean) * rstd;
+        g1 += g;
+        g2 += g * yh;
+    }
+    g1 /= (float)n;
+    g2 /= (float)n;
+    float* dp = dx + (size_t)b * n * C + c;
+    for (int t = 0; t < n; ++t) {
+        const float v = xp[(size_t)t * C], g = gp[(size_t)t * C];
+        const float yh = ((v > 0.f ? v : 0.2f * v) - mean) * rstd;
+        dp[(size_t)t * C] = (v > 0.f ? 1.0f : 0.2f) * rstd * (g - g1 - yh * g2);
+    }
+}
+// y[m, c] = a[m, c] + rows[m / n, c]: the VQ decoder's positional buffer is indexed by the CLIP (pe[:B], the reference's quirk)
+__global__ void add_clip_rows_kernel(const float* __restrict__ a, const float* __restrict__ rows, float* __restrict__ y, int M, int n, int C) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C), c = (int)(i - (long)m * C);
+        y[i] = a[i] + rows[(size_t)(m / n) * C + c];
+    }
+}
+// idx[b, t] = argmax_c logits[b, t + t_off, c] (first maximum), t < n_out; logits rows are [B, n_in, 512].  One wave per row.
+__global__ __launch_bounds__(256) void argmax512_kernel(const float* __restrict__ logits, int32_t* __restrict__ idx, int B, int n_in, int n_out,
+                                                        int t_off) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * n_out) return;
+    const int b = row / n_out, t = row - b * n_out;
+    const float* lr = logits + ((size_t)b * n_in + t + t_off) * 512;
+    float best = -3.4e38f;
+    int bi = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {   // ascending columns per lane: '>' keeps the first maximum
+        const float v = lr[lane + 64 * c];
+        if (v > best) {
+            best = v;
+            bi = lane + 64 * c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) idx[row] = bi;
+}
+// continuous loss of the decoded motion (code/seq2seq.py:270-276): rows (b, t) with mask[b, t + 1]; per selected row
+// n_exp = ||d[6:]||, n_jaw = ||d[:6]||, d = pred - target + 1e-6 (F.pairwise_distance's eps sits inside the norm);
+// loss = mean n_exp + mean n_jaw.  Pass 1: per-row norms and the unscaled gradient d / norm; pass 2 (one block): sums, count.
+__global__ __launch_bounds__(256) void cont_rows_kernel(const float* __restrict__ pred, const float* __restrict__ v_tgt, const uint8_t* __restrict__ mask,
+                                                        int B, int T, int n, float* __restrict__ rown, float* __restrict__ dpred) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * n) return;
+    const int b = row / n, t = row - b * n;
+    const bool sel = mask[(size_t)b * T + t + 1] != 0;
+    float d = 0.f;
+    if (lane < 56 && sel) d = pred[(size_t)row * 56 + lane] - v_tgt[((size_t)b * T + t + 1) * 56 + lane] + 1e-6f;
+    const float s_jaw = wave_sum(lane < 6 ? d * d : 0.f), s_exp = wave_sum(lane >= 6 ? d * d : 0.f);
+    const float n_jaw = sqrtf(s_jaw), n_exp = sqrtf(s_exp);
+    if (lane == 0) {
+        rown[2 * row] = sel ? n_exp : 0.f;
+        rown[2 * row + 1] = sel ? n_jaw : 0.f;
+    }
+    if (lane < 56) {
+        const float nn = lane < 6 ? n_jaw : n_exp;
+        dpred[(size_t)row * 56 + lane] = (sel && nn > 0.f) ? d / nn : 0.f;
+    }
+}
+// out[0] = mean n_exp + mean n_jaw, out[1] = 1 / count
+__global__ __launch_bounds__(256) void cont_finish_kernel(const float* __restrict__ rown, const uint8_t* __restrict__ mask, int B, int T, int n,
+                                                          float* __restrict__ out) {
+    __shared__ float sa[256];
+    __shared__ int sc[256];
+    float a = 0.f;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < B * n; i += 256) {
+        const int b = i / n, t = i - b * n;
+        a += rown[2 * i] + rown[2 * i + 1];
+        cnt += mask[(size_t)b * T + t + 1] ? 1 : 0;
+    }
+    sa[threadIdx.x] = a;
+    sc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sa[threadIdx.x] += sa[threadIdx.x + s];
+            sc[threadIdx.x] += sc[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float inv = 1.0f / (float)(sc[0] > 0 ? sc[0] : 1);
+        out[0] = sa[0] * inv;
+        out[1] = inv;
+    }
+}
+__global__ void scale_by_kernel(float* __restrict__ y, const float* __restrict__ factor, long n) {
+    const float f = *factor;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] *= f;
+}
+// head-padded operand layouts of the VQ attention (8 heads of 48 run on the 64-wide attention kernels as zero-padded heads):
+// dst row g * 64 + j <- src row g * 48 + j (j < 48), zero otherwise; `cols` contiguous columns per row.  unpad: the inverse copy.
+__global__ void pad_head_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int groups, int cols, int unpad) {
+    const long total = (long)groups * 64 * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const int r = (int)(i / cols), g = r >> 6, j = r & 63;
+        if (unpad) {
+            if (j < 48) dst[((size_t)g * 48 + j) * cols + c] = src[i];
+        } else {
+            dst[i] = j < 48 ? src[((size_t)g * 48 + j) * cols + c] : 0.f;
+        }
+    }
+}
+// the same along the columns: dst[r][g * 64 + j] <- src[r][g * 48 + j]
+__global__ void pad_head_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int groups, int unpad) {
+    const long total = (long)rows * groups * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % (groups * 64)), r = (int)(i / (groups * 64));
+        const int g = cc >> 6, j = cc & 63;
+        if (unpad) {
+            if (j < 48) dst[(size_t)r * groups * 48 + g * 48 + j] = src[i];
+        } else {
+            dst[i] = j < 48 ? src[(size_t)r * groups * 48 + g * 48 + j] : 0.f;
+        }
+    }
+}
+// id conditioning (code/seq2seq.py:240-252): e[b] = relu(table[ids[b]]); adjoint: dtable[ids[b]] += de[b] * (table > 0), clips in
+// order (two clips may carry the same id: a fixed order instead of atomics)
+__global__ void emb_relu_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, float* __restrict__ e, int B, int E) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * E; i += gridDim.x * blockDim.x) {
+        const int b = i / E, j = i - b * E;
+        const float v = table[(size_t)ids[b] * E + j];
+        e[i] = v > 0.f ? v : 0.f;
+    }
+}
+__global__ void emb_relu_bwd_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, const float* __restrict__ de,
+                                    float* __restrict__ dtable, int B, int E) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < E; j += gridDim.x * blockDim.x)
+        for (int b = 0; b < B; ++b) {
+            const size_t o = (size_t)ids[b] * E + j;
+            if (table[o] > 0.f) dtable[o] += de[(size_t)b * E + j];
+        }
+}
+// context with the id row in front: ctx[b, 0] = lid[b], ctx[b, 1 + t] = enc[b, t]; mask likewise (1 in front); split: the adjoint
+__global__ void prepend_row_kernel(const float* __restrict__ first, const float* __restrict__ rest, float* __restrict__ out, int B, int T, int C,
+                                   int split) {
+    const long total = (long)B * (T + 1) * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long r = i / C;
+        const int b = (int)(r / (T + 1)), t = (int)(r - (long)b * (T + 1));
+        if (!split) {
+            out[i] = t == 0 ? first[(size_t)b * C + c] : rest[((size_t)b * T + t - 1) * C + c];
+        } else {   // out = the joint gradient (read), first / rest written
+            if (t == 0) ((float*)first)[(size_t)b * C + c] = out[i];
+            else ((float*)rest)[((size_t)b * T + t - 1) * C + c] = out[i];
+        }
+    }
+}
+// z_ext[b] = {-100, z[b, 0..T)}, m_ext[b] = {1, mask[b, 0..T)}
+__global__ void prepend_tokens_kernel(const int32_t* __restrict__ z, const uint8_t* __restrict__ mask, int32_t* __restrict__ z_ext,
+                                      uint8_t* __restrict__ m_ext, int B, int T) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * (T + 1); i += gridDim.x * blockDim.x) {
+        const int b = i / (T + 1), t = i - b * (T + 1);
+        z_ext[i] = t == 0 ? -100 : z[(size_t)b * T + t - 1];
+        m_ext[i] = t == 0 ? 1 : mask[(size_t)b * T + t - 1];
+    }
+}
+// zq[b, t] = codebook[idx[b, t]] (rows of 128 floats)
+__global__ void gather128_kernel(const float* __restrict__ book, const int32_t* __restrict__ idx, float* __restrict__ out, int R) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)R * 128; i += (long)gridDim.x * blockDim.x)
+        out[i] = book[(size_t)idx[i >> 7] * 128 + (i & 127)];
+}
+
 inline int ew_grid(long n) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -846,15 +1132,17 @@ int tr_prep_pair(int out_dtype, const float* src, int lds, int rows, int cols, v
 
 // see prep_fused_kernel.  colpart: [*n_part][cols] partial column sums (n_part = ceil(rows / 32) rows are written), or null
 int tr_prep_fused(int out_dtype, int mode, const float* src, int lds, const float* src2, int lds2, const float* gamma, int rows, int cols,
-                  void* o, int Kp, void* t, int Mp, float* colpart, int* n_part, hipStream_t s) {
-    DIMX_REQUIRE(src && o && t && rows > 0 && cols > 0 && Kp >= cols && Mp >= rows && mode >= 0 && mode <= 3, DIMX_ERR_ARG, "prep_fused: bad arguments");
+                  void* o, int Kp, void* t, int Mp, float* colpart, int* n_part, hipStream_t s, const float* beta) {
+    DIMX_REQUIRE(src && o && t && rows > 0 && cols > 0 && Kp >= cols && Mp >= rows && mode >= 0 && mode <= 5, DIMX_ERR_ARG, "prep_fused: bad arguments");
     DIMX_REQUIRE(cols % 4 == 0 && lds % 4 == 0 && Kp % 4 == 0 && Mp % 32 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)o % 16) == 0 &&
                      ((uintptr_t)t % 16) == 0,
                  DIMX_ERR_ARG, "prep_fused: 16-byte groups (cols=%d lds=%d Kp=%d Mp=%d)", cols, lds, Kp, Mp);
     DIMX_REQUIRE(mode != 2 || (gamma && ((uintptr_t)gamma % 16) == 0), DIMX_ERR_ARG, "prep_fused: LayerNorm mode needs gamma");
-    DIMX_REQUIRE(mode != 3 || (src2 && lds2 % 4 == 0 && ((uintptr_t)src2 % 16) == 0), DIMX_ERR_ARG, "prep_fused: GELU' mode needs the pre-activation");
+    DIMX_REQUIRE((mode != 3 && mode != 5) || (src2 && lds2 % 4 == 0 && ((uintptr_t)src2 % 16) == 0), DIMX_ERR_ARG,
+                 "prep_fused: GELU' mode needs the pre-activation");
+    DIMX_REQUIRE(!beta || (mode == 2 && ((uintptr_t)beta % 16) == 0), DIMX_ERR_ARG, "prep_fused: beta belongs to the LayerNorm mode");
     PrepFused d;
-    d.src = src; d.lds = lds; d.src2 = src2; d.lds2 = lds2; d.gamma = gamma;
+    d.src = src; d.lds = lds; d.src2 = src2; d.lds2 = lds2; d.gamma = gamma; d.beta = beta;
     d.o = o; d.Kp = Kp; d.t = t; d.Mp = Mp; d.rows = rows; d.cols = cols; d.mode = mode; d.colpart = colpart;
     // LayerNorm: the block that owns 32 rows computes their statistics once, so it walks the whole row; otherwise 256-column chunks
     // columns per block: enough blocks to fill the chip (>= ~512) when there are few rows, at most 256 columns (LayerNorm mode: the
@@ -1030,5 +1318,60 @@ int tr_adamw(float* p, const float* g, float* m, float* v, long n, float lr, flo
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
+
+// ---- VQ-VAE decoder / legacy generator glue
+#define EW(kernel, n_, ...)                                                                      \
+    do {                                                                                         \
+        hipLaunchKernelGGL(kernel, dim3(ew_grid((long)(n_))), dim3(256), 0, s, __VA_ARGS__);    \
+        DIMX_HIP(hipGetLastError());                                                             \
+        return DIMX_OK;                                                                          \
+    } while (0)
+int tr_im2col5(const float* x, float* x5, int B, int n, int C, hipStream_t s) { EW(im2col5_kernel, (long)B * n * C, x, x5, B, n, C); }
+int tr_col2im5(const float* dx5, float* dx, int B, int n, int C, hipStream_t s) { EW(col2im5_kernel, (long)B * n * C, dx5, dx, B, n, C); }
+int tr_lrelu_inorm_fwd(const float* x, float* y, int B, int n, int C, hipStream_t s) {
+    hipLaunchKernelGGL(lrelu_inorm_fwd_kernel, dim3(B, ceil_div(C, 64)), dim3(64), 0, s, x, y, n, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_lrelu_inorm_bwd(const float* x, const float* dy, float* dx, int B, int n, int C, hipStream_t s) {
+    hipLaunchKernelGGL(lrelu_inorm_bwd_kernel, dim3(B, ceil_div(C, 64)), dim3(64), 0, s, x, dy, dx, n, C);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_add_clip_rows(const float* a, const float* rows, float* y, int M, int n, int C, hipStream_t s) {
+    EW(add_clip_rows_kernel, (long)M * C, a, rows, y, M, n, C);
+}
+int tr_argmax512(const float* logits, int32_t* idx, int B, int n_in, int n_out, int t_off, hipStream_t s) {
+    hipLaunchKernelGGL(argmax512_kernel, dim3(ceil_div(B * n_out, 4)), dim3(256), 0, s, logits, idx, B, n_in, n_out, t_off);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+// loss_out[0] = continuous loss, loss_out[1] = 1 / selected rows; dpred = d loss / d pred.  rown: 2 * B * n floats of scratch
+int tr_cont_loss(const float* pred, const float* v_tgt, const uint8_t* mask, int B, int T, int n, float* rown, float* dpred, float* loss_out,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(cont_rows_kernel, dim3(ceil_div(B * n, 4)), dim3(256), 0, s, pred, v_tgt, mask, B, T, n, rown, dpred);
+    hipLaunchKernelGGL(cont_finish_kernel, dim3(1), dim3(256), 0, s, rown, mask, B, T, n, loss_out);
+    hipLaunchKernelGGL(scale_by_kernel, dim3(ew_grid((long)B * n * 56)), dim3(256), 0, s, dpred, loss_out + 1, (long)B * n * 56);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+int tr_pad_head_rows(const float* src, float* dst, int groups, int cols, int unpad, hipStream_t s) {
+    EW(pad_head_rows_kernel, (long)groups * 64 * cols, src, dst, groups, cols, unpad);
+}
+int tr_pad_head_cols(const float* src, float* dst, int rows, int groups, int unpad, hipStream_t s) {
+    EW(pad_head_cols_kernel, (long)rows * groups * 64, src, dst, rows, groups, unpad);
+}
+int tr_emb_relu(const float* table, const int32_t* ids, float* e, int B, int E, hipStream_t s) { EW(emb_relu_kernel, (long)B * E, table, ids, e, B, E); }
+int tr_emb_relu_bwd(const float* table, const int32_t* ids, const float* de, float* dtable, int B, int E, hipStream_t s) {
+    EW(emb_relu_bwd_kernel, (long)E, table, ids, de, dtable, B, E);
+}
+int tr_prepend_row(const float* first, const float* rest, float* joint, int B, int T, int C, int split, hipStream_t s) {
+    EW(prepend_row_kernel, (long)B * (T + 1) * C, first, rest, joint, B, T, C, split);
+}
+int tr_prepend_tokens(const int32_t* z, const uint8_t* mask, int32_t* z_ext, uint8_t* m_ext, int B, int T, hipStream_t s) {
+    EW(prepend_tokens_kernel, (long)B * (T + 1), z, mask, z_ext, m_ext, B, T);
+}
+int tr_gather128(const float* book, const int32_t* idx, float* out, int R, hipStream_t s) { EW(gather128_kernel, (long)R * 128, book, idx, out, R); }
+#undef EW
 
 }  // namespace dimx

@@ -216,3 +216,51 @@ class HipTrainer:
             pred = self.model.forward_vq_decoder(logits, mode="train")
             l_cont = self.model.forward_continuous_loss(pred, v_listener.to(self.device), mask.bool().to(self.device))
         return l_ce + l_cont, {"l_ce_s": 0, "l_ce_l": l_ce, "l_cont_s": 0, "l_cont_l": l_cont, "nce": 0, "c_acc": 0}
+
+
+class LegacyHipTrainer(HipTrainer):
+    """The legacy ListenerGenerator's training step on the HIP kernels (reference loop code/x_engine.py:8-36):
+    the generator (bidirectional encoder, decoder with absolute positions), the listener-id conditioning and the listener
+    VQ-VAE's DECODER train; the frozen halves (speaker features, listener codes) come from the engine without a graph.  Same
+    flat arenas, clip + AdamW and gradient all-reduce as HipTrainer; ``dimx.train.legacy_loss`` (PyTorch autograd) is its checker
+    (tests/test_gpu_train_legacy.py)."""
+
+    def forward_backward(self, v_speaker, v_listener, mask, listener_ids=None, return_logits=False):
+        """-> (total loss = cross entropy + continuous loss, dict, pred [B,T-1,56][, logits]); gradients in ``self.grads``."""
+        m = self.model
+        mask = mask.bool()
+        B, T = mask.shape
+        with torch.no_grad():
+            eng, xs, xl, lens, m8 = m._prepare(v_speaker, v_listener, mask)
+            z_l = eng.vq_encode(1, xl, lens, pe_mode=0, pad_value=-100).to(torch.int32).contiguous()
+            x_speaker = eng.legacy_speaker_features(xs, m8).float().contiguous().clone()
+        v_l = v_listener.to(self.device, torch.float32).contiguous()
+        ids = listener_ids.to(self.device, torch.int32).contiguous() if listener_ids is not None else None
+        book = m.listener_vq.quantize.embedding.weight.detach().to(self.device, torch.float32).contiguous()
+        pe = m.listener_vq.decoder.decoder_pos_embedding.pe.detach().to(self.device, torch.float32).contiguous()
+        nd = T if ids is not None else T - 1
+        pred = torch.empty(B, T - 1, 56, dtype=torch.float32, device=self.device)
+        logits = torch.empty(B, nd, 512, dtype=torch.float32, device=self.device) if return_logits else None
+        need = int(self.lib.dimx_train_legacy_workspace_bytes(self.eng.h, B, T))
+        if need == 0:
+            raise L.DimxError("dimx_train_legacy_workspace_bytes(B=%d, T=%d) = 0: %s" % (B, T, (self.lib.dimx_last_error() or b"").decode()))
+        if need > self._ws_bytes:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        ws = ctypes.c_void_p((self._ws.data_ptr() + 255) // 256 * 256)
+        if self._loss.numel() < 4:
+            self._loss = torch.zeros(4, dtype=torch.float32, device=self.device)
+        L.check(self.lib.dimx_train_legacy_forward_backward(
+            self.eng.h, L.ptr(self.params), L.ptr(self.grads), L.ptr(x_speaker), L.ptr(z_l), L.ptr(v_l), L.ptr(m8), L.ptr(ids), L.ptr(book),
+            L.ptr(pe), B, T, L.ptr(self._loss), L.ptr(pred), L.ptr(logits), ws, self._ws.numel() - 256, L.stream_ptr(self.device)),
+            "dimx_train_legacy_forward_backward")
+        l_ce, l_cont = self._loss[0].clone(), self._loss[2].clone()
+        out = (l_ce + l_cont, {"l_ce": l_ce, "l_cont": l_cont}, pred)
+        return out + (logits,) if return_logits else out
+
+    def train_step(self, v_speaker, v_listener, mask, listener_ids=None):
+        """one optimisation step of the reference loop's body; returns (loss, pred) like ``model(src, tgt, mask, listener_ids=...)``."""
+        loss, _, pred = self.forward_backward(v_speaker, v_listener, mask, listener_ids=listener_ids)
+        self.all_reduce_grads()
+        self.step()
+        return loss, pred

@@ -233,6 +233,20 @@ int dimx_train_forward_backward(dimx_handle h, const float* params, float* grads
  * weight-gradient GEMMs on a side stream (the faster choice there: csrc/train.hip).  DIMX_TRAIN_GRAPH=0|1 / DIMX_TRAIN_SIDE=0|1
  * force either; results are bit-identical in every combination. */
 int dimx_train_graph_stats(dimx_handle h, int64_t* out3);
+/* The legacy generator's training step (reference loop code/x_engine.py:8-36 over ListenerGenerator.forward,
+ * code/seq2seq.py:235-278): handle of variant 1.  The arenas follow dimx_train_param_info of that handle: generator.*, the
+ * listener VQ-VAE's DECODER (listener_vq.decoder.*) and the listener-id conditioning (listener_embeddings.weight [100,256],
+ * fc_listener.*) -- what the reference trains on this call (code/seq2seq.py:165-176; speaker_ids is None in the loop).
+ * x_speaker [B,T,1024]: features of the frozen speaker VQ-VAE (dimx_legacy_speaker_features); z_l [B,T] listener codes, -100 on
+ * padding; v_listener [B,T,56]; mask [B,T]; listener_ids [B] int32 or NULL; codebook [512,128] and pe [>=B rows of 384] are the
+ * listener VQ-VAE's frozen codebook and its decoder's positional buffer (device pointers of the module's tensors).
+ * loss_out: 4 device floats {cross entropy, 1 / valid targets, continuous loss, 1 / selected rows}; pred_out optional
+ * [B,T-1,56]; logits_out optional [B,T (with ids) or T-1,512]. */
+size_t dimx_train_legacy_workspace_bytes(dimx_handle h, int B, int T);
+int dimx_train_legacy_forward_backward(dimx_handle h, const float* params, float* grads, const float* x_speaker, const int32_t* z_l,
+                                       const float* v_listener, const uint8_t* mask, const int32_t* listener_ids, const float* codebook,
+                                       const float* pe, int B, int T, float* loss_out, float* pred_out, float* logits_out, void* ws,
+                                       size_t ws_bytes, void* stream);
 /* Gradient clipping (torch.nn.utils.clip_grad_norm_, max_norm <= 0: none) + one torch.optim.AdamW step over a flat arena.
  * step: 1-based step count (bias correction).  scratch: >= 1026 device floats; scratch[1024] = gradient norm before clipping,
  * scratch[1025] = the clip coefficient applied. */
