@@ -148,6 +148,83 @@ int build_plan(dimx_handle h, TrainPlan& p) {
         DIMX_TRY(add_free("fc_listener.bias", 1, d.dim));
         return DIMX_OK;
     }
+    if (d.variant == 2) {
+        // SLM pre-training (code/seq2seq_pretrain.py:98-113): everything but the VQ-VAEs' encoders and codebooks trains -- the three
+        // encoders, the decoder with its absolute positional table, the stream norms / patch embeddings and BOTH VQ-VAE decoders
+        // (project_out of the encoders is never called: no gradient, not in the arena)
+        const int DD2 = d.dim + d.dim_a, H = d.vq_hidden, I = d.vq_inter;
+        for (const char* n : {"patch_embed_s", "patch_embed_l"}) DIMX_TRY(add(n, 1, d.dim_in));
+        for (const char* n : {"patch_embed_dec_s", "patch_embed_dec_l", "norm_s.weight", "norm_s.bias", "norm_l.weight", "norm_l.bias", "norm.weight",
+                              "norm.bias"})
+            DIMX_TRY(add(n, 1, d.dim));
+        for (const char* enc : {"encoder_s.", "encoder_l.", "encoder_joint."}) {
+            const std::string e(enc);
+            DIMX_TRY(add(e + "project_in.weight", d.dim, e == "encoder_joint." ? d.dim : d.dim_in));
+            DIMX_TRY(add(e + "pos_emb.emb.weight", d.max_seq_len, d.dim));
+            for (int i = 0; i < d.enc_depth; ++i) {
+                const std::string la = e + "attn_layers.layers." + std::to_string(2 * i) + ".";
+                const std::string lf = e + "attn_layers.layers." + std::to_string(2 * i + 1) + ".";
+                DIMX_TRY(add(la + "0.0.weight", 1, d.dim));
+                DIMX_TRY(add(la + "1.to_q.weight", inner, d.dim));
+                DIMX_TRY(add(la + "1.to_k.weight", inner, d.dim));
+                DIMX_TRY(add(la + "1.to_v.weight", inner, d.dim));
+                DIMX_TRY(add(la + "1.to_out.weight", d.dim, inner));
+                DIMX_TRY(add(lf + "0.0.weight", 1, d.dim));
+                DIMX_TRY(add(lf + "1.ff.0.0.weight", d.dim * d.ff_mult, d.dim));
+                DIMX_TRY(add(lf + "1.ff.0.0.bias", 1, d.dim * d.ff_mult));
+                DIMX_TRY(add(lf + "1.ff.2.weight", d.dim, d.dim * d.ff_mult));
+                DIMX_TRY(add(lf + "1.ff.2.bias", 1, d.dim));
+            }
+            DIMX_TRY(add(e + "attn_layers.final_norm.weight", 1, d.dim));
+        }
+        const std::string dn = "decoder_joint.net.";
+        DIMX_TRY(add(dn + "token_emb.emb.weight", d.num_tokens, DD2));
+        DIMX_TRY(add(dn + "pos_emb.emb.weight", d.max_seq_len, DD2));
+        for (int i = 0; i < d.dec_depth; ++i) {
+            for (int k = 0; k < 2; ++k) {
+                const std::string la = dn + "attn_layers.layers." + std::to_string(3 * i + k) + ".";
+                DIMX_TRY(add(la + "0.0.weight", 1, DD2));
+                DIMX_TRY(add(la + "1.to_q.weight", inner, DD2));
+                DIMX_TRY(add(la + "1.to_k.weight", inner, DD2));
+                DIMX_TRY(add(la + "1.to_v.weight", inner, DD2));
+                DIMX_TRY(add(la + "1.to_out.weight", DD2, inner));
+            }
+            const std::string lf = dn + "attn_layers.layers." + std::to_string(3 * i + 2) + ".";
+            DIMX_TRY(add(lf + "0.0.weight", 1, DD2));
+            DIMX_TRY(add(lf + "1.ff.0.0.weight", DD2 * d.ff_mult, DD2));
+            DIMX_TRY(add(lf + "1.ff.0.0.bias", 1, DD2 * d.ff_mult));
+            DIMX_TRY(add(lf + "1.ff.2.weight", DD2, DD2 * d.ff_mult));
+            DIMX_TRY(add(lf + "1.ff.2.bias", 1, DD2));
+        }
+        DIMX_TRY(add(dn + "attn_layers.final_norm.weight", 1, DD2));
+        DIMX_TRY(add(dn + "to_logits.weight", d.num_tokens, DD2));
+        for (const char* vq : {"speaker_vq.decoder.", "listener_vq.decoder."}) {
+            const std::string c(vq);
+            DIMX_TRY(add(c + "decoder_linear_embedding_pre.net.weight", H, d.vq_zdim));
+            DIMX_TRY(add(c + "decoder_linear_embedding_pre.net.bias", 1, H));
+            DIMX_TRY(add(c + "expander.0.0.weight", H, 5 * H));
+            DIMX_TRY(add(c + "expander.0.0.bias", 1, H));
+            DIMX_TRY(add(c + "decoder_linear_embedding.net.weight", H, H));
+            DIMX_TRY(add(c + "decoder_linear_embedding.net.bias", 1, H));
+            for (int i = 0; i < d.vq_layers; ++i) {
+                const std::string a = c + "decoder_transformer.net." + std::to_string(2 * i) + ".fn.";
+                const std::string m = c + "decoder_transformer.net." + std::to_string(2 * i + 1) + ".fn.";
+                DIMX_TRY(add(a + "norm.weight", 1, H));
+                DIMX_TRY(add(a + "norm.bias", 1, H));
+                DIMX_TRY(add(a + "fn.to_qkv.weight", 3 * H, H));
+                DIMX_TRY(add(a + "fn.to_out.weight", H, H));
+                DIMX_TRY(add(a + "fn.to_out.bias", 1, H));
+                DIMX_TRY(add(m + "norm.weight", 1, H));
+                DIMX_TRY(add(m + "norm.bias", 1, H));
+                DIMX_TRY(add(m + "fn.l1.weight", I, H));
+                DIMX_TRY(add(m + "fn.l1.bias", 1, I));
+                DIMX_TRY(add(m + "fn.l2.weight", H, I));
+                DIMX_TRY(add(m + "fn.l2.bias", 1, H));
+            }
+            DIMX_TRY(add(c + "vertice_map_reverse.weight", d.vq_in_dim, H));
+        }
+        return DIMX_OK;
+    }
     DIMX_TRY(add("patch_embed_s", 1, d.dim_in));
     DIMX_TRY(add("patch_embed_dec_s", 1, d.dim));
     DIMX_TRY(add("norm_s.weight", 1, d.dim));
@@ -508,8 +585,15 @@ int lin_bwd(Step& s, const Lin& l, const float* x, int ldx, const float* dy, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------- sublayers
+// a self-attention sublayer over rows that hold several batches of different lengths (the joint encoder of SLM runs [B, 2T] and
+// [2B, T] through the same weights): every row-wise operator sees all rows at once, the attention runs once per segment
+struct AttnSeg {
+    int row0, B, L;
+    const uint8_t* kmask;   // [B, L] keep-mask of the segment's keys
+};
 struct AttnSave {
     std::string pre;      // "...layers.N." prefix
+    std::vector<AttnSeg> segs;
     // round 4: to_q / to_k / to_v are consecutive [inner, C] tensors of the flat arenas, so the projections are ONE Linear with
     // 3 inner rows for self-attention (one forward GEMM, one dX GEMM over K = 3 inner, one dW GEMM, one operand copy of the
     // joint gradient) and q + a joint k / v Linear for cross-attention (their inputs differ)
@@ -586,7 +670,7 @@ int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C
         a.ldkv = 2 * inner;
     }
     a.ob = s.f32((size_t)M * inner);
-    a.lse = s.f32((size_t)shape.B * shape.H * shape.Lq);
+    a.lse = s.f32(a.segs.empty() ? (size_t)shape.B * shape.H * shape.Lq : (size_t)shape.H * M);
     a.src = cross ? ctx : a.y;
     a.shape = shape;
     a.shape.ldq = a.ldq;
@@ -603,7 +687,18 @@ int attn_fwd(Step& s, AttnSave& a, const float* h_in, float* h_out, int M, int C
         DIMX_TRY(lin_fwd(s, a.q, a.y, C, M, a.qb, inner, nullptr, 0, 2, h_in, s.p(a.pre + "0.0.weight")));
         DIMX_TRY(lin_fwd(s, a.kv, a.src, a.Ck, a.Mk, a.kb, 2 * inner));
     }
-    TR(tr_attn_fwd(a.shape, a.qb, a.kb, a.vb, a.ob, a.lse, s.st));
+    if (a.segs.empty()) {
+        TR(tr_attn_fwd(a.shape, a.qb, a.kb, a.vb, a.ob, a.lse, s.st));
+    } else {
+        size_t lse_off = 0;
+        for (const AttnSeg& g : a.segs) {
+            TrAttn t = a.shape;
+            t.B = g.B; t.Lq = t.Lk = g.L; t.kmask = g.kmask;
+            TR(tr_attn_fwd(t, a.qb + (size_t)g.row0 * a.ldq, a.kb + (size_t)g.row0 * a.ldkv, a.vb + (size_t)g.row0 * a.ldkv,
+                           a.ob + (size_t)g.row0 * inner, a.lse + lse_off, s.st));
+            lse_off += (size_t)g.B * t.H * g.L;
+        }
+    }
     // encoders: to_out(o) with the padded query rows zero-filled, then the residual.  to_out has no bias, so zero rows of o give
     // zero rows of to_out(o): the attention output's padded rows are zeroed in place and the projection keeps its residual epilogue
     // (before round 4: projection into a temporary, zero_rows, copy, add)
@@ -631,8 +726,20 @@ int attn_bwd(Step& s, AttnSave& a, float* dh, float* dctx) {
         dk = s.f32((size_t)a.Mk * 2 * inner);
         dv = dk + inner;
     }
-    float* delta = s.f32((size_t)a.shape.B * a.shape.H * a.shape.Lq);
-    TR(tr_attn_bwd(a.shape, a.qb, a.kb, a.vb, a.ob, d_o, a.lse, delta, dq, a.ldq, dk, a.ldkv, dv, a.ldkv, s.st));
+    float* delta = s.f32(a.segs.empty() ? (size_t)a.shape.B * a.shape.H * a.shape.Lq : (size_t)a.shape.H * M);
+    if (a.segs.empty()) {
+        TR(tr_attn_bwd(a.shape, a.qb, a.kb, a.vb, a.ob, d_o, a.lse, delta, dq, a.ldq, dk, a.ldkv, dv, a.ldkv, s.st));
+    } else {
+        size_t lse_off = 0;
+        for (const AttnSeg& g : a.segs) {
+            TrAttn t = a.shape;
+            t.B = g.B; t.Lq = t.Lk = g.L; t.kmask = g.kmask;
+            const size_t rq = (size_t)g.row0 * a.ldq, rk = (size_t)g.row0 * a.ldkv, ro = (size_t)g.row0 * inner;
+            TR(tr_attn_bwd(t, a.qb + rq, a.kb + rk, a.vb + rk, a.ob + ro, d_o + ro, a.lse + lse_off, delta + lse_off, dq + rq, a.ldq, dk + rk,
+                           a.ldkv, dv + rk, a.ldkv, s.st));
+            lse_off += (size_t)g.B * t.H * g.L;
+        }
+    }
     float* dy = s.f32((size_t)M * C);
     if (!a.cross) {
         DIMX_TRY(lin_bwd(s, a.qkv, a.y, C, dq, 3 * inner, M, dy, C, false));
@@ -684,12 +791,25 @@ struct EncSave {
     std::vector<FFSave> ff;
     std::vector<float*> h;  // residual stream after every sublayer (h[0] = after project_in + pos)
     float* out;             // final norm output
+    int M;                  // rows
+    std::vector<AttnSeg> segs;   // empty: one [s.B, s.T] batch
 };
 
 int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int Cin, const uint8_t* mask_rows, const uint8_t* mask_bt,
-            int causal = 1) {
+            int causal = 1, const std::vector<AttnSeg>* segs = nullptr) {
     const dimx_dims& d = s.h->d;
-    const int M = s.M, C = d.dim;
+    const int C = d.dim;
+    int M = s.M;
+    e.segs.clear();
+    if (segs) {
+        e.segs = *segs;
+        M = 0;
+        for (const AttnSeg& g : e.segs) {
+            DIMX_REQUIRE(g.row0 == M, DIMX_ERR_STATE, "train: encoder segments must tile the rows in order");
+            M += g.B * g.L;
+        }
+    }
+    e.M = M;
     e.pre = pre;
     e.x_in = x_in;
     e.Cin = Cin;
@@ -710,7 +830,13 @@ int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int 
         const size_t mark = s.ar->off;
         float* t = s.f32((size_t)M * C);
         DIMX_TRY(lin_fwd(s, e.pin, x_in, Cin, M, t, C));
-        TR(tr_add_rows(t, C, nullptr, s.p(pre + "pos_emb.emb.weight"), 1.0f / sqrtf((float)C), s.T, e.h[0], C, M, C, s.st));
+        if (e.segs.empty()) {
+            TR(tr_add_rows(t, C, nullptr, s.p(pre + "pos_emb.emb.weight"), 1.0f / sqrtf((float)C), s.T, e.h[0], C, M, C, s.st));
+        } else {
+            for (const AttnSeg& g : e.segs)
+                TR(tr_add_rows(t + (size_t)g.row0 * C, C, nullptr, s.p(pre + "pos_emb.emb.weight"), 1.0f / sqrtf((float)C), g.L,
+                               e.h[0] + (size_t)g.row0 * C, C, g.B * g.L, C, s.st));
+        }
         s.ar->off = mark;
     }
     TrAttn sh;
@@ -720,6 +846,7 @@ int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int 
     sh.causal = causal;
     sh.kmask = mask_bt;
     for (int i = 0; i < d.enc_depth; ++i) {
+        e.attn[i].segs = e.segs;
         DIMX_TRY(attn_fwd(s, e.attn[i], e.h[2 * i], e.h[2 * i + 1], M, C, false, nullptr, 0, 0, sh, mask_rows));
         DIMX_TRY(ff_fwd(s, e.ff[i], e.h[2 * i + 1], e.h[2 * i + 2], M, C));
     }
@@ -730,7 +857,7 @@ int enc_fwd(Step& s, EncSave& e, const std::string& pre, const float* x_in, int 
 // d_out: gradient wrt the encoder output [M, C]; dx_in (optional): gradient wrt its input [M, Cin]
 int enc_bwd(Step& s, EncSave& e, const float* d_out, float* dx_in) {
     const dimx_dims& d = s.h->d;
-    const int M = s.M, C = d.dim;
+    const int M = e.M, C = d.dim;
     const size_t mark = s.ar->off;
     float* dh = s.f32((size_t)M * C);
     DIMX_TRY(ln_bwd_full(s, e.h[2 * d.enc_depth], e.pre + "attn_layers.final_norm.weight", "", d_out, dh, M, C));
@@ -739,7 +866,13 @@ int enc_bwd(Step& s, EncSave& e, const float* d_out, float* dx_in) {
         DIMX_TRY(attn_bwd(s, e.attn[i], dh, nullptr));
     }
     // h0 = project_in(x) + pos[:T] * C^-0.5.  Rows beyond T of the table get no gradient (the caller zeroed G).
-    TR(tr_pos_grad(dh, s.g(e.pre + "pos_emb.emb.weight"), s.B, s.T, C, 1.0f / sqrtf((float)C), s.st));
+    if (e.segs.empty()) {
+        TR(tr_pos_grad(dh, s.g(e.pre + "pos_emb.emb.weight"), s.B, s.T, C, 1.0f / sqrtf((float)C), s.st));
+    } else {   // the segments share the table (zeroed with the arena at the start of the step): each adds its rows, in stream order
+        for (const AttnSeg& g : e.segs) {
+            TR(tr_pos_grad(dh + (size_t)g.row0 * C, s.g(e.pre + "pos_emb.emb.weight"), g.B, g.L, C, 1.0f / sqrtf((float)C), s.st, 1));
+        }
+    }
     DIMX_TRY(lin_bwd(s, e.pin, e.x_in, e.Cin, dh, C, M, dx_in, e.Cin, false));
     s.ar->off = mark;
     return DIMX_OK;
@@ -1334,6 +1467,205 @@ int dimx_train_legacy_forward_backward(dimx_handle h, const float* params, float
     }
     return legacy_run(h, params, grads, x_speaker, z_l, v_listener, mask, listener_ids, codebook, pe, B, T, loss_out, pred_out, logits_out, ws,
                       ws_bytes, (hipStream_t)stream, nullptr, side);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- SLM pre-training
+// One forward + backward pass of SLM.forward (code/seq2seq_pretrain.py:300-323) as the reference's pre-training loop differentiates it
+// (code/train_s2s_pretrain.py:41-64 -> x_engine_pt.train_epoch): masked speaker / listener streams through encoder_s / encoder_l
+// (bidirectional), encoder_joint over the 2T concatenation AND over each stream alone (:200-221 -- one pass over 4 B T rows here:
+// every Linear / LayerNorm / feed-forward sees all rows, the attention runs per segment [B, 2T] and [2B, T], so each weight is used
+// once and its gradient is ONE GEMM), InfoNCE between the clip means (:270-289), the decoder twice (z_s from the listener half of
+// x_joint, z_l from the speaker half, :223-243 -- one pass over a batch of 2 B), two cross entropies, and the continuous losses of
+// the decoded arg-max codes through BOTH VQ-VAE decoders, which they train.
+static int slm_run(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_listener, const float* v_audio,
+                   const uint8_t* mask, const uint8_t* mask_speaker, const uint8_t* mask_listener, const int32_t* z_s, const int32_t* z_l,
+                   const float* codebook_s, const float* codebook_l, const float* pe_s, const float* pe_l, int B, int T, float* loss_out, void* ws,
+                   size_t ws_bytes, hipStream_t st, size_t* need, bool use_side) {
+    int rc;
+    TrainState* ts = state_of(h, &rc);
+    if (!ts) return rc;
+    TrainPlan* plan = &ts->plan;
+    const dimx_dims& d = h->d;
+    DIMX_REQUIRE(h->variant == 2, DIMX_ERR_ARG, "train_slm: the handle is not the SLM variant");
+    DIMX_REQUIRE(B >= 1 && T >= 2 && 2 * T <= d.max_seq_len, DIMX_ERR_ARG, "train_slm: B=%d T=%d out of range (2 T <= %d)", B, T, d.max_seq_len);
+    DIMX_REQUIRE(d.num_tokens == 512 && d.vq_in_dim == 56 && d.dim_in == 56, DIMX_ERR_ARG, "train_slm: 512 codes, 56 coefficients");
+    Arena ar(ws, ws_bytes);
+    Step s;
+    s.h = h; s.plan = plan; s.P = params; s.G = grads; s.ar = &ar; s.st = st;
+    s.at = h->at;
+    s.bk = h->at == DIMX_BF16 ? 64 : 32;
+    s.B = B; s.T = T; s.M = B * T;
+    s.n = T - 1;
+    s.Md = B * (T - 1);
+    s.prep.n = 0;
+    s.prep.total_tiles = 0;
+    const int C = d.dim, DD = d.dim + d.dim_a, F = std::max(DD * d.ff_mult, d.vq_inter), inner = d.heads * d.dim_head, n = T - 1;
+    const int BT = B * T, rows_max = 4 * BT;
+    s.part = s.f32((size_t)2 * kTrSlabs * F);
+    s.ts = ts;
+    s.use_side = use_side;
+    if (use_side) {
+        const size_t slot = (size_t)std::max(F, 3 * inner) * pad_to(rows_max, s.bk) * s.es();
+        for (int i = 0; i < kSideSlots; ++i) s.slot_buf[i] = s.take(slot);
+        if (ws != nullptr) DIMX_TRY(side_ready(*ts));
+    }
+    {   // partial rows of the deferred column reductions
+        const size_t n_ln_c = (size_t)(3 * (2 * d.enc_depth + 1) + 6 + 2 * 4 * d.vq_layers + 8), n_ln_dd = (size_t)(3 * d.dec_depth + 2);
+        const size_t n_b = (size_t)(3 * 2 * d.enc_depth + 2 * d.dec_depth + 2 * 3 * d.vq_layers + 16);
+        s.pool_cap = n_ln_c * (kLnBlocks + 4) * (size_t)std::max(C, d.vq_hidden) + n_ln_dd * (kLnBlocks + 4) * (size_t)DD +
+                     n_b * (size_t)std::max(kTrSlabs, ceil_div(rows_max, 32) + 1) * (size_t)F + 4096;
+        s.pool = s.f32(s.pool_cap);
+        s.pool_off = 0;
+        s.fin.n = 0;
+        s.fin.total_blocks = 0;
+    }
+    const bool live = ws != nullptr;
+    if (live) DIMX_HIP(hipMemsetAsync(grads, 0, (size_t)plan->total * sizeof(float), st));
+
+    // ---------------- masks: keep-masks of the masked-out input rows, the joint encoder's key masks
+    uint8_t* keep_s = (uint8_t*)s.take((size_t)BT);
+    uint8_t* keep_l = (uint8_t*)s.take((size_t)BT);
+    uint8_t* mj = (uint8_t*)s.take((size_t)4 * BT);   // [B, 2T] = cat(mask, mask) along time | [2B, T] = mask twice
+    TR(tr_copy_bt_u8(mask_speaker, T, keep_s, T, B, T, 1, st));
+    TR(tr_copy_bt_u8(mask_listener, T, keep_l, T, B, T, 1, st));
+    TR(tr_copy_bt_u8(mask, T, mj, 2 * T, B, T, 0, st));
+    TR(tr_copy_bt_u8(mask, T, mj + T, 2 * T, B, T, 0, st));
+    TR(tr_copy_bt_u8(mask, T, mj + 2 * BT, T, B, T, 0, st));
+    TR(tr_copy_bt_u8(mask, T, mj + 3 * BT, T, B, T, 0, st));
+    // ---------------- stream encoders on (v + patch_embed) with the masked-out frames zeroed
+    float* x0s = s.f32((size_t)BT * d.dim_in);
+    float* x0l = s.f32((size_t)BT * d.dim_in);
+    TR(tr_add_rows(v_speaker, d.dim_in, s.p("patch_embed_s"), nullptr, 0.f, T, x0s, d.dim_in, BT, d.dim_in, st));
+    TR(tr_zero_rows(x0s, keep_s, BT, d.dim_in, st));
+    TR(tr_add_rows(v_listener, d.dim_in, s.p("patch_embed_l"), nullptr, 0.f, T, x0l, d.dim_in, BT, d.dim_in, st));
+    TR(tr_zero_rows(x0l, keep_l, BT, d.dim_in, st));
+    EncSave es, el, ej;
+    DIMX_TRY(enc_fwd(s, es, "encoder_s.", x0s, d.dim_in, mask, mask, 0));
+    DIMX_TRY(enc_fwd(s, el, "encoder_l.", x0l, d.dim_in, mask, mask, 0));
+    // ---------------- joint encoder: rows [0, 2BT) = cat(x_s, x_l) along time, [2BT, 3BT) = x_s, [3BT, 4BT) = x_l
+    float* xin = s.f32((size_t)4 * BT * C);
+    TR(tr_copy_bt(es.out, (long)T * C, C, xin, (long)2 * T * C, C, B, T, C, nullptr, 0, st));
+    TR(tr_copy_bt(el.out, (long)T * C, C, xin + (size_t)T * C, (long)2 * T * C, C, B, T, C, nullptr, 0, st));
+    TR(tr_copy_cols(es.out, C, xin + (size_t)2 * BT * C, C, BT, C, 0, st));
+    TR(tr_copy_cols(el.out, C, xin + (size_t)3 * BT * C, C, BT, C, 0, st));
+    const std::vector<AttnSeg> segs = {{0, B, 2 * T, mj}, {2 * BT, 2 * B, T, mj + 2 * BT}};
+    DIMX_TRY(enc_fwd(s, ej, "encoder_joint.", xin, C, mj, mj, 0, &segs));
+    float* xn = s.f32((size_t)4 * BT * C);   // norm(x_joint) | norm_s(x_s) | norm_l(x_l)
+    TR(launch_layernorm(DIMX_F32, ej.out, xn, s.p("norm.weight"), s.p("norm.bias"), 2 * BT, C, st));
+    TR(launch_layernorm(DIMX_F32, ej.out + (size_t)2 * BT * C, xn + (size_t)2 * BT * C, s.p("norm_s.weight"), s.p("norm_s.bias"), BT, C, st));
+    TR(launch_layernorm(DIMX_F32, ej.out + (size_t)3 * BT * C, xn + (size_t)3 * BT * C, s.p("norm_l.weight"), s.p("norm_l.bias"), BT, C, st));
+    // ---------------- InfoNCE (forward and adjoint: the whole thing is a few [B, C] reductions)
+    float* d_xn = s.f32((size_t)4 * BT * C);
+    float* nce_scr = s.f32(tr_nce_scratch_floats(B, C));
+    TR(tr_nce(xn + (size_t)2 * BT * C, xn + (size_t)3 * BT * C, mask, B, T, C, nce_scr, loss_out ? loss_out + 8 : nullptr, d_xn + (size_t)2 * BT * C,
+              d_xn + (size_t)3 * BT * C, st));
+    // ---------------- decoder over 2B sequences: rows [0, B) predict z_s from the LISTENER half of x_joint, rows [B, 2B) z_l from the speaker half
+    float* ctx = s.f32((size_t)2 * BT * DD);
+    TR(tr_copy_bt(xn + (size_t)T * C, (long)2 * T * C, C, ctx, (long)T * DD, DD, B, T, C, s.p("patch_embed_dec_l"), 0, st));
+    TR(tr_copy_bt(xn, (long)2 * T * C, C, ctx + (size_t)BT * DD, (long)T * DD, DD, B, T, C, s.p("patch_embed_dec_s"), 0, st));
+    TR(tr_copy_cols(v_audio, d.dim_a, ctx + C, DD, BT, d.dim_a, 0, st));
+    TR(tr_copy_cols(v_audio, d.dim_a, ctx + (size_t)BT * DD + C, DD, BT, d.dim_a, 0, st));
+    int32_t* zc = (int32_t*)s.take((size_t)2 * BT * 4);
+    TR(tr_mask_tokens(z_s, mask_speaker, zc, (long)BT, st));
+    TR(tr_mask_tokens(z_l, mask_listener, zc + BT, (long)BT, st));
+    int32_t* inp = (int32_t*)s.take((size_t)2 * B * n * 4);
+    int32_t* tgt = (int32_t*)s.take((size_t)2 * B * n * 4);
+    TR(launch_shift_tokens(zc, inp, tgt, 2 * B, T, st));
+    DecSave D;
+    DIMX_TRY(dec_prepare(s, D, "decoder_joint.net.", d.dec_depth));
+    DIMX_TRY(flush_prep(s));
+    float* logits = s.f32((size_t)2 * B * n * d.num_tokens);
+    DIMX_TRY(dec_fwd(s, D, inp, 2 * B, n, ctx, T, DD, mj + 2 * BT, nullptr, true, logits));
+    float* dlogits = s.f32((size_t)2 * B * n * d.num_tokens);
+    float* row_loss = s.f32((size_t)2 * B * n);
+    const size_t half = (size_t)B * n;
+    TR(tr_cross_entropy(logits, tgt, row_loss, dlogits, B * n, loss_out, st));
+    TR(tr_cross_entropy(logits + half * d.num_tokens, tgt + half, row_loss + half, dlogits + half * d.num_tokens, B * n, loss_out ? loss_out + 2 : nullptr, st));
+    // ---------------- decoded arg-max codes -> continuous losses over the masked-out frames, through the two VQ-VAE decoders
+    int32_t* idx = (int32_t*)s.take((size_t)2 * B * n * 4);
+    TR(tr_argmax512(logits, idx, 2 * B, n, n, 0, st));
+    float* pred_s = s.f32((size_t)B * n * d.vq_in_dim);
+    float* pred_l = s.f32((size_t)B * n * d.vq_in_dim);
+    VqDecSave Vs, Vl;
+    DIMX_TRY(vqdec_fwd(s, Vs, "speaker_vq.decoder.", idx, codebook_s, pe_s, B, n, pred_s));
+    DIMX_TRY(vqdec_fwd(s, Vl, "listener_vq.decoder.", idx + half, codebook_l, pe_l, B, n, pred_l));
+    float* rown = s.f32((size_t)2 * B * n);
+    float* dpred_s = s.f32((size_t)B * n * d.vq_in_dim);
+    float* dpred_l = s.f32((size_t)B * n * d.vq_in_dim);
+    TR(tr_cont_loss(pred_s, v_speaker, mask_speaker, B, T, n, rown, dpred_s, loss_out ? loss_out + 4 : nullptr, st));
+    TR(tr_cont_loss(pred_l, v_listener, mask_listener, B, T, n, rown, dpred_l, loss_out ? loss_out + 6 : nullptr, st));
+
+    // ---------------- backward
+    DIMX_TRY(vqdec_bwd(s, Vs, dpred_s));
+    DIMX_TRY(vqdec_bwd(s, Vl, dpred_l));
+    float* dctx = s.f32((size_t)2 * BT * DD);
+    if (live) DIMX_HIP(hipMemsetAsync(dctx, 0, (size_t)2 * BT * DD * sizeof(float), st));
+    DIMX_TRY(dec_bwd(s, D, dlogits, dctx));
+    {   // context -> the two halves of norm(x_joint) (+ the decoder-side patch embeddings); the audio columns have no parameters behind them
+        float* dc = s.f32((size_t)2 * BT * C);
+        TR(tr_copy_cols(dctx, DD, dc, C, 2 * BT, C, 0, st));
+        DIMX_TRY(bias_adjoint(s, dc, s.g("patch_embed_dec_l"), BT, C));
+        DIMX_TRY(bias_adjoint(s, dc + (size_t)BT * C, s.g("patch_embed_dec_s"), BT, C));
+        TR(tr_copy_bt(dc, (long)T * C, C, d_xn + (size_t)T * C, (long)2 * T * C, C, B, T, C, nullptr, 0, st));
+        TR(tr_copy_bt(dc + (size_t)BT * C, (long)T * C, C, d_xn, (long)2 * T * C, C, B, T, C, nullptr, 0, st));
+    }
+    float* d_ej = s.f32((size_t)4 * BT * C);
+    DIMX_TRY(ln_bwd_full(s, ej.out, "norm.weight", "norm.bias", d_xn, d_ej, 2 * BT, C));
+    DIMX_TRY(ln_bwd_full(s, ej.out + (size_t)2 * BT * C, "norm_s.weight", "norm_s.bias", d_xn + (size_t)2 * BT * C, d_ej + (size_t)2 * BT * C, BT, C));
+    DIMX_TRY(ln_bwd_full(s, ej.out + (size_t)3 * BT * C, "norm_l.weight", "norm_l.bias", d_xn + (size_t)3 * BT * C, d_ej + (size_t)3 * BT * C, BT, C));
+    float* d_xin = s.f32((size_t)4 * BT * C);
+    DIMX_TRY(enc_bwd(s, ej, d_ej, d_xin));
+    // x_s / x_l fed the joint pass twice: the stand-alone rows + their half of the concatenation
+    TR(tr_copy_bt(d_xin, (long)2 * T * C, C, d_xin + (size_t)2 * BT * C, (long)T * C, C, B, T, C, nullptr, 1, st));
+    TR(tr_copy_bt(d_xin + (size_t)T * C, (long)2 * T * C, C, d_xin + (size_t)3 * BT * C, (long)T * C, C, B, T, C, nullptr, 1, st));
+    float* d_x0s = s.f32((size_t)BT * d.dim_in);
+    float* d_x0l = s.f32((size_t)BT * d.dim_in);
+    DIMX_TRY(enc_bwd(s, es, d_xin + (size_t)2 * BT * C, d_x0s));
+    DIMX_TRY(enc_bwd(s, el, d_xin + (size_t)3 * BT * C, d_x0l));
+    TR(tr_zero_rows(d_x0s, keep_s, BT, d.dim_in, st));
+    TR(tr_zero_rows(d_x0l, keep_l, BT, d.dim_in, st));
+    DIMX_TRY(bias_adjoint(s, d_x0s, s.g("patch_embed_s"), BT, d.dim_in));
+    DIMX_TRY(bias_adjoint(s, d_x0l, s.g("patch_embed_l"), BT, d.dim_in));
+    DIMX_TRY(flush_fin(s));
+    if (use_side && live && s.slot_n > 0) {
+        DIMX_HIP(hipEventRecord(ts->ev_join, ts->side));
+        DIMX_HIP(hipStreamWaitEvent(st, ts->ev_join, 0));
+    }
+    if (need) *need = s.peak + 256;
+    DIMX_REQUIRE(!s.pool_overflow, DIMX_ERR_STATE, "train_slm: the partial-row pool of the column reductions is too small");
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "train_slm: workspace %zu < required %zu", ws_bytes, s.peak);
+    return DIMX_OK;
+}
+
+size_t dimx_train_slm_workspace_bytes(dimx_handle h, int B, int T) {
+    if (!h || B < 1 || T < 2) return 0;
+    size_t need = 0;
+    if (slm_run(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, T,
+                nullptr, nullptr, 0, nullptr, &need, true) != DIMX_OK)
+        return 0;
+    return need;
+}
+
+int dimx_train_slm_forward_backward(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_listener,
+                                    const float* v_audio, const uint8_t* mask, const uint8_t* mask_speaker, const uint8_t* mask_listener,
+                                    const int32_t* z_s, const int32_t* z_l, const float* codebook_s, const float* codebook_l, const float* pe_s,
+                                    const float* pe_l, int B, int T, float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+    DIMX_REQUIRE(h && params && grads && v_speaker && v_listener && v_audio && mask && mask_speaker && mask_listener && z_s && z_l && codebook_s &&
+                     codebook_l && pe_s && pe_l && loss_out && ws,
+                 DIMX_ERR_ARG, "train_slm: null argument");
+    DIMX_REQUIRE(((uintptr_t)ws % 256) == 0 && ((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0 && ((uintptr_t)codebook_s % 16) == 0 &&
+                     ((uintptr_t)codebook_l % 16) == 0 && ((uintptr_t)pe_s % 16) == 0 && ((uintptr_t)pe_l % 16) == 0,
+                 DIMX_ERR_ARG, "train_slm: workspace must be 256-byte aligned, arenas / codebooks / pe 16-byte aligned");
+    DIMX_HIP(hipSetDevice(h->device));
+    const bool side = train_use_side(4 * B * T);
+    {
+        size_t need = 0;
+        DIMX_TRY(slm_run(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B,
+                         T, nullptr, nullptr, 0, nullptr, &need, side));
+        DIMX_REQUIRE(ws_bytes >= need, DIMX_ERR_WORKSPACE, "train_slm: workspace %zu < required %zu (dimx_train_slm_workspace_bytes)", ws_bytes, need);
+    }
+    return slm_run(h, params, grads, v_speaker, v_listener, v_audio, mask, mask_speaker, mask_listener, z_s, z_l, codebook_s, codebook_l, pe_s, pe_l,
+                   B, T, loss_out, ws, ws_bytes, (hipStream_t)stream, nullptr, side);
 }
 
 size_t dimx_train_workspace_bytes(dimx_handle h, int B, int T) {

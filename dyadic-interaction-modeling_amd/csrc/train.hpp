@@ -66,6 +66,14 @@ int tr_emb_relu_bwd(const float* table, const int32_t* ids, const float* de, flo
 int tr_prepend_row(const float* first, const float* rest, float* joint, int B, int T, int C, int split, hipStream_t s);
 int tr_prepend_tokens(const int32_t* z, const uint8_t* mask, int32_t* z_ext, uint8_t* m_ext, int B, int T, hipStream_t s);
 int tr_gather128(const float* book, const int32_t* idx, float* out, int R, hipStream_t s);
+// SLM pre-training glue (train_kernels.hip)
+int tr_copy_bt(const float* src, long src_bs, int src_ld, float* dst, long dst_bs, int dst_ld, int B, int T, int C, const float* addrow,
+               int accumulate, hipStream_t s);
+int tr_copy_bt_u8(const uint8_t* src, long src_bs, uint8_t* dst, long dst_bs, int B, int T, int invert, hipStream_t s);
+int tr_mask_tokens(const int32_t* z, const uint8_t* sel, int32_t* out, long n, hipStream_t s);
+size_t tr_nce_scratch_floats(int B, int C);
+int tr_nce(const float* xs, const float* xl, const uint8_t* mask, int B, int T, int C, float* scr, float* out, float* dxs, float* dxl,
+           hipStream_t s);
 int tr_transpose_pad(int out_dtype, const float* in, int ld_in, void* out, int ld_out, int R, int C, hipStream_t s);
 int tr_attn_fwd(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s);
 int tr_attn_bwd(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
@@ -99,7 +107,7 @@ int tr_add_rows(const float* a, int lda, const float* row, const float* table, f
                 hipStream_t s);
 int tr_zero_rows(float* y, const uint8_t* keep, int M, int C, hipStream_t s);
 int tr_copy_cols(const float* src, int lds_, float* dst, int ldd, int M, int C, int accumulate, hipStream_t s);
-int tr_pos_grad(const float* dx, float* dtable, int B, int T, int C, float scale, hipStream_t s);
+int tr_pos_grad(const float* dx, float* dtable, int B, int T, int C, float scale, hipStream_t s, int accumulate = 0);
 int tr_cross_entropy(const float* logits, const int32_t* target, float* row_loss, float* dlogits, int R, float* loss_out, hipStream_t s);
 int tr_onehot_t(int out_dtype, const int32_t* tokens, void* out, int ld_out, int M, int rows, hipStream_t s);
 int tr_grad_norm(const float* g, long n, float max_norm, float* part, float* norm_out, hipStream_t s);

@@ -650,12 +650,12 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int lds_, float*
     }
 }
 // table[t, c] gradient of "x[b, t] += table[t] * scale": sum over clips, deterministic
-__global__ void pos_grad_kernel(const float* __restrict__ dx, float* __restrict__ dtable, int B, int T, int C, float scale) {
+__global__ void pos_grad_kernel(const float* __restrict__ dx, float* __restrict__ dtable, int B, int T, int C, float scale, int accumulate) {
     const long total = (long)T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += dx[(size_t)b * T * C + i];
-        dtable[i] = s * scale;
+        dtable[i] = accumulate ? dtable[i] + s * scale : s * scale;
     }
 }
 
@@ -1083,6 +1083,159 @@ __global__ void gather128_kernel(const float* __restrict__ book, const int32_t* 
         out[i] = book[(size_t)idx[i >> 7] * 128 + (i & 127)];
 }
 
+// ---- SLM pre-training glue (code/seq2seq_pretrain.py:200-323)
+// dst[b][t][0:C) (+)= src[b][t][0:C) (+ addrow) with independent batch / row strides: the halves of x_joint [B, 2T, C], the
+// concatenated context, and their adjoints
+__global__ void copy_bt_kernel(const float* __restrict__ src, long src_bs, int src_ld, float* __restrict__ dst, long dst_bs, int dst_ld, int B,
+                               int T, int C, const float* __restrict__ addrow, int accumulate) {
+    const long total = (long)B * T * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long r = i / C;
+        const int t = (int)(r % T), b = (int)(r / T);
+        float v = src[(size_t)b * src_bs + (size_t)t * src_ld + c];
+        if (addrow) v += addrow[c];
+        float* d = dst + (size_t)b * dst_bs + (size_t)t * dst_ld + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+// the same for mask bytes (invert: dst = !src, a "frame masked out" mask as the keep-mask of zero_rows)
+__global__ void copy_bt_u8_kernel(const uint8_t* __restrict__ src, long src_bs, uint8_t* __restrict__ dst, long dst_bs, int B, int T, int invert) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * T; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T), b = (int)(i / T);
+        const uint8_t v = src[(size_t)b * src_bs + t] != 0;
+        dst[(size_t)b * dst_bs + t] = invert ? !v : v;
+    }
+}
+// z[~sel] = -100 (:308-309): only the masked-out frames' codes are targets
+__global__ void mask_tokens_kernel(const int32_t* __restrict__ z, const uint8_t* __restrict__ sel, int32_t* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = sel[i] ? z[i] : -100;
+}
+
+// InfoNCE between the clip means of x_s and x_l (forward_contrastive, :270-289).  Three launches:
+//  1. mean[side][b] = mean of the first len_b rows (len_b = number of valid frames)
+//  2. one block: F.normalize (eps 1e-12), total = s . l^T / 0.05, log-softmax over dim 0, nce = -mean diag, c_acc, and the adjoint
+//     down to d mean (fixed summation order throughout)
+//  3. d x[b, t] = d mean[b] / len_b for t < len_b
+__global__ __launch_bounds__(128) void nce_mean_kernel(const float* __restrict__ xs, const float* __restrict__ xl, const uint8_t* __restrict__ mask,
+                                                       int B, int T, int C, float* __restrict__ mean, int* __restrict__ lens) {
+    const int b = blockIdx.x, side = blockIdx.y;
+    __shared__ int s_len;
+    if (threadIdx.x < 64) {
+        int n = 0;
+        for (int t = threadIdx.x; t < T; t += 64) n += mask[(size_t)b * T + t] ? 1 : 0;
+        n = (int)wave_sum((float)n);
+        if (threadIdx.x == 0) {
+            s_len = n;
+            if (side == 0) lens[b] = n;
+        }
+    }
+    __syncthreads();
+    const int len = s_len;
+    const float* x = (side ? xl : xs) + (size_t)b * T * C;
+    for (int c = threadIdx.x; c < C; c += 128) {
+        float a = 0.f;
+        for (int t = 0; t < len; ++t) a += x[(size_t)t * C + c];
+        mean[((size_t)side * B + b) * C + c] = len > 0 ? a / (float)len : 0.f;
+    }
+}
+// scr: sn [2][B][C] | nrm [2][B] | total [B][B] | dtot [B][B] | dsn [2][B][C]
+__global__ __launch_bounds__(256) void nce_core_kernel(const float* __restrict__ mean, int B, int C, float* __restrict__ scr, float* __restrict__ dmean,
+                                                       float* __restrict__ out) {
+    float* sn = scr;
+    float* nrm = sn + (size_t)2 * B * C;
+    float* total = nrm + 2 * B;
+    float* dtot = total + (size_t)B * B;
+    float* dsn = dtot + (size_t)B * B;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ float red[256];
+    for (int r = wave; r < 2 * B; r += 4) {          // one wave per (side, clip): the norm
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float v = mean[(size_t)r * C + c];
+            a += v * v;
+        }
+        a = wave_sum(a);
+        const float n = fmaxf(sqrtf(a), 1e-12f);
+        if (lane == 0) nrm[r] = n;
+        for (int c = lane; c < C; c += 64) sn[(size_t)r * C + c] = mean[(size_t)r * C + c] / n;
+    }
+    __syncthreads();
+    for (int p = wave; p < B * B; p += 4) {           // total[i][j] = s_i . l_j / 0.05
+        const int i = p / B, j = p - i * B;
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += sn[(size_t)i * C + c] * sn[((size_t)B + j) * C + c];
+        a = wave_sum(a);
+        if (lane == 0) total[p] = a / 0.05f;
+    }
+    __syncthreads();
+    float loss = 0.f, hit = 0.f;
+    for (int j = tid; j < B; j += 256) {              // column j: softmax over the rows i
+        float mx = -3.0e38f;
+        int am = 0;
+        for (int i = 0; i < B; ++i) {
+            const float v = total[(size_t)i * B + j];
+            if (v > mx) {
+                mx = v;
+                am = i;
+            }
+        }
+        float se = 0.f;
+        for (int i = 0; i < B; ++i) se += expf(total[(size_t)i * B + j] - mx);
+        const float lse = mx + logf(se);
+        loss -= total[(size_t)j * B + j] - lse;
+        hit += am == j ? 1.f : 0.f;
+        for (int i = 0; i < B; ++i) dtot[(size_t)i * B + j] = (expf(total[(size_t)i * B + j] - lse) - (i == j ? 1.f : 0.f)) / (float)B;
+    }
+    red[tid] = loss;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+        if (tid < s_) red[tid] += red[tid + s_];
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = red[0] / (float)B;
+    __syncthreads();
+    red[tid] = hit;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+        if (tid < s_) red[tid] += red[tid + s_];
+        __syncthreads();
+    }
+    if (tid == 0) out[1] = red[0] / (float)B;
+    __syncthreads();
+    for (long e = tid; e < (long)2 * B * C; e += 256) {   // d s_i = sum_j dtot[i][j] l_j / 0.05 ; d l_j = sum_i dtot[i][j] s_i / 0.05
+        const int side = (int)(e / ((long)B * C)), r = (int)((e / C) % B), c = (int)(e % C);
+        float a = 0.f;
+        if (side == 0) for (int j = 0; j < B; ++j) a += dtot[(size_t)r * B + j] * sn[((size_t)B + j) * C + c];
+        else for (int i = 0; i < B; ++i) a += dtot[(size_t)i * B + r] * sn[(size_t)i * C + c];
+        dsn[e] = a / 0.05f;
+    }
+    __syncthreads();
+    for (int r = wave; r < 2 * B; r += 4) {          // through F.normalize: d m = (d s - s (s . d s)) / |m|
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += sn[(size_t)r * C + c] * dsn[(size_t)r * C + c];
+        a = wave_sum(a);
+        const float n = nrm[r];
+        for (int c = lane; c < C; c += 64) {
+            const float g = n > 1e-12f ? (dsn[(size_t)r * C + c] - sn[(size_t)r * C + c] * a) / n : dsn[(size_t)r * C + c] / 1e-12f;
+            dmean[(size_t)r * C + c] = g;
+        }
+    }
+}
+__global__ void nce_bcast_kernel(const float* __restrict__ dmean, const int* __restrict__ lens, int B, int T, int C, float* __restrict__ dxs,
+                                 float* __restrict__ dxl) {
+    const long per = (long)B * T * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * per; i += (long)gridDim.x * blockDim.x) {
+        const int side = i >= per ? 1 : 0;
+        const long e = i - side * per;
+        const int c = (int)(e % C);
+        const long r = e / C;
+        const int t = (int)(r % T), b = (int)(r / T);
+        const int len = lens[b];
+        (side ? dxl : dxs)[e] = t < len ? dmean[((size_t)side * B + b) * C + c] / (float)len : 0.f;
+    }
+}
+
 inline int ew_grid(long n) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -1282,8 +1435,8 @@ int tr_copy_cols(const float* src, int lds_, float* dst, int ldd, int M, int C, 
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
-int tr_pos_grad(const float* dx, float* dtable, int B, int T, int C, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(pos_grad_kernel, dim3(ew_grid((long)T * C)), dim3(256), 0, s, dx, dtable, B, T, C, scale);
+int tr_pos_grad(const float* dx, float* dtable, int B, int T, int C, float scale, hipStream_t s, int accumulate) {
+    hipLaunchKernelGGL(pos_grad_kernel, dim3(ew_grid((long)T * C)), dim3(256), 0, s, dx, dtable, B, T, C, scale, accumulate);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
@@ -1372,6 +1525,28 @@ int tr_prepend_tokens(const int32_t* z, const uint8_t* mask, int32_t* z_ext, uin
     EW(prepend_tokens_kernel, (long)B * (T + 1), z, mask, z_ext, m_ext, B, T);
 }
 int tr_gather128(const float* book, const int32_t* idx, float* out, int R, hipStream_t s) { EW(gather128_kernel, (long)R * 128, book, idx, out, R); }
+int tr_copy_bt(const float* src, long src_bs, int src_ld, float* dst, long dst_bs, int dst_ld, int B, int T, int C, const float* addrow,
+               int accumulate, hipStream_t s) {
+    EW(copy_bt_kernel, (long)B * T * C, src, src_bs, src_ld, dst, dst_bs, dst_ld, B, T, C, addrow, accumulate);
+}
+int tr_copy_bt_u8(const uint8_t* src, long src_bs, uint8_t* dst, long dst_bs, int B, int T, int invert, hipStream_t s) {
+    EW(copy_bt_u8_kernel, (long)B * T, src, src_bs, dst, dst_bs, B, T, invert);
+}
+int tr_mask_tokens(const int32_t* z, const uint8_t* sel, int32_t* out, long n, hipStream_t s) { EW(mask_tokens_kernel, n, z, sel, out, n); }
+size_t tr_nce_scratch_floats(int B, int C) { return (size_t)8 * B * C + 4 * (size_t)B + 2 * (size_t)B * B + 64; }
+// out[0] = nce, out[1] = c_acc; dxs / dxl [B, T, C] = d nce / d x_s, d x_l.  scr: tr_nce_scratch_floats(B, C) floats
+int tr_nce(const float* xs, const float* xl, const uint8_t* mask, int B, int T, int C, float* scr, float* out, float* dxs, float* dxl,
+           hipStream_t s) {
+    float* mean = scr;                              // [2][B][C]
+    float* dmean = mean + (size_t)2 * B * C;        // [2][B][C]
+    int* lens = (int*)(dmean + (size_t)2 * B * C);  // [B]
+    float* core = (float*)(lens + B + (B & 1));     // sn | nrm | total | dtot | dsn
+    hipLaunchKernelGGL(nce_mean_kernel, dim3(B, 2), dim3(128), 0, s, xs, xl, mask, B, T, C, mean, lens);
+    hipLaunchKernelGGL(nce_core_kernel, dim3(1), dim3(256), 0, s, mean, B, C, core, dmean, out);
+    hipLaunchKernelGGL(nce_bcast_kernel, dim3(ew_grid((long)2 * B * T * C)), dim3(256), 0, s, dmean, lens, B, T, C, dxs, dxl);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
 #undef EW
 
 }  // namespace dimx

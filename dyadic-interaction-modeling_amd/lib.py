@@ -81,6 +81,8 @@ SIGNATURES = {
     "dimx_train_legacy_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "dimx_train_legacy_forward_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                    c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dimx_train_slm_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "dimx_train_slm_forward_backward": (c_int, [c_void_p] + [c_void_p] * 14 + [c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dimx_train_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                  c_int, c_float, c_void_p, c_void_p]),
     "dimx_op_train_attention": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -264,3 +264,68 @@ class LegacyHipTrainer(HipTrainer):
         self.all_reduce_grads()
         self.step()
         return loss, pred
+
+
+class SlmHipTrainer(HipTrainer):
+    """The SLM pre-training step on the HIP kernels (reference loop code/train_s2s_pretrain.py:41-64 ->
+    x_engine_pt.train_epoch over SLM.forward, code/seq2seq_pretrain.py:300-323): the three encoders (the joint one over the 2T
+    concatenation and over each stream, one pass), InfoNCE, the decoder for both streams (one pass over 2B sequences), both cross
+    entropies and the continuous losses through BOTH VQ-VAE decoders, which train.  The frozen VQ encoders run on the inference
+    engine.  Same flat arenas, clip + AdamW and gradient all-reduce as HipTrainer; ``dimx.train.slm_loss`` (PyTorch autograd) is
+    its checker (tests/test_gpu_train_slm.py)."""
+
+    KEYS = ("l_ce_s", "l_ce_l", "l_cont_s", "l_cont_l", "nce", "c_acc")
+
+    def _frozen(self):
+        m = self.model
+        c = getattr(self, "_frozen_cache", None)
+        if c is None:
+            f = lambda t: t.detach().to(self.device, torch.float32).contiguous()
+            c = (f(m.speaker_vq.quantize.embedding.weight), f(m.listener_vq.quantize.embedding.weight),
+                 f(m.speaker_vq.decoder.decoder_pos_embedding.pe), f(m.listener_vq.decoder.decoder_pos_embedding.pe))
+            self._frozen_cache = c
+        return c
+
+    def forward_backward(self, v_speaker, v_listener, v_audio, mask, mask_speaker=None, mask_listener=None, z_s=None, z_l=None,
+                         mask_ratio=0.15):
+        """-> (total loss, dict of the reference's six entries) as device scalars; gradients in ``self.grads``.  mask_speaker /
+        mask_listener (True = frame masked out) are drawn like the reference when not given."""
+        m = self.model
+        mask = mask.bool()
+        B, T = mask.shape
+        with torch.no_grad():
+            if z_s is None or z_l is None:
+                z_s, z_l = m.forward_vq(v_speaker, v_listener, mask)
+            if mask_speaker is None:
+                mask_speaker = m.random_masking_unstructured(v_speaker, mask, mask_ratio)
+            if mask_listener is None:
+                mask_listener = m.random_masking_unstructured(v_listener, mask, mask_ratio)
+        f = lambda t: t.to(self.device, torch.float32).contiguous()
+        u8 = lambda t: t.to(self.device).to(torch.uint8).contiguous()
+        i32 = lambda t: t.to(self.device).to(torch.int32).contiguous()
+        v_s, v_l, v_a = f(v_speaker), f(v_listener), f(v_audio)
+        m8, ms8, ml8, zs, zl = u8(mask), u8(mask_speaker), u8(mask_listener), i32(z_s), i32(z_l)
+        book_s, book_l, pe_s, pe_l = self._frozen()
+        need = int(self.lib.dimx_train_slm_workspace_bytes(self.eng.h, B, T))
+        if need == 0:
+            raise L.DimxError("dimx_train_slm_workspace_bytes(B=%d, T=%d) = 0: %s" % (B, T, (self.lib.dimx_last_error() or b"").decode()))
+        if need > self._ws_bytes:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        ws = ctypes.c_void_p((self._ws.data_ptr() + 255) // 256 * 256)
+        if self._loss.numel() < 10:
+            self._loss = torch.zeros(10, dtype=torch.float32, device=self.device)
+        L.check(self.lib.dimx_train_slm_forward_backward(
+            self.eng.h, L.ptr(self.params), L.ptr(self.grads), L.ptr(v_s), L.ptr(v_l), L.ptr(v_a), L.ptr(m8), L.ptr(ms8), L.ptr(ml8),
+            L.ptr(zs), L.ptr(zl), L.ptr(book_s), L.ptr(book_l), L.ptr(pe_s), L.ptr(pe_l), B, T, L.ptr(self._loss), ws,
+            self._ws.numel() - 256, L.stream_ptr(self.device)), "dimx_train_slm_forward_backward")
+        out = self._loss.clone()
+        d = {"l_ce_s": out[0], "l_ce_l": out[2], "l_cont_s": out[4], "l_cont_l": out[6], "nce": out[8], "c_acc": out[9]}
+        return out[0] + out[2] + out[4] + out[6] + out[8], d
+
+    def train_step(self, v_speaker, v_listener, v_audio, mask, **kw):
+        """one optimisation step of the reference loop's body; returns (total, d) like ``SLM.forward`` (its third value is None)."""
+        total, d = self.forward_backward(v_speaker, v_listener, v_audio, mask, **kw)
+        self.all_reduce_grads()
+        self.step()
+        return total, d

@@ -247,6 +247,21 @@ int dimx_train_legacy_forward_backward(dimx_handle h, const float* params, float
                                        const float* v_listener, const uint8_t* mask, const int32_t* listener_ids, const float* codebook,
                                        const float* pe, int B, int T, float* loss_out, float* pred_out, float* logits_out, void* ws,
                                        size_t ws_bytes, void* stream);
+/* The SLM pre-training step (reference loop code/train_s2s_pretrain.py:41-64 -> x_engine_pt.train_epoch over
+ * SLM.forward, code/seq2seq_pretrain.py:300-323): handle of variant 2.  The arenas follow dimx_train_param_info of that handle:
+ * everything the reference trains there (:98-113) -- the patch embeddings, norm / norm_s / norm_l, encoder_s / encoder_l /
+ * encoder_joint, decoder_joint (with its absolute positional table) and BOTH VQ-VAE decoders; the VQ encoders and codebooks are
+ * frozen.  v_speaker / v_listener [B,T,56], v_audio [B,T,768] f32; mask [B,T] uint8 (1 = valid frame); mask_speaker /
+ * mask_listener [B,T] uint8 (1 = frame masked out: random_masking_unstructured, :170-183); z_s / z_l [B,T] int32 codes of the
+ * frozen VQ encoders (dimx_vq_encode); codebook_* [512,128] and pe_* [>= B rows of 384]: the VQ-VAEs' frozen codebooks and their
+ * decoders' positional buffers.  2T <= max_seq_len.  loss_out: 10 device floats {l_ce_s, 1 / targets, l_ce_l, 1 / targets,
+ * l_cont_s, 1 / rows, l_cont_l, 1 / rows, nce, c_acc}; the reference's total is [0] + [2] + [4] + [6] + [8]. */
+size_t dimx_train_slm_workspace_bytes(dimx_handle h, int B, int T);
+int dimx_train_slm_forward_backward(dimx_handle h, const float* params, float* grads, const float* v_speaker, const float* v_listener,
+                                    const float* v_audio, const uint8_t* mask, const uint8_t* mask_speaker, const uint8_t* mask_listener,
+                                    const int32_t* z_s, const int32_t* z_l, const float* codebook_s, const float* codebook_l,
+                                    const float* pe_s, const float* pe_l, int B, int T, float* loss_out, void* ws, size_t ws_bytes,
+                                    void* stream);
 /* Gradient clipping (torch.nn.utils.clip_grad_norm_, max_norm <= 0: none) + one torch.optim.AdamW step over a flat arena.
  * step: 1-based step count (bias correction).  scratch: >= 1026 device floats; scratch[1024] = gradient norm before clipping,
  * scratch[1025] = the clip coefficient applied. */
