@@ -323,7 +323,7 @@ class SlmHipTrainer(HipTrainer):
         d = {"l_ce_s": out[0], "l_ce_l": out[2], "l_cont_s": out[4], "l_cont_l": out[6], "nce": out[8], "c_acc": out[9]}
         return out[0] + out[2] + out[4] + out[6] + out[8], d
 
-    def train_step(self, v_speaker, v_listener, v_audio, mask, **kw):
+    def train_step(self, v_speaker, v_listener, v_audio, mask, with_cont_loss=True, **kw):
         """one optimisation step of the reference loop's body; returns (total, d) like ``SLM.forward`` (its third value is None)."""
         total, d = self.forward_backward(v_speaker, v_listener, v_audio, mask, **kw)
         self.all_reduce_grads()

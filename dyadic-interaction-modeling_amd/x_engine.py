@@ -11,7 +11,9 @@ teacher-forced decoder logits, which ``ListenerGenerator.forward`` keeps as ``la
 
 ``model`` may be the bare module or a wrapper exposing ``.module`` (the reference calls
 ``model.module.generate`` on its DataParallel wrapper).  ``train_epoch`` / ``train_continuous_epoch`` are the
-reference's loops (:8-62); the generator's backward pass runs on PyTorch-ROCm autograd (dimx.train.legacy_loss).
+reference's loops (:8-62).  ``train_epoch`` over a ListenerGenerator on a GPU with a torch.optim.AdamW lands on the
+hand-written HIP training step (dimx.train_hip.LegacyHipTrainer: forward, backward, clip and AdamW in libdimx_hip.so);
+``backward="autograd"`` keeps the PyTorch-autograd restatement (dimx.train.legacy_loss), its checker.
 """
 import numpy as np
 import torch
@@ -116,10 +118,61 @@ def _train_loop(model, loader, optimizer, device, scheduler, clip, print_freq, e
     return float(np.mean(seen)) if seen else float("nan")
 
 
-def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, print_freq=100, epoch=0):
+def _train_epoch_hip(model, loader, trainer, device, scheduler, clip, print_freq, epoch, optimizer=None):
+    """the reference's loop body on the HIP step: the loop only feeds batches; lr / betas / eps / weight_decay follow the torch
+    optimizer the trainer stands in for (schedulers work), the trained weights and the moments go back at the end of the epoch."""
+    from . import train as T
+    from .x_engine_pt import _adopt_hyperparameters, _set_epoch
+    model.train()
+    trainer.clip = float(clip or 0.0)
+    try:
+        T.assert_same_batch_count(len(loader), device)
+    except TypeError:
+        pass
+    _set_epoch(loader, epoch)
+    losses, seen = [], []
+    for i, batch in enumerate(loader):
+        src, tgt, src_len, (_speaker_ids, listener_ids) = batch[0], batch[1], batch[2], batch[3]
+        src, tgt, listener_ids = src.to(device), tgt.to(device), listener_ids.to(device)
+        if optimizer is not None:
+            _adopt_hyperparameters(trainer, optimizer)
+            optimizer._opt_called = True
+        loss, _ = trainer.train_step(src, tgt, _mask_from_lens(src, src_len, device), listener_ids=listener_ids)
+        if scheduler is not None:
+            scheduler.step()
+        losses.append(loss)                      # device scalars: the host synchronises once per print_freq batches
+        if i % print_freq == 0:
+            vals = [float(v) for v in torch.stack(losses).cpu()]
+            seen += vals
+            print("Epoch: [{0}][{1}/{2}]\tLoss {loss_avg:.4f}\t".format(epoch, i, len(loader), loss_avg=np.mean(vals)))
+            losses = []
+    if losses:
+        seen += [float(v) for v in torch.stack(losses).cpu()]
+    trainer.sync_to_model()
+    if optimizer is not None and type(optimizer) is torch.optim.AdamW:
+        trainer.export_optimizer_state(optimizer)
+    return float(np.mean(seen)) if seen else float("nan")
+
+
+def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, print_freq=100, epoch=0, backward="auto"):
     """reference code/x_engine.py:8-36: batches ``(src, tgt, src_len, (speaker_ids, listener_ids), data_ids)``;
     ``model(src, tgt, mask, speaker_ids=None, listener_ids=listener_ids) -> (loss, pred)``.  Returns the epoch's mean
-    loss (the reference returns None; the value is extra)."""
+    loss (the reference returns None; the value is extra).  The reference's own call (a torch.optim.AdamW over the module's
+    parameters, the module on a GPU) runs on ``LegacyHipTrainer``; a ``LegacyHipTrainer`` may also be passed as ``optimizer``."""
+    from .train_hip import LegacyHipTrainer
+    if backward not in ("auto", "hip", "autograd"):
+        raise ValueError("backward must be 'auto', 'hip' or 'autograd'")
+    if isinstance(optimizer, LegacyHipTrainer):
+        return _train_epoch_hip(model, loader, optimizer, device, scheduler, clip, print_freq, epoch)
+    if backward != "autograd":
+        from .x_engine_pt import _hip_trainer_for
+        tr = _hip_trainer_for(model, optimizer, device, print)
+        if tr is not None:
+            return _train_epoch_hip(model, loader, tr, device, scheduler, clip, print_freq, epoch, optimizer=optimizer)
+        if backward == "hip":
+            from . import lib as L
+            raise L.DimxError("train_epoch(backward='hip'): this call cannot run on the HIP training step (see the log line)")
+
     def step_loss(batch):
         src, tgt, src_len, (_speaker_ids, listener_ids) = batch[0], batch[1], batch[2], batch[3]
         src, tgt, listener_ids = src.to(device), tgt.to(device), listener_ids.to(device)

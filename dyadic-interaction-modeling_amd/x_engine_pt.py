@@ -277,15 +277,18 @@ def _adopt_hyperparameters(trainer, optimizer):
 
 
 def _hip_trainer_for(model, optimizer, device, log):
-    """The HipTrainer that stands in for ``optimizer`` (a torch.optim.AdamW over this SLMFT's parameters), or None when the
-    reference call cannot be mapped onto the HIP step -- then the PyTorch-autograd restatement runs it, and the reason is logged.
+    """The HIP trainer that stands in for ``optimizer`` (a torch.optim.AdamW over this module's parameters), or None when the
+    reference call cannot be mapped onto a HIP step -- then the PyTorch-autograd restatement runs it, and the reason is logged.
+    SLMFT -> HipTrainer, SLM -> SlmHipTrainer, the legacy ListenerGenerator -> LegacyHipTrainer (dimx.x_engine.train_epoch).
     Cached on the module per optimizer object: the AdamW moments and the step count live in the trainer's flat arenas between
     epochs and are exported into ``optimizer.state`` at the end of every epoch (``optimizer.state_dict()`` stays meaningful)."""
-    from .train_hip import HipTrainer
+    from . import train_hip
     inner = getattr(model, "module", model)
     why = None
-    if getattr(inner, "engine_variant", None) != "slmft" or not hasattr(inner, "draw_kv_mask"):
-        why = "the HIP training step covers SLMFT (fine-tuning); %s trains on the autograd restatement" % type(inner).__name__
+    cls = {"slmft": train_hip.HipTrainer, "slm": train_hip.SlmHipTrainer, "legacy": train_hip.LegacyHipTrainer}.get(
+        getattr(inner, "engine_variant", None))
+    if cls is None or not hasattr(inner, "engine"):
+        why = "no HIP training step for %s" % type(inner).__name__
     elif type(optimizer) is not torch.optim.AdamW:
         why = "optimizer %s is not torch.optim.AdamW" % type(optimizer).__name__
     elif torch.device(device).type != "cuda" or next(inner.parameters()).device.type != "cuda":
@@ -301,7 +304,7 @@ def _hip_trainer_for(model, optimizer, device, log):
         cached = getattr(inner, "_dimx_hip_trainer", None)
         if cached is not None and cached[0] is optimizer:
             return cached[1]
-        tr = HipTrainer(inner, device=device)
+        tr = cls(inner, device=device)
         have = {id(p) for g in optimizer.param_groups for p in g["params"]}
         named = dict(inner.named_parameters())
         missing = [n for n, _, _ in tr.layout if id(named[n]) not in have]
@@ -333,7 +336,7 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoc
     if ddist.world_size() > 1 and hasattr(loader, "__len__"):
         T.assert_same_batch_count(len(loader), device)
     _set_epoch(loader, epoch)
-    losses, ces, conts, all_losses = [], [], [], []
+    losses, parts, all_losses = [], {}, []
     for i, batch in enumerate(loader):
         src_s_v, src_s_a, tgt, mask, _, _ = _prepare(batch, device)
         if optimizer is not None:
@@ -343,14 +346,15 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoc
         if scheduler is not None:
             scheduler.step()
         losses.append(loss)                      # device scalars: no host synchronisation per batch
-        ces.append(d_step["l_ce_l"])
-        conts.append(d_step["l_cont_l"])
+        for k, v in d_step.items():
+            if torch.is_tensor(v):
+                parts.setdefault(k, []).append(v)
         if i % print_freq == 0:
             vals = [float(v) for v in torch.stack(losses).cpu()]
             all_losses += vals
-            log("Epoch %d Batch %d:\tLoss %.4f\tl_ce_l %.4f\tl_cont_l %.4f" % (
-                epoch, i, float(np.mean(vals)), float(torch.stack(ces).mean()), float(torch.stack(conts).mean())))
-            losses, ces, conts = [], [], []
+            log("Epoch %d Batch %d:\tLoss %.4f\t" % (epoch, i, float(np.mean(vals))) +
+                "\t".join("%s %.4f" % (k, float(torch.stack(v).mean())) for k, v in parts.items()))
+            losses, parts = [], {}
     if losses:
         all_losses += [float(v) for v in torch.stack(losses).cpu()]
     trainer.sync_to_model()

@@ -102,3 +102,32 @@ def test_legacy_hip_training_reduces_the_loss_and_bf16_agrees():
     g1 = gb.grads.clone()
     gb.forward_backward(*args, listener_ids=lid)
     assert torch.equal(g1, gb.grads)
+
+
+def test_x_engine_train_epoch_with_a_torch_adamw_runs_on_the_hip_step():
+    """the reference's own call (code/x_engine.py:8-36 from code/train_vq_decoder... scripts: train_epoch(model, loader, AdamW, device,
+    clip)) lands on LegacyHipTrainer; against the same epochs on the autograd restatement: same losses, same trained weights."""
+    from dimx import lib, x_engine
+    from dimx import train as T
+    from dimx.train_hip import LegacyHipTrainer
+    dev = torch.device("cuda:0")
+    v_s, v_l, mask = _case(2, 20, [20, 13], seed=21)
+    batch = (v_s, v_l, [20, 13], (torch.tensor([0, 1]), torch.tensor([3, 41])), ["a", "b"])
+    runs = {}
+    for how in ("auto", "autograd"):
+        m = _model(lib.MODE_PARITY_F32)
+        opt = torch.optim.AdamW([p for _, p in T.legacy_trainable_parameters(m)], lr=2e-4)
+        losses = [x_engine.train_epoch(m, [batch], opt, dev, clip=1.0, backward=how) for _ in range(3)]
+        runs[how] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, m, opt)
+    assert isinstance(runs["auto"][2]._dimx_hip_trainer[1], LegacyHipTrainer)
+    assert not hasattr(runs["autograd"][2], "_dimx_hip_trainer")
+    for a, b in zip(runs["auto"][0], runs["autograd"][0]):
+        assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (runs["auto"][0], runs["autograd"][0])
+    worst = 0.0
+    for k, v in runs["autograd"][1].items():
+        if v.dtype.is_floating_point:
+            worst = max(worst, (runs["auto"][1][k] - v).abs().max().item())
+    print("legacy train_epoch, HIP step vs autograd after 3 AdamW steps: max |weight difference| %.2e" % worst)
+    assert worst < 5e-5       # three steps of lr 2e-4: an AdamW step moves a weight by ~lr whatever the gradient's size
+    st = runs["auto"][3].state[dict(runs["auto"][2].named_parameters())["generator.decoder.net.to_logits.weight"]]
+    assert float(st["step"]) == 3.0

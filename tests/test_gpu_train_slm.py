@@ -110,3 +110,36 @@ def test_slm_hip_training_reduces_the_loss_and_bf16_agrees():
         float(da["nce"]), rel))
     assert abs(float(db["l_ce_s"]) - float(da["l_ce_s"])) < 5e-2 and abs(float(db["l_ce_l"]) - float(da["l_ce_l"])) < 5e-2
     assert abs(float(db["nce"]) - float(da["nce"])) < 5e-2 and rel < 0.08
+
+
+def test_train_epoch_with_a_torch_adamw_runs_the_slm_on_the_hip_step():
+    """the reference's own call (code/train_s2s_pretrain.py:41-64): x_engine_pt.train_epoch(model, loader, torch.optim.AdamW(...),
+    device, clip=1.0) builds a SlmHipTrainer that stands in for the AdamW; the moments come back in optimizer.state, the trained
+    weights in the module.  The random frame masks are drawn inside the step, so the check is the protocol and the optimisation."""
+    from dimx import lib, x_engine_pt
+    from dimx import train as Tr
+    from dimx.train_hip import SlmHipTrainer
+    dev = torch.device("cuda:0")
+    v_s, v_l, v_a, mask, _, _ = _case(3, 40, [40, 33, 12])
+    batch = (torch.cat([v_s, v_a], dim=-1), v_l, [40, 33, 12], None, None)
+    m = _model(lib.MODE_PARITY_F32)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    opt = torch.optim.AdamW([p for _, p in Tr.slm_trainable_parameters(m)], lr=1e-4)
+    logs = []
+    torch.manual_seed(0)
+    first = x_engine_pt.train_epoch(m, [batch], opt, dev, clip=1.0, log=logs.append)
+    for _ in range(4):
+        last = x_engine_pt.train_epoch(m, [batch], opt, dev, clip=1.0, log=logs.append)
+    assert not any("autograd" in l for l in logs), logs
+    assert isinstance(m._dimx_hip_trainer[1], SlmHipTrainer) and m._dimx_hip_trainer[1].step_count == 5
+    assert all(k in logs[0] for k in ("l_ce_s", "l_ce_l", "l_cont_s", "l_cont_l", "nce", "c_acc"))
+    assert last < first, (first, last)
+    after = m.state_dict()
+    for k in before:
+        changed = not torch.equal(before[k], after[k])
+        if k.startswith(Tr.SLM_FROZEN_PREFIXES):
+            assert not changed, k
+        elif k.startswith(("encoder_s.attn_layers", "decoder_joint.net.attn_layers", "listener_vq.decoder.decoder_transformer")):
+            assert changed, k
+    st = opt.state[dict(m.named_parameters())["decoder_joint.net.to_logits.weight"]]
+    assert float(st["step"]) == 5.0 and float(st["exp_avg_sq"].abs().max()) > 0.0
