@@ -312,7 +312,13 @@ struct AttnArgs {
     int dbg;               // attention_tr.hip ablation bits (DIMX_ATTN_DBG, tuning only: results are wrong when set)
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
-int launch_attention_tr(const AttnArgs& a, hipStream_t s);  // attention_tr.hip: bf16, D 48 / 64, q / k / v row-major
+int launch_attention_tr(const AttnArgs& a, hipStream_t s);
+// mlp_fused.hip: x <- x + W2 . gelu(W1 . LayerNorm(x) + b1) + b2 in one launch (bf16 operands, C = 384); the weights are packed once
+// on the host into the kernel's LDS chunk images
+size_t mlp_fused_packed_bytes(int C, int F);
+int mlp_fused_pack(const float* w1, const float* b1, const float* w2, int C, int F, uint16_t* out);
+int launch_mlp_fused(float* x, const void* packed, const float* b2, const float* ln_g, const float* ln_b, int M, int C, int F, int act,
+                     hipStream_t s);  // attention_tr.hip: bf16, D 48 / 64, q / k / v row-major
 
 struct DecodeAttnArgs {
     int dtype;             // storage type of q / caches / out

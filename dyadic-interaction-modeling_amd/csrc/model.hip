@@ -291,6 +291,25 @@ static int pack_linear_scaled(dimx_ctx* c, const std::string& wname, const std::
     return DIMX_OK;
 }
 
+// the feed-forward sublayer's weights as the chunk images of mlp_fused.hip (bf16 perf mode, width 384; DIMX_NO_FUSED_MLP=1 keeps
+// the LayerNorm + two-GEMM form for A/B runs)
+static int pack_mlp(dimx_ctx* c, const std::string& w1, const std::string& b1, const std::string& w2, const void** out) {
+    *out = nullptr;
+    static const bool off = getenv("DIMX_NO_FUSED_MLP") != nullptr;
+    if (off || c->at != DIMX_BF16) return DIMX_OK;
+    auto i1 = c->host.find(w1), ib = c->host.find(b1), i2 = c->host.find(w2);
+    DIMX_REQUIRE(i1 != c->host.end() && ib != c->host.end() && i2 != c->host.end(), DIMX_ERR_WEIGHT, "missing weight %s", w1.c_str());
+    const int F = (int)i1->second.shape[0], C = (int)i1->second.shape[1];
+    const size_t bytes = mlp_fused_packed_bytes(C, F);
+    if (bytes == 0 || (int)i2->second.shape[0] != C || (int)i2->second.shape[1] != F) return DIMX_OK;   // another geometry: the GEMM form
+    std::vector<uint16_t> img(bytes / 2);
+    DIMX_TRY(mlp_fused_pack(i1->second.data.data(), ib->second.data.data(), i2->second.data.data(), C, F, img.data()));
+    void* p;
+    DIMX_TRY(dev_upload(c, img.data(), bytes, &p));
+    *out = p;
+    return DIMX_OK;
+}
+
 static int pack_vq(dimx_ctx* c, int which) {
     VQNet& v = c->vq[which];
     const VQGeom& vg = c->vqg[which];
@@ -319,6 +338,7 @@ static int pack_vq(dimx_ctx* c, int which) {
             DIMX_TRY(upload_f32(c, m + "norm.bias", &blk[i].ln2_b));
             DIMX_TRY(pack_linear(c, {m + "fn.l1.weight"}, m + "fn.l1.bias", false, &blk[i].l1));
             DIMX_TRY(pack_linear(c, {m + "fn.l2.weight"}, m + "fn.l2.bias", false, &blk[i].l2));
+            DIMX_TRY(pack_mlp(c, m + "fn.l1.weight", m + "fn.l1.bias", m + "fn.l2.weight", &blk[i].mlp));
         }
     }
     DIMX_TRY(upload_f32(c, e + "encoder_pos_embedding.pe", &v.pe_enc));
@@ -359,6 +379,7 @@ static int pack_xff(dimx_ctx* c, const std::string& p, XFF* f) {
     DIMX_TRY(upload_f32(c, p + "0.0.weight", &f->ln_g));
     DIMX_TRY(pack_linear(c, {p + "1.ff.0.0.weight"}, p + "1.ff.0.0.bias", false, &f->f1));
     DIMX_TRY(pack_linear(c, {p + "1.ff.2.weight"}, p + "1.ff.2.bias", false, &f->f2));
+    DIMX_TRY(pack_mlp(c, p + "1.ff.0.0.weight", p + "1.ff.0.0.bias", p + "1.ff.2.weight", &f->mlp));
     return DIMX_OK;
 }
 static int pack_xenc(dimx_ctx* c, const std::string& pre, XEnc* e) {
@@ -595,6 +616,9 @@ static void plan_vq(const dimx_ctx* c, const VQGeom& vg, Arena& ar, int B, int T
     s.idx_tmp = (int32_t*)ar.take(M * vg.fqn * 4);
 }
 
+// below this many rows a fused-MLP launch leaves most CUs idle (one block = 128 rows): the GEMM form's 64 x 64 tiles spread better
+constexpr int kFusedMlpMinRows = 8192;
+
 static int run_vq_blocks(const dimx_ctx* c, const VQGeom& vg, const VQBlock* blk, VQScratch& s, int B, int T,
                          const int32_t* lens, hipStream_t st) {
     const int M = B * T, Hd = vg.hidden, heads = vg.heads, D = Hd / heads, Tp = tpad(T);
@@ -619,6 +643,10 @@ static int run_vq_blocks(const dimx_ctx* c, const VQGeom& vg, const VQBlock* blk
         g.ldr = Hd;
         gemm_set_plain_out(g, s.h, Hd);
         DIMX_TRY(launch_gemm(g, st));
+        if (b.mlp && M >= kFusedMlpMinRows) {   // the whole MLP sublayer in one launch (mlp_fused.hip)
+            DIMX_TRY(launch_mlp_fused(s.h, b.mlp, b.l2.bias, b.ln2_g, b.ln2_b, M, Hd, vg.inter, ACT_GELU_TANH, st));
+            continue;
+        }
         DIMX_TRY(launch_layernorm(c->at, s.h, s.y, b.ln2_g, b.ln2_b, M, Hd, st));
         gemm_lin(c, s.y, Hd, b.l1, M, g);
         g.out_dtype = c->at;
@@ -1050,6 +1078,10 @@ static int run_xenc(const dimx_ctx* c, const EncGeom& eg, const XEnc& e, const v
         g.ldr = dim;
         gemm_set_plain_out(g, s.h, dim);
         DIMX_TRY(launch_gemm(g, st));
+        if (e.ff[l].mlp && M >= kFusedMlpMinRows) {
+            DIMX_TRY(launch_mlp_fused(s.h, e.ff[l].mlp, e.ff[l].f2.bias, e.ff[l].ln_g, nullptr, M, dim, dim * eg.ff_mult, ACT_GELU_ERF, st));
+            continue;
+        }
         DIMX_TRY(launch_layernorm(c->at, s.h, s.y, e.ff[l].ln_g, nullptr, M, dim, st));
         gemm_lin(c, s.y, dim, e.ff[l].f1, M, g);
         g.out_dtype = c->at;
@@ -2155,6 +2187,23 @@ int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, v
     a.q_f32 = q_is_f32 ? 1 : 0;
     a.nslab = 1;
     return launch_decode_attn(a, (hipStream_t)stream);
+}
+
+int dimx_op_mlp_fused(float* x, const float* w1_host, const float* b1_host, const float* w2_host, const float* b2, const float* ln_g,
+                      const float* ln_b, int M, int C, int F, int act, void* stream) {
+    DIMX_REQUIRE(x && w1_host && w2_host && b2 && ln_g && M > 0, DIMX_ERR_ARG, "op_mlp_fused: null argument");
+    const size_t bytes = mlp_fused_packed_bytes(C, F);
+    DIMX_REQUIRE(bytes > 0, DIMX_ERR_ARG, "op_mlp_fused: C = %d F = %d not supported", C, F);
+    std::vector<uint16_t> img(bytes / 2);
+    DIMX_TRY(mlp_fused_pack(w1_host, b1_host, w2_host, C, F, img.data()));
+    void* p = nullptr;
+    DIMX_HIP(hipMalloc(&p, bytes));
+    int rc = DIMX_OK;
+    if (hipMemcpy(p, img.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) rc = DIMX_ERR_HIP;
+    if (rc == DIMX_OK) rc = launch_mlp_fused(x, p, b2, ln_g, ln_b, M, C, F, act, (hipStream_t)stream);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && rc == DIMX_OK) rc = DIMX_ERR_HIP;
+    (void)hipFree(p);
+    return rc;
 }
 
 int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,

@@ -17,6 +17,7 @@ struct Linear {
 struct VQBlock {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     Linear qkv, out, l1, l2;
+    const void* mlp = nullptr;   // bf16 mode, hidden 384: the MLP sublayer's weights as mlp_fused.hip chunk images
 };
 
 struct VQNet {
@@ -46,6 +47,7 @@ struct XFF {
     Linear f1, f2;
     Linear f1_ln;  // decoder, bf16 mode: gamma-scaled first projection + row sums (GemmArgs.ln_stats)
     const float* f1_ln_colsum = nullptr;
+    const void* mlp = nullptr;   // encoders, bf16 mode, dim 384: mlp_fused.hip chunk images
 };
 struct XEnc {
     Linear proj_in;

@@ -107,6 +107,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "dimx_op_decode_attn_self": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_void_p, c_float, c_int, c_void_p]),
+    "dimx_op_mlp_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dimx_op_add_slabs_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_int, ctypes.c_long, c_void_p, c_void_p, c_int,
                                             c_int, c_void_p]),
     "dimx_op_chain": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -329,6 +329,13 @@ int dimx_op_fused_probe(const void* A, const void* W, const float* bias, void* C
 int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, void* vcache, void* out, int B, int H,
                              int Tmax, const int32_t* step_dev, float scale, int q_is_f32, void* stream);
 /* Decode-step residual + pre-norm: x[M,C] += sum_s slabs[s] (fixed order), y = LayerNorm(x) * gamma (no bias). */
+/* The prefill's fused feed-forward sublayer alone (csrc/mlp_fused.hip; unit parity): x [M,C] f32 on the device is replaced by
+ * x + W2 . gelu(W1 . LayerNorm(x) + b1) + b2 with bf16 operands and f32 accumulation.  w1 [F,C], b1 [F] (or NULL), w2 [C,F] are HOST
+ * f32 arrays (packed into the kernel's chunk images by the call); b2 [C], ln_g [C], ln_b [C] (or NULL) are device f32.  C = 384,
+ * F a multiple of 32; act 2 = tanh-GELU (VQ-VAE blocks, code/models/lib/base_models.py:56-68), 3 = erf-GELU (x-transformers
+ * FeedForward).  Synchronises the stream. */
+int dimx_op_mlp_fused(float* x, const float* w1_host, const float* b1_host, const float* w2_host, const float* b2, const float* ln_g,
+                      const float* ln_b, int M, int C, int F, int act, void* stream);
 int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
                                 const float* gamma, int M, int C, void* stream);
 /* One XCD-local chain launch of the decode step (csrc/chain.hip; bf16 only, B <= 256, 256-CU device):

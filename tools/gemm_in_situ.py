@@ -17,7 +17,7 @@ print("log lines %d, gemm kernels in the trace %d" % (len(shapes), len(gemms)))
 agg = collections.OrderedDict()
 n = min(len(shapes), len(gemms))
 for sh, r in zip(shapes[:n], gemms[:n]):
-    k = r["Kernel_Name"].split("(")[0].replace("void dimx::", "").replace("(anonymous namespace)::", "")[:60]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("dimx::", "").split("(")[0][:60]
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     agg.setdefault((sh, k), []).append(us)
 tot = 0.0
