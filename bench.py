@@ -163,7 +163,59 @@ def train_step_line(device, T, batches=(16, 4, 64), warm=3, steps=8):
     out["hip_graph"] = {"steps_replayed": g[0], "steps_kernel_by_kernel": g[1]}
     del tr, m
     torch.cuda.empty_cache()
+    out["other_models"] = other_train_steps(device, T, warm=2, steps=4)
     return out
+
+
+def other_train_steps(device, T, B=16, warm=2, steps=4):
+    """The two other training loops of the reference on their HIP steps: SLM pre-training
+    (code/train_s2s_pretrain.py:41-64 over SLM.forward, code/seq2seq_pretrain.py:300-323: three encoders, InfoNCE, the decoder for
+    both streams, both trainable VQ-VAE decoders) and the legacy ListenerGenerator (code/x_engine.py:8-36; its step includes the
+    frozen speaker VQ-VAE encoder on the inference engine).  bf16 operands, f32 accumulation and master weights, B clips of T frames."""
+    from dimx import train as Tr
+    from dimx.seq2seq import ListenerGenerator
+    from dimx.seq2seq_pretrain import SLM
+    from dimx.train_hip import LegacyHipTrainer, SlmHipTrainer
+    res = {}
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / steps, last
+    v_s, v_l, v_a, mask = synth_batch(B, T, device, salt=9)
+    m = SLM(synthetic_seed=SEED, numeric_mode=L.MODE_PERF_BF16).to(device)
+    Tr.set_slm_trainable(m)
+    m.train()
+    with torch.no_grad():
+        z_s, z_l = m.forward_vq(v_s, v_l, mask)
+    ms_, ml_ = m.random_masking_unstructured(v_s, mask, 0.15), m.random_masking_unstructured(v_l, mask, 0.15)
+    tr = SlmHipTrainer(m, lr=1e-5, clip=1.0)
+    dt, last = timed(lambda: tr.train_step(v_s, v_l, v_a, mask, mask_speaker=ms_, mask_listener=ml_, z_s=z_s, z_l=z_l)[0])
+    assert torch.isfinite(last)
+    res["slm_pretraining"] = {"ms_per_step": dt * 1e3, "clips_per_s": B / dt, "batch": B, "frames": T,
+                              "note": "SlmHipTrainer: dimx_train_slm_forward_backward + dimx_train_adamw"}
+    del tr, m
+    torch.cuda.empty_cache()
+    g = torch.Generator().manual_seed(5)
+    v_s824 = torch.randn(B, T, 824, generator=g).to(device)
+    lid = (torch.arange(B) % 100).to(device)
+    m = ListenerGenerator(numeric_mode=L.MODE_PERF_BF16).to(device)
+    Tr.set_legacy_trainable(m)
+    m.train()
+    tr = LegacyHipTrainer(m, lr=1e-5, clip=1.0)
+    dt, last = timed(lambda: tr.train_step(v_s824, v_l, mask, listener_ids=lid)[0])
+    assert torch.isfinite(last)
+    res["legacy_generator"] = {"ms_per_step": dt * 1e3, "clips_per_s": B / dt, "batch": B, "frames": T,
+                               "note": "LegacyHipTrainer: dimx_train_legacy_forward_backward + dimx_train_adamw; includes the frozen "
+                                       "speaker VQ-VAE encoder + listener VQ encode of the step's inputs"}
+    del tr, m
+    torch.cuda.empty_cache()
+    return res
 
 
 def _free_port():

@@ -2189,6 +2189,20 @@ int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, v
     return launch_decode_attn(a, (hipStream_t)stream);
 }
 
+size_t dimx_mlp_fused_packed_bytes(int C, int F) { return mlp_fused_packed_bytes(C, F); }
+
+int dimx_mlp_fused_pack(const float* w1_host, const float* b1_host, const float* w2_host, int C, int F, void* out_host, size_t out_bytes) {
+    DIMX_REQUIRE(w1_host && w2_host && out_host, DIMX_ERR_ARG, "mlp_fused_pack: null argument");
+    DIMX_REQUIRE(mlp_fused_packed_bytes(C, F) > 0 && out_bytes >= mlp_fused_packed_bytes(C, F), DIMX_ERR_ARG,
+                 "mlp_fused_pack: C = %d F = %d unsupported or the output buffer is too small", C, F);
+    return mlp_fused_pack(w1_host, b1_host, w2_host, C, F, (uint16_t*)out_host);
+}
+
+int dimx_op_mlp_fused_packed(float* x, const void* packed, const float* b2, const float* ln_g, const float* ln_b, int M, int C, int F, int act,
+                             void* stream) {
+    return launch_mlp_fused(x, packed, b2, ln_g, ln_b, M, C, F, act, (hipStream_t)stream);
+}
+
 int dimx_op_mlp_fused(float* x, const float* w1_host, const float* b1_host, const float* w2_host, const float* b2, const float* ln_g,
                       const float* ln_b, int M, int C, int F, int act, void* stream) {
     DIMX_REQUIRE(x && w1_host && w2_host && b2 && ln_g && M > 0, DIMX_ERR_ARG, "op_mlp_fused: null argument");

@@ -259,6 +259,39 @@ def prefill_cross_attention(B, T, device, iters=10):
             "avg_launch_us": sec * 1e6, "achieved": tf, "unit": "TFLOP/s", "util_pct": 100.0 * tf / MFMA_PEAK_TFLOPS["bf16"]}
 
 
+def prefill_mlp_fused(B, T, device, iters=8):
+    """The fused feed-forward sublayer of the prefill (csrc/mlp_fused.hip; 20 launches per forward: 12 in the VQ-VAE stacks with
+    tanh-GELU, 8 in the encoders with erf-GELU) at the headline row count M = B T: 4 M C F flops (C = 384, F = 1536) against the
+    dense bf16 MFMA peak, and its algorithmic bytes (x read once for the LayerNorm, read again for the residual, written once)."""
+    import ctypes
+    from . import lib as L
+    lib = L.load()
+    M, C, F = B * T, 384, 1536
+    g = torch.Generator().manual_seed(11)
+    w1, b1, w2 = torch.randn(F, C, generator=g) * C ** -0.5, torch.randn(F, generator=g) * 0.05, torch.randn(C, F, generator=g) * F ** -0.5
+    nbytes = int(lib.dimx_mlp_fused_packed_bytes(C, F))
+    host = torch.empty(nbytes, dtype=torch.uint8)
+    hp = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.check(lib.dimx_mlp_fused_pack(hp(w1), hp(b1), hp(w2), C, F, hp(host), nbytes), "mlp_fused_pack")
+    packed = host.to(device)
+    b2, ln_g, ln_b = torch.randn(C, device=device) * 0.02, torch.rand(C, device=device) + 0.5, torch.randn(C, device=device) * 0.1
+    xs = [torch.randn(M, C, device=device) for _ in range(2)]
+    out = []
+    for act, beta, name in ((2, ln_b, "tanh-GELU, LayerNorm with bias (VQ-VAE blocks)"), (3, None, "erf-GELU (encoders)")):
+        def run(i):
+            L.check(lib.dimx_op_mlp_fused_packed(L.ptr(xs[i % 2]), L.ptr(packed), L.ptr(b2), L.ptr(ln_g), L.ptr(beta), M, C, F, act,
+                                                 L.stream_ptr(device)), "mlp_fused")
+        sec = _time_launches(run, 2, iters)
+        for x in xs:                      # the sublayer is applied in place: keep the rows in a sane range between launches
+            x.normal_()
+        tf = 4.0 * M * C * F / sec / 1e12
+        out.append({"kernel": "mlp_fused_kernel (x += W2 gelu(W1 LN(x) + b1) + b2 in one launch, M %d x 384 -> 1536 -> 384; %s)" % (M, name),
+                    "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS["bf16"],
+                    "traffic": None, "algorithmic_flops_per_launch": 4.0 * M * C * F, "algorithmic_bytes_per_launch": 3 * M * C * 4,
+                    "avg_launch_us": sec * 1e6})
+    return out
+
+
 def cross_attn_bundle(B, T, mode, device, roof, kv):
     """SURVEY 8(d)'s 'cross-attention GEMM' bundle -- K/V projection of the context (4.25 GFLOP per clip at T = 300) + the
     cross-attention q and out projections of the T - 1 decode steps (4.23) + the decode steps' scores / AV (1.10) = 9.58
@@ -303,4 +336,6 @@ def dominant_kernel(eng, B, T, mode):
     first = dict(first)
     first["secondary"] = second
     first["others"] = [decode_self_attention(B, T, mode, dev), decode_layernorm(B, mode, dev)]
+    if mode == "bf16":
+        first["others"] += prefill_mlp_fused(B, T, dev)
     return first

@@ -336,6 +336,12 @@ int dimx_op_decode_attn_self(int dtype, const void* qkv, int ld, void* kcache, v
  * FeedForward).  Synchronises the stream. */
 int dimx_op_mlp_fused(float* x, const float* w1_host, const float* b1_host, const float* w2_host, const float* b2, const float* ln_g,
                       const float* ln_b, int M, int C, int F, int act, void* stream);
+/* The same in its parts (what dimx_load_weights / the forward do): the size of the packed weights, the host-side packing, and the
+ * asynchronous launch on weights that already sit on the device (packed: dimx_mlp_fused_packed_bytes(C, F) bytes, 16-byte aligned). */
+size_t dimx_mlp_fused_packed_bytes(int C, int F);
+int dimx_mlp_fused_pack(const float* w1_host, const float* b1_host, const float* w2_host, int C, int F, void* out_host, size_t out_bytes);
+int dimx_op_mlp_fused_packed(float* x, const void* packed, const float* b2, const float* ln_g, const float* ln_b, int M, int C, int F,
+                             int act, void* stream);
 int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
                                 const float* gamma, int M, int C, void* stream);
 /* One XCD-local chain launch of the decode step (csrc/chain.hip; bf16 only, B <= 256, 256-CU device):
