@@ -47,6 +47,21 @@ python tools/bench_train.py 16 300 5 all 2>&1 | grep -v amdgpu > $O/r04_train_st
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -- python tools/bench_train.py 16 300 3 bf16 > /dev/null 2>&1
 cp $(ls $O/kt_train/*/*kernel_stats.csv | head -1) $O/r04_train_step_kernel_stats.csv
 bash tools/scale_check.sh 1 > $O/r04_scale_check_n1.txt 2>&1
-rm -rf $O/kt $O/kt32 $O/kt_train $O/pmc_fetch $O/pmc_write $O/pa1 $O/pa2 $O/pa3
+# 7. the other models' training steps (SLM pre-training, legacy generator) next to their PyTorch-autograd restatements
+python tools/bench_train_slm.py 16 300 5 all 2>&1 | grep -v amdgpu > $O/r04_train_step_other_models.txt
+python tools/bench_train_slm.py 4 300 5 all 0 2>&1 | grep -v amdgpu >> $O/r04_train_step_other_models.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_slm -- python tools/bench_train_slm.py 16 300 3 slm 0 > /dev/null 2>&1
+cp $(ls $O/kt_slm/*/*kernel_stats.csv | head -1) $O/r04_train_slm_kernel_stats.csv
+python tools/bench_dw_split.py 2>&1 | grep -v amdgpu > $O/r04_dw_split.txt
+# 8. the fused feed-forward sublayer: kernel time per ablation (DIMX_MLP_ABL bits: 1 no DMA in the loop, 2 no GELU, 4 no chunk loop,
+#    8 no fragment reads, 16 no MFMAs), the headline without it, everything outside the decode loop in situ
+for abl in 0 1 2 3 4 11 19; do
+  DIMX_MLP_ABL=$abl rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_mlp$abl -- python tools/bench_mlp_fused.py > /dev/null 2>&1
+  echo "== DIMX_MLP_ABL=$abl"; python tools/kstat.py $O/kt_mlp$abl mlp_fused; rm -rf $O/kt_mlp$abl
+done > $O/r04_mlp_fused.txt
+DIMX_NO_FUSED_MLP=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --no-train-step --no-roofline > $O/r04_bench_line_no_fused_mlp.json 2>/dev/null
+bash tools/prefill_in_situ.sh > /dev/null 2>&1
+cp gpurun_out/insitu/gemm_in_situ.txt $O/r04_prefill_gemm_in_situ.txt; cp gpurun_out/insitu/other_kernels.txt $O/r04_forward_kernels_in_situ.txt
+rm -rf $O/kt $O/kt32 $O/kt_train $O/kt_slm $O/pmc_fetch $O/pmc_write $O/pa1 $O/pa2 $O/pa3
 ls -la $O
 tail -c 400 $O/r04_bench_line.json
