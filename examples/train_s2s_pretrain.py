@@ -1,11 +1,12 @@
 """The reference's pre-training driver (code/train_s2s_pretrain.py:41-64) on the dimx drop-ins: SLM, AdamW lr 1e-5, clip
 1.0, train_epoch + evaluate_epoch per epoch, best checkpoint by validation loss.  The frozen VQ encoders and every
-evaluation forward run on the HIP engine; SLM's backward pass runs on PyTorch-ROCm autograd (dimx.train.slm_loss) -- the
-hand-written HIP training step is SLMFT's (examples/finetune_s2s_pretrain.py).  Single process, or one process per GPU with
+evaluation forward run on the HIP engine; the training step -- forward, backward, clip and AdamW -- runs on the hand-written HIP
+kernels too: train_epoch hands the torch AdamW to dimx.train_hip.SlmHipTrainer (csrc/train.hip: slm_run), `--backward autograd`
+selects the PyTorch-autograd restatement (dimx.train.slm_loss), its checker.  Single process, or one process per GPU with
 `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_s2s_pretrain.py` (gradients
-averaged over RCCL in flat buckets; every rank reads its own shard of the clips).
+averaged over RCCL: ONE all-reduce of the flat gradient arena per step; every rank reads its own shard of the clips).
 
-    python examples/train_s2s_pretrain.py [--epochs 2] [--clips 64] [--batch 4] [--max-len 120]
+    python examples/train_s2s_pretrain.py [--epochs 2] [--clips 64] [--batch 4] [--max-len 120] [--backward auto|hip|autograd]
 """
 import argparse
 import os
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--max-len", type=int, default=120)
     ap.add_argument("--out", default="best_model_pretrain_15.pt")
+    ap.add_argument("--backward", default="auto", choices=["auto", "hip", "autograd"])
     args = ap.parse_args()
     rank, world, local = ddist.init_from_env()
     device = torch.device("cuda:{}".format(local))
@@ -44,7 +46,7 @@ def main():
     best = float("inf")
     for epoch in range(args.epochs):
         model.train()
-        train_epoch(model, dataset["train"], optimizer, device, scheduler=None, clip=1.0, print_freq=2000, epoch=epoch, log=log)
+        train_epoch(model, dataset["train"], optimizer, device, scheduler=None, clip=1.0, print_freq=2000, epoch=epoch, log=log, backward=args.backward)
         val_loss = evaluate_epoch(model, dataset["valid"], device, log=log)
         log("Epoch %d val loss: %.4f" % (epoch, val_loss))
         if rank == 0 and val_loss < best:
