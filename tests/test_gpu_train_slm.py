@@ -75,6 +75,40 @@ def test_slm_hip_gradients_match_autograd(B, T, lens):
     assert torch.equal(g1, tr.grads)
 
 
+@pytest.mark.parametrize("B,T,lens", [(1, 24, [24]), (3, 30, [30, 5, 2])])
+def test_slm_hip_edge_shapes_match_autograd(B, T, lens):
+    """a single clip (the InfoNCE matrix is 1 x 1: nce = 0, no gradient through it) and clips too short to get a masked frame
+    (int(len * ratio) = 0: they contribute no targets, only keys): losses and gradients still equal autograd's."""
+    from dimx import lib
+    from dimx.train_hip import SlmHipTrainer
+    dev = torch.device("cuda:0")
+    model = _model(lib.MODE_PARITY_F32)
+    v_s, v_l, v_a, mask, ms, ml = (t.to(dev) for t in _case(B, T, lens, seed=13))
+    assert bool(ms.any()) and bool(ml.any())
+    with torch.no_grad():
+        z_s, z_l = model.forward_vq(v_s, v_l, mask)
+    with torch.enable_grad():
+        a_total, a_d, _ = model(v_s, v_l, v_a, mask, mask_speaker=ms, mask_listener=ml, z_s=z_s, z_l=z_l)
+        a_total.backward()
+    tr = SlmHipTrainer(model)
+    total, d = tr.forward_backward(v_s, v_l, v_a, mask, mask_speaker=ms, mask_listener=ml, z_s=z_s, z_l=z_l)
+    assert torch.isfinite(total) and abs(total.item() - a_total.item()) < 1e-4 * max(1.0, abs(a_total.item()))
+    if B == 1:
+        assert abs(float(d["nce"])) < 1e-6 and float(d["c_acc"]) == 1.0
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for name, _, _ in tr.layout:
+        g_a = named[name].grad
+        g_h = tr.grad(name)
+        if g_a is None or float(g_a.abs().max()) == 0.0:
+            assert float(g_h.abs().max()) < 1e-7, name
+            continue
+        rel = (g_h - g_a).abs().max().item() / max(g_a.abs().max().item(), 1e-8)
+        worst = max(worst, rel)
+        assert rel < 1e-3, (name, rel)
+    print("SLM HIP step, edge shape B=%d lens=%s: worst relative gradient error %.2e" % (B, lens, worst))
+
+
 def test_slm_hip_training_reduces_the_loss_and_bf16_agrees():
     from dimx import lib
     from dimx import train as Tr
