@@ -66,3 +66,40 @@ def test_fused_mlp_matches_float64(M, act, beta):
         M, act, err, err_exact, scale))
     assert err < 2e-3 * max(scale, 1.0), (err, scale)
     assert err_exact < 2e-2 * max(scale, 1.0), (err_exact, scale)
+
+
+def test_fused_mlp_full_size_is_row_independent_and_deterministic():
+    """M = 76 800 (the headline row count, 600 blocks = 2.34 rounds of the chip): a row's result depends on nothing but the row --
+    permuting the rows permutes the output bit for bit, a row copied to another block's tile gives the same bits -- and two launches
+    give identical results (no atomics, fixed summation order); a sample of rows against the float64 form."""
+    from dimx import lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    M = 76800
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, C, generator=g)
+    x[12345] = x[7]                                   # the same row in two different blocks / waves / lanes
+    w1 = torch.randn(F, C, generator=g) * C ** -0.5
+    b1 = torch.randn(F, generator=g) * 0.05
+    w2 = torch.randn(C, F, generator=g) * F ** -0.5
+    b2 = (torch.randn(C, generator=g) * 0.02).to(dev)
+    gam = (torch.rand(C, generator=g) + 0.5).to(dev)
+    nbytes = int(lib.dimx_mlp_fused_packed_bytes(C, F))
+    host = torch.empty(nbytes, dtype=torch.uint8)
+    hp = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.check(lib.dimx_mlp_fused_pack(hp(w1), hp(b1), hp(w2), C, F, hp(host), nbytes), "mlp_fused_pack")
+    packed = host.to(dev)
+
+    def run(inp):
+        y = inp.to(dev).contiguous()
+        L.check(lib.dimx_op_mlp_fused_packed(L.ptr(y), L.ptr(packed), L.ptr(b2), L.ptr(gam), None, M, C, F, 3, L.stream_ptr(dev)), "mlp_fused")
+        torch.cuda.synchronize()
+        return y.cpu()
+    y0, y1 = run(x), run(x)
+    assert torch.equal(y0, y1)
+    assert torch.equal(y0[12345], y0[7])
+    perm = torch.randperm(M, generator=g)
+    assert torch.equal(run(x[perm]), y0[perm])
+    rows = torch.tensor([0, 7, 127, 128, 4099, 65535, 65536, 76799])
+    want = _reference(x[rows], w1, b1, w2, b2.cpu(), gam.cpu(), None, 3, rounded=True)
+    assert (y0[rows].double() - want).abs().max().item() < 4e-3
