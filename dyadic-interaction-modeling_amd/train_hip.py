@@ -60,11 +60,25 @@ class HipTrainer:
     def _named(self):
         return dict(self.model.named_parameters())
 
+    def _versions(self):
+        named = self._named()
+        return tuple(int(named[name]._version) for name, _, _ in self.layout)
+
     def load_from_model(self):
         named = self._named()
         with torch.no_grad():
             for name, off, numel in self.layout:
                 self.params[off:off + numel].copy_(named[name].detach().reshape(-1).to(self.device, torch.float32))
+        self._synced_versions = self._versions()
+
+    def refresh_from_model_if_changed(self):
+        """the arenas are the master copy between ``sync_to_model()`` calls; if somebody wrote the module's parameters in the
+        meantime (``load_state_dict`` of a checkpoint, a manual re-initialisation), adopt them instead of overwriting them at the
+        end of the next epoch.  Detected through the tensors' version counters.  Returns True when the arena was reloaded."""
+        if getattr(self, "_synced_versions", None) == self._versions():
+            return False
+        self.load_from_model()
+        return True
 
     def sync_to_model(self):
         """write the trained parameters back into the nn.Module (its engine re-packs them before its next launch)."""
@@ -73,6 +87,7 @@ class HipTrainer:
             for name, off, numel in self.layout:
                 p = named[name]
                 p.copy_(self.params[off:off + numel].view_as(p))
+        self._synced_versions = self._versions()
 
     # ------------------------------------------------------------------ torch.optim.AdamW <-> arenas
     def import_optimizer_state(self, optimizer):

@@ -124,6 +124,8 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, clip, print_freq
     from . import train as T
     from .x_engine_pt import _adopt_hyperparameters, _set_epoch
     model.train()
+    if trainer.refresh_from_model_if_changed():
+        print("train_epoch: the module's parameters changed since the HIP trainer last synchronised: arena reloaded from the module")
     trainer.clip = float(clip or 0.0)
     try:
         T.assert_same_batch_count(len(loader), device)

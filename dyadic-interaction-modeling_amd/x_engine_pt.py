@@ -326,6 +326,8 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoc
     trainer stands in for) supplies lr / betas / eps / weight_decay per step and receives the moments at the end."""
     from . import train as T
     model.train()
+    if trainer.refresh_from_model_if_changed():
+        log("train_epoch: the module's parameters changed since the HIP trainer last synchronised (load_state_dict?): arena reloaded from the module")
     if clip is not None:
         trainer.clip = float(clip)
     if scheduler is not None and optimizer is None:

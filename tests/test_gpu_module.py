@@ -321,3 +321,30 @@ def test_reference_sub_apis_with_the_reference_call_shapes(model, full_sd):
     sd2["listener_vq.quantize.embedding.weight"] = lat.permute(0, 2, 1).reshape(-1, 128)
     ref = ref_cpu.vq_decode(sd2, torch.arange(2 * 26).view(2, 26), prefix="listener_vq.")
     assert out.shape == (2, 26, 56) and (out.cpu() - ref).abs().max() < 1e-4
+
+
+def test_hip_trainer_adopts_parameters_written_between_epochs():
+    """the flat arenas are the master copy between sync_to_model() calls; a checkpoint loaded into the module in between must not be
+    overwritten at the end of the next epoch: train_epoch notices the change (tensor version counters) and reloads the arena."""
+    from dimx import lib, prng, x_engine_pt
+    from dimx.seq2seq_pretrain import SLMFT
+    dev = torch.device("cuda:0")
+    m = SLMFT(numeric_mode=lib.MODE_PARITY_F32).to(dev)
+    B, T = 2, 24
+    v_s = torch.from_numpy(prng.normal(3, "adopt.vs", (B, T, 56)))
+    v_a = torch.from_numpy(prng.normal(3, "adopt.va", (B, T, 768)))
+    v_l = torch.from_numpy(prng.normal(3, "adopt.vl", (B, T, 56)))
+    batch = (torch.cat([v_s, v_a], dim=-1), v_l, [T, 17], None, None)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    logs = []
+    with torch.enable_grad():
+        x_engine_pt.train_epoch(m, [batch], opt, dev, clip=1.0, log=logs.append)
+        tr = m._dimx_hip_trainer[1]
+        assert not tr.refresh_from_model_if_changed()
+        name = "decoder_joint.net.to_logits.weight"
+        with torch.no_grad():
+            dict(m.named_parameters())[name].fill_(0.125)            # stands for load_state_dict of a checkpoint
+        x_engine_pt.train_epoch(m, [batch], opt, dev, clip=1.0, log=logs.append)
+    assert any("arena reloaded" in ln for ln in logs)
+    w = dict(m.named_parameters())[name]
+    assert (w - 0.125).abs().max().item() < 1e-3 and not torch.equal(w, torch.full_like(w, 0.125))   # one AdamW step away from the new value
