@@ -288,32 +288,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(TrAttn a, const floa
     if (hl == 0) lse[((size_t)b * a.H + h) * a.Lq + qi] = m + logf(ltot);
 }
 
-// delta_i = dO_i . O_i, one thread per (clip, head, query)
-__global__ __launch_bounds__(256) void attn_delta_kernel(TrAttn a, const float* __restrict__ o, const float* __restrict__ d_o,
-                                                         float* __restrict__ delta) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long n = (long)a.B * a.H * a.Lq;
-    if (idx >= n) return;
-    const int i = (int)(idx % a.Lq);
-    const int h = (int)((idx / a.Lq) % a.H);
-    const int b = (int)(idx / ((long)a.Lq * a.H));
-    const float4* op = (const float4*)(o + ((size_t)b * a.Lq + i) * a.ldo + h * 64);
-    const float4* gp = (const float4*)(d_o + ((size_t)b * a.Lq + i) * a.ldo + h * 64);
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const float4 x = op[c], g = gp[c];
-        s += x.x * g.x + x.y * g.y + x.z * g.z + x.w * g.w;
-    }
-    delta[idx] = s;
-}
-
 // ------------------------------------------------------------------------------------------------ dQ
+// (the kernel also PRODUCES delta_i = dO_i . O_i for its query rows -- each lane half sums 32 columns of its row in f32, the halves
+// meet through one shuffle -- and stores it for the dK / dV kernel that follows on the stream: one launch per attention less than the
+// separate one-thread-per-row pass of round 3)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_dq_mfma_kernel(TrAttn a, const float* __restrict__ q, const float* __restrict__ k,
-                                                           const float* __restrict__ v, const float* __restrict__ d_o,
-                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           float* __restrict__ dq, int lddq) {
+                                                           const float* __restrict__ v, const float* __restrict__ o,
+                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                           float* __restrict__ delta, float* __restrict__ dq, int lddq) {
     typedef typename Cfg<T>::E E;
     constexpr int NS = Cfg<T>::kNS;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -328,7 +311,19 @@ __global__ __launch_bounds__(256) void attn_dq_mfma_kernel(TrAttn a, const float
     frag_rows_global<T>(Qf, q + ((size_t)b * a.Lq + (q_ok ? qi : 0)) * a.ldq + h * 64, q_ok, hl);
     frag_rows_global<T>(Gf, d_o + ((size_t)b * a.Lq + (q_ok ? qi : 0)) * a.ldo + h * 64, q_ok, hl);
     const float L = q_ok ? lse[((size_t)b * a.H + h) * a.Lq + qi] : kInf;
-    const float dl = q_ok ? delta[((size_t)b * a.H + h) * a.Lq + qi] : 0.f;
+    float dl = 0.f;
+    {
+        const float4* op4 = (const float4*)(o + ((size_t)b * a.Lq + (q_ok ? qi : 0)) * a.ldo + h * 64 + 32 * hl);
+        const float4* gp4 = (const float4*)(d_o + ((size_t)b * a.Lq + (q_ok ? qi : 0)) * a.ldo + h * 64 + 32 * hl);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 x = op4[c], g = gp4[c];
+            dl += x.x * g.x + x.y * g.y + x.z * g.z + x.w * g.w;
+        }
+        dl += __shfl_xor(dl, 32);
+        if (!q_ok) dl = 0.f;
+        if (q_ok && hl == 0) delta[((size_t)b * a.H + h) * a.Lq + qi] = dl;
+    }
     const float* kb = k + (size_t)b * a.Lk * a.ldk + h * 64;
     const float* vb = v + (size_t)b * a.Lk * a.ldv + h * 64;
     f32x16_t acc[2];
@@ -523,9 +518,7 @@ static int bwd_typed(const TrAttn& t, const float* q, const float* k, const floa
         (void)hipFuncSetAttribute((const void*)attn_dq_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         (void)hipFuncSetAttribute((const void*)attn_dkv_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     }
-    const long n = (long)t.B * t.H * t.Lq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, o, d_o, delta);
-    hipLaunchKernelGGL(attn_dq_mfma_kernel<T>, dim3((t.Lq + 127) / 128, t.H, t.B), dim3(256), lds_q, s, t, q, k, v, d_o, lse, delta, dq,
+    hipLaunchKernelGGL(attn_dq_mfma_kernel<T>, dim3((t.Lq + 127) / 128, t.H, t.B), dim3(256), lds_q, s, t, q, k, v, o, d_o, lse, delta, dq,
                        lddq);
     hipLaunchKernelGGL(attn_dkv_mfma_kernel<T>, dim3((t.Lk + 127) / 128, t.H, t.B), dim3(256), lds_kv, s, t, q, k, v, d_o, lse, delta,
                        dk, lddk, dv, lddv);
