@@ -489,25 +489,18 @@ int launch_attention_tr(const AttnArgs& a_in, hipStream_t s) {
         DIMX_HIP(hipGetDevice(&dev));
         DIMX_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    // key masks travel as 64-bit validity words (clip lengths folded in), packed on the launch stream into a buffer this file
-    // owns (grown outside of any stream capture: a capturing caller must have run the same shape once before)
+    // key masks travel as 64-bit validity words (clip lengths folded in), packed on the launch stream into scratch the CALLER
+    // provides (AttnArgs.kwords: a slice of the handle's workspace arena; until round 4 a process-wide static buffer that every
+    // handle, stream and device shared and that was re-allocated inside the launch path)
     const unsigned long long* kwords = nullptr;
     const int nwords = ceil_div(a.Lk, 64);
     if (a.kmask) {
-        static unsigned long long* buf = nullptr;
-        static size_t cap = 0;
         const size_t need = (size_t)a.B * nwords;
-        if (need > cap) {
-            if (buf) {
-                DIMX_HIP(hipDeviceSynchronize());
-                DIMX_HIP(hipFree(buf));
-            }
-            cap = need * 2 > 65536 ? need * 2 : 65536;
-            DIMX_HIP(hipMalloc((void**)&buf, cap * sizeof(unsigned long long)));
-        }
+        DIMX_REQUIRE(a.kwords && a.kwords_cap >= need, DIMX_ERR_ARG,
+                     "attention_tr: a key mask needs %zu words of caller scratch (AttnArgs.kwords), got %zu", need, a.kwords ? a.kwords_cap : (size_t)0);
         hipLaunchKernelGGL(pack_key_words_kernel, dim3(ceil_div((int)need * 64, 256)), dim3(256), 0, s, a.kmask, a.kmask_ld, a.lens, a.B, a.Lk,
-                           nwords, buf);
-        kwords = buf;
+                           nwords, a.kwords);
+        kwords = a.kwords;
     }
     // persistent blocks, 2 per CU (80 KiB of LDS each): each walks (clip, head) pairs g, g + grid, ...
     const int items = a.B * a.H * nqb;

@@ -310,6 +310,11 @@ struct AttnArgs {
     const uint8_t* kmask;  // [B, kmask_ld] optional
     int kmask_ld;
     int dbg;               // attention_tr.hip ablation bits (DIMX_ATTN_DBG, tuning only: results are wrong when set)
+    // attention_tr.hip with a key mask: scratch for the packed 64-bit validity words, B * ceil(Lk / 64) of them, owned by the
+    // CALLER (its workspace arena: one buffer per handle and call, so launches on other streams / devices never share it and
+    // nothing is allocated inside a launch or a stream capture -- ADVICE round 4)
+    unsigned long long* kwords;
+    size_t kwords_cap;     // in words
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 int launch_attention_tr(const AttnArgs& a, hipStream_t s);

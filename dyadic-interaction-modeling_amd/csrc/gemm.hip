@@ -22,6 +22,7 @@
 namespace dimx {
 
 static int gemm_cfg_small();
+static bool gemm_use_ws72(const GemmArgs& a);
 
 void gemm_args_init(GemmArgs& a) {
     memset(&a, 0, sizeof(a));
@@ -101,7 +102,10 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_fn(float x) {
 
 template <typename OutT, int MI, int NI, int ACT, bool FAST>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w,
-                                              int half, int l31, int split, unsigned long long* st = nullptr) {
+                                              int half, int l31, int split, unsigned long long* st = nullptr,
+                                              int n_lim = 0x7fffffff, const float* bias_pre = nullptr) {
+    // n_lim: first column the block does NOT own (gemm_ws72_kernel: a 96-wide MFMA tile holds 72 valid columns);
+    // bias_pre[j]: the lane's bias values requested before the main loop (a dependent load here cost 0.5 us per launch)
     const bool first = split == 0;
     const bool plain = a.nseg == 1 && a.seg[0].sd == 1 && a.seg[0].sh == 0 && a.seg[0].sb == a.seg[0].st * (long)a.rowT;
     if (plain && a.rowadd_mode == 0) {
@@ -110,8 +114,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = n0w + j * 32 + l31;
-            if (n >= a.N) continue;
-            float bias_v = (a.bias && first) ? a.bias[n] : 0.f;
+            if (n >= a.N || n >= n_lim) continue;
+            float bias_v = bias_pre ? bias_pre[j] : ((a.bias && first) ? a.bias[n] : 0.f);
             if (st) {  // tools/gemm_phases.py: kernel arguments + bias in registers
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(bias_v)::"memory");
                 st[24] = wall_clock64();
@@ -159,8 +163,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0w + j * 32 + l31;
-        if (n >= a.N) continue;
-        const float bias_v = (a.bias && first) ? a.bias[n] : 0.f;
+        if (n >= a.N || n >= n_lim) continue;
+        const float bias_v = bias_pre ? bias_pre[j] : ((a.bias && first) ? a.bias[n] : 0.f);
         int s = 0, nn = n;
         if (a.nseg > 1) {
             s = n / a.seg_width;
@@ -226,13 +230,14 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& a, const f32x16_t 
 
 template <typename T, typename OutT, int MI, int NI>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, const f32x16_t (&acc)[MI][NI], int m0w, int n0w, int half,
-                                         int l31, int split, unsigned long long* st = nullptr) {
+                                         int l31, int split, unsigned long long* st = nullptr, int n_lim = 0x7fffffff,
+                                         const float* bias_pre = nullptr) {
     constexpr bool FAST = sizeof(T) == 2;
     switch (a.act) {
-        case ACT_LEAKY: epilogue_tile<OutT, MI, NI, ACT_LEAKY, FAST>(a, acc, m0w, n0w, half, l31, split, st); break;
-        case ACT_GELU_TANH: epilogue_tile<OutT, MI, NI, ACT_GELU_TANH, FAST>(a, acc, m0w, n0w, half, l31, split, st); break;
-        case ACT_GELU_ERF: epilogue_tile<OutT, MI, NI, ACT_GELU_ERF, FAST>(a, acc, m0w, n0w, half, l31, split, st); break;
-        default: epilogue_tile<OutT, MI, NI, ACT_NONE, FAST>(a, acc, m0w, n0w, half, l31, split, st); break;
+        case ACT_LEAKY: epilogue_tile<OutT, MI, NI, ACT_LEAKY, FAST>(a, acc, m0w, n0w, half, l31, split, st, n_lim, bias_pre); break;
+        case ACT_GELU_TANH: epilogue_tile<OutT, MI, NI, ACT_GELU_TANH, FAST>(a, acc, m0w, n0w, half, l31, split, st, n_lim, bias_pre); break;
+        case ACT_GELU_ERF: epilogue_tile<OutT, MI, NI, ACT_GELU_ERF, FAST>(a, acc, m0w, n0w, half, l31, split, st, n_lim, bias_pre); break;
+        default: epilogue_tile<OutT, MI, NI, ACT_NONE, FAST>(a, acc, m0w, n0w, half, l31, split, st, n_lim, bias_pre); break;
     }
 }
 
@@ -1097,6 +1102,237 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_ws72_kernel (round 5): the loader/consumer decode GEMM on 64 x 72 tiles -- ONE block per CU, exactly.
+// Measured (tools/r05_gemm_blocks.py, profiles/r05_gemm_blocks.txt): the three chip-wide decode GEMMs launch 288 blocks of
+// 64 x 64 tiles on 256 CUs; a CU that hosts two blocks pulls twice the operand bytes through its LDS-DMA path (55-67 GB/s
+// per CU whatever the block count) and the launch lasts as long as those 32 CUs: the same kernel at a column count that gives
+// 256 blocks runs 7.7 instead of 11.1 us (K = 4608, 4 slabs), 9.2 instead of 10.8 (ff1), 6.3 instead of 6.6 (qkv).  No
+// 64-column tiling of N = 4608 / 1152 / 2304 at M = 256 gives 256 equal blocks (9 | N / 128); 72 = N / 64, N / 16, N / 32 does:
+// 4 row tiles x {64, 16, 32} column tiles x {1, 4, 2} K splits = 256 blocks with the SAME k-tile counts (18 / 18 / 9) and the
+// same slab counts as before.  A 72-column tile is three 32-column MFMA blocks of which the third holds 8 valid columns: six
+// consumer waves (2 x 3, one 32 x 32 accumulator each, the loop body of gemm_ws_kernel unchanged), four loader waves; a k-tile
+// is 8 A pieces + 9 W pieces of 1 KiB (17 KiB against 16: loader 0 issues five pieces per tile, the others four -- the counted
+// vmcnt waits are instantiated per loader).  The W fragment reads of the third column block run past the 72 rows that were
+// loaded (into the next ring slot / the slack behind the ring): whatever they find only reaches accumulator columns that are
+// never stored (n_lim).  bf16 operands only; M and N edges are clamped like in gemm_ws_kernel.
+template <typename OutT, bool PROF>
+struct Ws72 {
+    static constexpr int BM = 64, BN = 72, BK = 64, STAGES = 4, NLOAD = 4, NCONS = 6;
+    static constexpr int TILE_BYTES = (BM + BN) * 128;
+    // + the rows 72..95 read behind the last slot; and never less than 84 KiB: two blocks must NOT fit a CU.  Launched into an idle
+    // GPU the 256 blocks land one per CU, but behind another kernel the dispatcher hands a CU that drained early a second block
+    // while others still wait for their first (LDS and waves would allow it) -- and the doubled CUs set the launch time again:
+    // 8.8 us by in-kernel stamps (isolated launches) against 10.4 us back to back (profiles/r05_gemm_ws72.txt)
+    static constexpr int RING_BYTES = STAGES * TILE_BYTES + 24 * 128;
+    static constexpr int SMEM_BYTES = RING_BYTES > 84 * 1024 ? RING_BYTES : 84 * 1024;
+
+    template <int LW>  // W pieces of this loader wave (3 for loader 0, 2 for the others)
+    static __device__ __forceinline__ void loader(const GemmArgs& a, int block_id, int lw, int lane, int m0, int n0, int kt0, int nk,
+                                                  unsigned char* smem, float* ln_sm) {
+        constexpr int LA = 2, LPT = LA + LW;
+        static_assert((STAGES - 1) * LPT < 64, "ring depth");
+        auto stamp = [&](int i) {
+            if (PROF && lane == 0 && lw == 0 && i < 32) a.prof[(size_t)block_id * 64 + 32 + i] = wall_clock64();
+        };
+        const bf16* __restrict__ A = (const bf16*)a.A;
+        const bf16* __restrict__ W = (const bf16*)a.W;
+        const bf16* gA[LA];
+        const bf16* gW[LW];
+        int pA[LA], pW[LW];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            pA[j] = lw * LA + j;
+            const int row = pA[j] * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            gA[j] = A + (size_t)m * a.lda + c * 8 + (size_t)kt0 * BK;
+        }
+#pragma unroll
+        for (int j = 0; j < LW; ++j) {
+            pW[j] = (lw == 0 ? 0 : 1 + 2 * lw) + j;
+            const int row = pW[j] * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int n = n0 + row;
+            n = n < a.N ? n : a.N - 1;
+            gW[j] = W + (size_t)n * a.ldw + c * 8 + (size_t)kt0 * BK;
+        }
+        auto issue = [&](int kt, int buf) {
+            unsigned char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+            for (int j = 0; j < LA; ++j)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gA[j] + (size_t)kt * BK), (lds_void_t*)(base + pA[j] * 1024), 16, 0, 0);
+#pragma unroll
+            for (int j = 0; j < LW; ++j)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gW[j] + (size_t)kt * BK), (lds_void_t*)(base + BM * 128 + pW[j] * 1024), 16, 0,
+                                                 0);
+        };
+        // deferred LayerNorm of the A rows: as in gemm_ws_body (loader lw reduces the partial sums of rows lw * 16 + (lane & 15))
+        float2 lp[8];
+        if (a.ln_stats) {
+            int m = m0 + lw * 16 + (lane & 15);
+            m = m < a.M ? m : a.M - 1;
+            const float2* sp = (const float2*)a.ln_stats + ((size_t)(m >> 5) * 32 + (lane >> 4) * 8) * 32 + (m & 31);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lp[i] = sp[(size_t)i * 32];
+        }
+#pragma unroll
+        for (int st = 0; st < STAGES - 1; ++st)
+            if (st < nk) issue(st, st);
+        stamp(1);
+        for (int it = 0; it < nk; ++it) {
+            if (it < 12) stamp(2 + 2 * it);
+            if (nk - 1 - it < STAGES - 2)
+                wait_vmcnt<0>();
+            else
+                wait_vmcnt<(STAGES - 2) * LPT>();
+            if (it < 12) stamp(3 + 2 * it);
+            __builtin_amdgcn_s_barrier();
+            if (it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
+            if (a.ln_stats && it == nk - 2) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s1 += lp[i].x;
+                s1 += xor_lane_f32<16>(s1);
+                s1 += xor_lane_f32<32>(s1);
+                const float inv_c = 1.0f / (float)a.ln_C;
+                const float mean = s1 * inv_c;
+                const float ncs = (float)a.ln_C * (1.0f / 32.0f), inv_n = 32.0f * inv_c;
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = lp[i].x * inv_n - mean;
+                    s2 += lp[i].y + ncs * d * d;
+                }
+                s2 += xor_lane_f32<16>(s2);
+                s2 += xor_lane_f32<32>(s2);
+                const float var = s2 * inv_c;
+                const float rstd = rsqrtf(var + 1e-5f);
+                if (a.ln_err && lane < 16 && m0 + lw * 16 + lane < a.M && mean * mean > 64.0f * var) atomicOr(a.ln_err, 4u);
+                if (lane < 16) {
+                    ln_sm[lw * 16 + lane] = mean;
+                    ln_sm[64 + lw * 16 + lane] = rstd;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        stamp(28);
+    }
+
+    static __device__ __forceinline__ void body(const GemmArgs& a, int block_id, int nblocks, unsigned char* smem, float* ln_sm) {
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+        const int ntiles = tiles_m * tiles_n;
+        int bid = block_id;  // XCD-aware order: an XCD's blocks are a contiguous range of n-major tiles (the row tiles of a column
+                             // tile share its W rows through that XCD's L2)
+        {
+            const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, i = bid >> 3;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+        }
+        const int split = bid / ntiles, tile = bid - split * ntiles;
+        const int tile_n = tile / tiles_m, tile_m = tile - tile_n * tiles_m;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        const int nk_all = (a.kloop ? a.kloop : a.ldw) / BK;
+        const int per = (nk_all + a.splitk - 1) / a.splitk;
+        const int kt0 = split * per;
+        int nk = nk_all - kt0;
+        nk = nk > per ? per : nk;
+        if (nk <= 0) return;
+        auto stamp = [&](int i) {
+            if (PROF && lane == 0 && wave == 0 && i < 32) a.prof[(size_t)block_id * 64 + i] = wall_clock64();
+        };
+        stamp(0);
+        if (wave >= NCONS) {
+            const int lw = wave - NCONS;
+            if (lw == 0)
+                loader<3>(a, block_id, lw, lane, m0, n0, kt0, nk, smem, ln_sm);
+            else
+                loader<2>(a, block_id, lw, lane, m0, n0, kt0, nk, smem, ln_sm);
+            return;
+        }
+        // ---------------- consumer waves: 2 x 3, one 32 x 32 accumulator each
+        const int wm = wave / 3, wn = wave - 3 * wm;
+        const int half = lane >> 5, l31 = lane & 31;
+        const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+        unsigned aoff[4], woff[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            aoff[ks] = lds0 + lds_off(wm * 32 + l31, 2 * ks + half);
+            woff[ks] = lds0 + BM * 128 + lds_off(wn * 32 + l31, 2 * ks + half);
+        }
+        f32x16_t acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        // the lane's column: bias and (deferred LayerNorm) the column sum of the gamma-scaled weights are requested NOW -- the
+        // consumers wait ~1.5 us for the first tile anyway; as dependent loads behind the main loop they cost 0.5 us per launch
+        const int n_lim = n0 + BN < a.N ? n0 + BN : a.N;
+        const int ncol = n0 + wn * 32 + l31;
+        const int ncl = ncol < n_lim ? ncol : n_lim - 1;
+        float bias_pre[1];
+        bias_pre[0] = (a.bias && split == 0) ? a.bias[ncl] : 0.f;
+        const float ln_cs = a.ln_stats ? a.ln_colsum[ncl] : 0.f;
+        for (int it = 0; it < nk; ++it) {
+            const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
+            if (it < 12) stamp(2 + 2 * it);
+            __builtin_amdgcn_s_barrier();
+            if (it < 12) stamp(3 + 2 * it);
+            u32x4_t fa[4][1], fw[4][1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ds_read128<0>(fa[q][0], aoff[q] + boff);
+                ds_read128<0>(fw[q][0], woff[q] + boff);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q == 0) wait_lgkm<6>();
+                if (q == 1) wait_lgkm<4>();
+                if (q == 2) wait_lgkm<2>();
+                if (q == 3) wait_lgkm<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                FragMma<bf16, 1, 1>::run(acc, fa[q], fw[q]);
+            }
+        }
+        stamp(28);
+        if (a.ln_stats) {
+            const float* strip = ln_sm + wm * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 mq = *(const float4*)(strip + 8 * q + 4 * half);
+                const float4 rq = *(const float4*)(strip + 64 + 8 * q + 4 * half);
+                acc[0][0][4 * q + 0] = rq.x * (acc[0][0][4 * q + 0] - mq.x * ln_cs);
+                acc[0][0][4 * q + 1] = rq.y * (acc[0][0][4 * q + 1] - mq.y * ln_cs);
+                acc[0][0][4 * q + 2] = rq.z * (acc[0][0][4 * q + 2] - mq.z * ln_cs);
+                acc[0][0][4 * q + 3] = rq.w * (acc[0][0][4 * q + 3] - mq.w * ln_cs);
+            }
+        }
+        epilogue<bf16, OutT, 1, 1>(a, acc, m0 + wm * 32, n0 + wn * 32, half, l31, split,
+                                   (PROF && wave == 0 && lane == 0) ? a.prof + (size_t)block_id * 64 : nullptr, n_lim, bias_pre);
+        if (PROF) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(29);
+        }
+    }
+};
+
+template <typename OutT, bool PROF = false>
+__global__ __launch_bounds__(640) void gemm_ws72_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Ws72<OutT, PROF>::SMEM_BYTES];
+    __shared__ __attribute__((aligned(16))) float ln_sm[128];
+    Ws72<OutT, PROF>::body(a, blockIdx.x, gridDim.x, smem, ln_sm);
+}
+
+template <typename OutT> static int launch_ws72(const GemmArgs& a, hipStream_t s) {
+    const int tiles = ceil_div(a.M, 64) * ceil_div(a.N, 72);
+    if (a.prof)
+        hipLaunchKernelGGL((gemm_ws72_kernel<OutT, true>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_ws72_kernel<OutT, false>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Attention / GEMM co-residency probe (tools/fuse_probe.py; VERDICT round 2, item 2: "hide the decode step's GEMM chain
 // under its attention: horizontal fusion over two half-batches").  Streams do not overlap the decode kernels and CU masks
 // starve the HBM stream (round 2); what is left to try is ONE launch whose blocks take either role: blocks of role 0 run the
@@ -1193,7 +1429,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 //  6: 128x64 3 stages    7: 128x64 2 stages    8: 64x128 3 stages
 template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a, int cfg, hipStream_t s) {
     DIMX_REQUIRE(!a.w_tiled || (cfg >= 34 && cfg <= 40), DIMX_ERR_ARG, "gemm: block-tiled W is read by the decode kernel only (cfg %d)", cfg);
-    DIMX_REQUIRE(!a.ln_stats || (cfg >= 34 && cfg <= 37 && a.splitk == 1 && a.ln_colsum && a.ln_C > 0 &&
+    DIMX_REQUIRE(!a.ln_stats || (((cfg >= 34 && cfg <= 37) || cfg == 72) && a.splitk == 1 && a.ln_colsum && a.ln_C > 0 &&
                                  a.K >= 16 * Elem<T>::kPerChunk),
                  DIMX_ERR_ARG, "gemm: the deferred-LayerNorm epilogue exists in the decode kernel only, without split-K, from two "
                                "k-tiles up (cfg %d, K %d)", cfg, a.K);
@@ -1218,6 +1454,9 @@ template <typename T, typename OutT> static int launch_by_cfg(const GemmArgs& a,
         case 39: return launch_ws<T, OutT, 4, 2>(a, s);
         case 40: return launch_ws<T, OutT, 4, 3>(a, s);
 #endif
+        case 72:  // 64x72, 6 consumer + 4 loader waves, one block per CU (bf16 operands)
+            if constexpr (sizeof(T) == 2) return launch_ws72<OutT>(a, s);
+            break;
         case 34: return launch_ws<T, OutT, 4>(a, s);  // 64x64, 4 consumer + 4 loader waves, 64 KB ring
         case 35: return launch_ws<T, OutT, 6>(a, s);  // ... 96 KB ring (one block per CU)
         default: break;
@@ -1234,6 +1473,7 @@ static inline void cfg_tile(int cfg, int& bm, int& bn) {
         case 17: case 18: case 27: case 31: bm = 256; bn = 128; break;
         case 19: case 28: bm = 256; bn = 256; break;
         case 8: bm = 64; bn = 128; break;
+        case 72: bm = 64; bn = 72; break;
         default: bm = 64; bn = 64; break;
     }
 }
@@ -1254,6 +1494,8 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     // measured on MI355X: 128x128 8-wave for large M; bf16 from 288 tiles (the dW of a 1152 x 4608 projection at 4 800 rows:
     // 122.9 us on the 64 x 64 kernel, 80.4 on this one; 228 tiles and fewer: level or behind -- profiles/r03_train_gemm.txt)
     if (cfg == 0) cfg = tiles128 >= (sizeof(T) == 2 ? 288 : 512) ? 14 : gemm_cfg_small();
+    if (a.cfg == 0 && gemm_use_ws72(a0)) cfg = 72;
+    DIMX_REQUIRE(cfg != 72 || (sizeof(T) == 2 && a.N % 72 == 0 && !a.w_tiled), DIMX_ERR_ARG, "gemm: cfg 72 needs bf16 operands and N %% 72 == 0 (N=%d)", a.N);
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;
@@ -1303,6 +1545,7 @@ int gemm_plan_splits(const GemmArgs& a) {
     if (a.conv_T != 0 || a.K % bk != 0 || a.K != kext || a.force_simple) return 1;  // register-staged kernel: no split
     int cfg = a.cfg, bm, bn;
     if (cfg == 0) cfg = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) >= 512 ? 14 : 4;
+    if (a.cfg == 0 && gemm_use_ws72(a)) cfg = 72;
     cfg_tile(cfg, bm, bn);
     const int tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
     const int nk = kext / bk;
@@ -1335,6 +1578,16 @@ int gemm_plan_splits(const GemmArgs& a) {
         return best;
     }
     if (tiles >= 256) return 1;
+    if (cfg == 72) {
+        // one block per CU and no more (round 5, profiles/r05_gemm_blocks.txt): the largest split count that keeps the launch within
+        // 256 blocks with at least min_nk k-tiles per block
+        static const int min_nk72 = getenv("DIMX_SPLIT_MINNK") ? atoi(getenv("DIMX_SPLIT_MINNK")) : 6;
+        int sp = 256 / tiles;
+        const int max_sp = nk / min_nk72 > 0 ? nk / min_nk72 : 1;
+        sp = sp > max_sp ? max_sp : sp;
+        sp = sp > 8 ? 8 : sp;
+        return sp < 1 ? 1 : sp;
+    }
     // measured (tools/bench_gemm.py under rocprofv3): ~288 blocks (one per CU + a few) is the sweet spot
     static const int target = getenv("DIMX_SPLIT_TARGET") ? atoi(getenv("DIMX_SPLIT_TARGET")) : 288;
     static const int min_nk = getenv("DIMX_SPLIT_MINNK") ? atoi(getenv("DIMX_SPLIT_MINNK")) : 6;  // k-tiles per split at least (swept 3..9)
@@ -1351,6 +1604,17 @@ static int gemm_cfg_small() {
     // (36: 5, 35: 6, 37: 8 slots) are slower (tools/gemm_ab.py)
     static const int cfg_small = getenv("DIMX_GEMM_CFG_SMALL") ? atoi(getenv("DIMX_GEMM_CFG_SMALL")) : 34;
     return cfg_small;
+}
+
+// the 64 x 72 one-block-per-CU decode kernel: bf16 operands, the LDS-DMA path, a decode-sized M, N a multiple of 72 whose
+// tiles fit the chip in one round (DIMX_NO_WS72=1: the 64 x 64 kernel everywhere, for A/B runs)
+static bool gemm_use_ws72(const GemmArgs& a) {
+    static const bool off = getenv("DIMX_NO_WS72") != nullptr;
+    if (off || a.in_dtype != DIMX_BF16 || gemm_cfg_small() != 34) return false;
+    const int kext = a.kloop ? a.kloop : a.ldw;
+    if (a.conv_T != 0 || a.K % 64 != 0 || a.K != kext || a.force_simple || a.w_tiled) return false;
+    if (a.M > 256 || a.N % 72 != 0) return false;
+    return ceil_div(a.M, 64) * (a.N / 72) <= 256;
 }
 
 bool gemm_decode_has_ln_epilogue() {

@@ -896,6 +896,8 @@ namespace dimx {
 struct EncScratch {
     void *xa, *y, *q, *k, *vt, *o, *f;
     float *h, *tmp;
+    unsigned long long* kw;  // packed key-mask words of the prefill attention (AttnArgs.kwords)
+    size_t kw_cap;
 };
 struct CtxPersist {
     void* ck[8];
@@ -906,6 +908,8 @@ struct DecScratch {
     float* h;
     int32_t *inp, *tgt;
     uint8_t* kvm;
+    unsigned long long* kw;  // packed key-mask words of the prefill attention (AttnArgs.kwords)
+    size_t kw_cap;
 };
 struct GenScratch {
     void* sk[8];
@@ -942,6 +946,8 @@ static void plan_enc(const dimx_ctx* c, Arena& ar, int B, int T, EncScratch& s) 
     s.vt = ar.take((size_t)B * inner * Tp * es);
     s.o = ar.take(M * inner * es);
     s.f = ar.take(M * dim * eg.ff_mult * es);
+    s.kw_cap = (size_t)B * ((T + 63) / 64);
+    s.kw = (unsigned long long*)ar.take(s.kw_cap * 8);
 }
 // number of decoder positions: SLMFT feeds / generates T-1 tokens (code/seq2seq_pretrain.py:469,500);
 // the legacy generator is teacher-forced on T-1 tokens but generates seq_len = T (code/seq2seq.py:256,300)
@@ -960,6 +966,8 @@ static void plan_dec(const dimx_ctx* c, Arena& ar, int B, int T, DecScratch& s) 
     s.inp = (int32_t*)ar.take(M * 4);
     s.tgt = (int32_t*)ar.take(M * 4);
     s.kvm = (uint8_t*)ar.take(M);
+    s.kw_cap = (size_t)B * ((T + 63) / 64);
+    s.kw = (unsigned long long*)ar.take(s.kw_cap * 8);
 }
 static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) {
     const size_t es = es_of(c);
@@ -1071,6 +1079,8 @@ static int run_xenc(const dimx_ctx* c, const EncGeom& eg, const XEnc& e, const v
         a.causal = eg.causal;
         a.kmask = mask;
         a.kmask_ld = T;
+        a.kwords = s.kw;
+        a.kwords_cap = s.kw_cap;
         DIMX_TRY(launch_attention(a, st));
         gemm_lin(c, s.o, inner, e.attn[l].out, M, g);
         g.out_dtype = DIMX_F32;
@@ -1495,6 +1505,8 @@ int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, c
         a.causal = 1;
         a.kmask = kv_mask;
         a.kmask_ld = n;
+        a.kwords = s.kw;
+        a.kwords_cap = s.kw_cap;
         DIMX_TRY(launch_attention(a, st));
         gemm_lin(h, s.o, inner, h->dec.self_[l].out, M, g);
         g.out_dtype = DIMX_F32;
@@ -1512,6 +1524,8 @@ int dimx_decode_tf(dimx_handle h, const int32_t* z_l, const uint8_t* ctx_mask, c
         a.scale = scale;
         a.kmask = ctx_mask;
         a.kmask_ld = T;
+        a.kwords = s.kw;
+        a.kwords_cap = s.kw_cap;
         DIMX_TRY(launch_attention(a, st));
         gemm_lin(h, s.o, inner, h->dec.cross[l].out, M, g);
         g.out_dtype = DIMX_F32;
@@ -2005,7 +2019,7 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
     g.cfg = (flags >> 8) & 0xff;           /* tuning: tile/stage config id */
     g.force_splitk = (flags >> 16) & 0xff; /* tuning: split count */
     if (ldw > K && K % (in_dtype == DIMX_BF16 ? 64 : 32) == 0) g.kloop = K; /* padded row stride, exact k extent */
-    if (getenv("DIMX_GEMM_PROF") && residual && !g.out_slabs && out_dtype == DIMX_BF16 && M <= 1024) {
+    if (getenv("DIMX_GEMM_PROF") && residual && M <= 1024) {
         g.prof = (unsigned long long*)residual; /* tools/gemm_phases.py smuggles its stamp buffer in here */
         g.residual = nullptr;
     }
@@ -2064,6 +2078,19 @@ int dimx_op_instnorm(int out_dtype, const float* x, void* y, const int32_t* lens
     return launch_instnorm(out_dtype, x, y, lens, B, T, C, (hipStream_t)stream);
 }
 
+// operator entry points (tests / tools): the key-mask scratch of attention_tr.hip is a stream-ordered allocation around the call
+static int op_attention_with_scratch(AttnArgs& a, hipStream_t st) {
+    void* kw = nullptr;
+    if (a.kmask && a.v_rows && a.dtype == DIMX_BF16) {
+        a.kwords_cap = (size_t)a.B * ((a.Lk + 63) / 64);
+        DIMX_HIP(hipMallocAsync(&kw, a.kwords_cap * 8, st));
+        a.kwords = (unsigned long long*)kw;
+    }
+    const int rc = launch_attention(a, st);
+    if (kw) DIMX_HIP(hipFreeAsync(kw, st));
+    return rc;
+}
+
 int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int H, int Lq, int Lk,
                       int D, int ldq, int ldk, int ld_vt, int ldo, float scale, int causal, const int32_t* lens,
                       const uint8_t* kmask, void* stream) {
@@ -2081,7 +2108,7 @@ int dimx_op_attention(int dtype, const void* q, const void* k, const void* vt, v
     a.lens = lens;
     a.kmask = kmask;
     a.kmask_ld = Lk;
-    return launch_attention(a, (hipStream_t)stream);
+    return op_attention_with_scratch(a, (hipStream_t)stream);
 }
 
 int dimx_op_attention_rowv(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk, int D, int ldq,
@@ -2102,7 +2129,7 @@ int dimx_op_attention_rowv(const void* q, const void* k, const void* v, void* ou
     a.lens = lens;
     a.kmask = kmask;
     a.kmask_ld = Lk;
-    return launch_attention(a, (hipStream_t)stream);
+    return op_attention_with_scratch(a, (hipStream_t)stream);
 }
 
 int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void* vcache, void* out, int B, int H,

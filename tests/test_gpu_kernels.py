@@ -106,6 +106,29 @@ def test_gemm_loader_consumer_kernel(dev, M, N, K, S, act, cfg, bf16):
     assert _err(out, ref) < (0.05 if kw.get("out_bf16") else (2e-3 if bf16 else 1e-4))
 
 
+@pytest.mark.parametrize("M,N,K,S,act", [(256, 4608, 1152, 0, 3), (256, 2304, 1152, 2, 0), (256, 1152, 4608, 4, 0),
+                                         (200, 1152, 768, 2, 0), (1, 1152, 1152, 0, 0), (33, 4608, 1152, 0, 3),
+                                         (256, 144, 64, 0, 1), (256, 1152, 4608, 8, 0)])
+def test_gemm_one_block_per_cu_kernel(dev, M, N, K, S, act):
+    """round 5: the decode GEMM on 64 x 72 tiles (cfg 72; what M <= 256, N % 72 == 0 takes by default): same k order and the
+    same split partition as the 64 x 64 kernels -> bit-identical results; ragged M, a single row, a single k-tile, slabs;
+    columns 72..95 of the third MFMA column block are never stored (the neighbouring tile's columns stay intact)."""
+    from dimx import engine
+    g = torch.Generator().manual_seed(M + N + K + S)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    ref = ACTS[act](_bf(a).double() @ _bf(w).double().t() + bias.double())
+    kw = dict(bf16=True, slabs=S) if S else dict(bf16=True, out_bf16=act == 3)
+    new = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, cfg=72, **kw)
+    old = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, cfg=3, **kw)
+    auto = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, **kw)   # the default route
+    assert torch.equal(new, old)
+    if not S:
+        assert torch.equal(auto, old)
+    out = new.sum(0) if S else new.float()
+    assert _err(out, ref) < (0.05 if kw.get("out_bf16") else 2e-3)
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_gemm_bf16_out(dev, bf16):
     from dimx import engine
