@@ -1473,7 +1473,7 @@ static inline void cfg_tile(int cfg, int& bm, int& bn) {
         case 17: case 18: case 27: case 31: bm = 256; bn = 128; break;
         case 19: case 28: bm = 256; bn = 256; break;
         case 8: bm = 64; bn = 128; break;
-        case 72: bm = 64; bn = 72; break;
+        case 72: case 73: bm = 64; bn = 72; break;
         default: bm = 64; bn = 64; break;
     }
 }
@@ -1533,6 +1533,9 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
             a.vt_pack4 = pack ? 1 : 0;
         }
     }
+    if constexpr (sizeof(T) == 2) {
+        if ((cfg == 72 && a.cfg == 0 && gemm_dec_eligible(a)) || cfg == 73) return launch_gemm_dec(a, s);
+    }
     return launch_by_cfg<T, OutT>(a, cfg, s);
 }
 
@@ -1578,7 +1581,7 @@ int gemm_plan_splits(const GemmArgs& a) {
         return best;
     }
     if (tiles >= 256) return 1;
-    if (cfg == 72) {
+    if (cfg == 72 || cfg == 73) {
         // one block per CU and no more (round 5, profiles/r05_gemm_blocks.txt): the largest split count that keeps the launch within
         // 256 blocks with at least min_nk k-tiles per block
         static const int min_nk72 = getenv("DIMX_SPLIT_MINNK") ? atoi(getenv("DIMX_SPLIT_MINNK")) : 6;
