@@ -269,8 +269,6 @@ struct GemmArgs {
     int tile_map;      // set by the launcher (prefill): 1 = every XCD works on one half of the N tiles of a quarter of the
                        // M tiles, so that its share of W (N/2 x K) stays L2-resident while the A panels stream through
     int vt_pack4;      // set by the launcher: transposed (time-contiguous) segments take 4 packed rows per store
-    const void* w_frag;  // optional: the same weights in MFMA fragment order (gemm_dec.hip, launch_pack_w_frag); decode-sized
-                         // GEMMs with a plain destination then take gemm_dec_kernel (W streams into registers, not through LDS)
 };
 
 void gemm_args_init(GemmArgs& a);
@@ -285,11 +283,6 @@ int launch_gemm256(const GemmArgs& a, hipStream_t s);
 int launch_gemm256_segs(const GemmArgs& a, const OutSeg* segs, int nseg, int seg_width, hipStream_t s);
 // number of K splits launch_gemm will use for an out_slabs GEMM (the consumer needs it)
 int gemm_plan_splits(const GemmArgs& a);
-// gemm_dec.hip: the decode step's chip-wide GEMMs on fragment-packed weights
-size_t gemm_dec_frag_bytes(int N, int K);  // 0 when the shape has no fragment form (N % 72, K % 64)
-int launch_pack_w_frag(const void* W, int ldw, int N, int K, void* out, hipStream_t s);
-bool gemm_dec_eligible(const GemmArgs& a);
-int launch_gemm_dec(const GemmArgs& a, hipStream_t s);  // a.splitk set by the caller (launch_gemm)
 
 // ---------------------------------------------------------------- other launchers
 int launch_layernorm(int out_dtype, const float* x, void* y, const float* gamma, const float* beta, int M,

@@ -1115,22 +1115,27 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
 // vmcnt waits are instantiated per loader).  The W fragment reads of the third column block run past the 72 rows that were
 // loaded (into the next ring slot / the slack behind the ring): whatever they find only reaches accumulator columns that are
 // never stored (n_lim).  bf16 operands only; M and N edges are clamped like in gemm_ws_kernel.
-template <typename OutT, bool PROF>
+// KT (round 5, second step): k-tiles per ring slot = per block barrier.  KT = 2: three slots of two k-tiles; the consumers request
+// the fragments of a slot's second k-tile before the first one's MFMAs start (its LDS latency disappears behind them) and meet
+// the loaders half as often.
+template <typename OutT, bool PROF, int KT>
 struct Ws72 {
-    static constexpr int BM = 64, BN = 72, BK = 64, STAGES = 4, NLOAD = 4, NCONS = 6;
+    static constexpr int BM = 64, BN = 72, BK = 64, STAGES = KT == 1 ? 4 : 3, NLOAD = 4, NCONS = 6;
     static constexpr int TILE_BYTES = (BM + BN) * 128;
+    static constexpr int SLOT_BYTES = KT * TILE_BYTES;
     // + the rows 72..95 read behind the last slot; and never less than 84 KiB: two blocks must NOT fit a CU.  Launched into an idle
     // GPU the 256 blocks land one per CU, but behind another kernel the dispatcher hands a CU that drained early a second block
     // while others still wait for their first (LDS and waves would allow it) -- and the doubled CUs set the launch time again:
     // 8.8 us by in-kernel stamps (isolated launches) against 10.4 us back to back (profiles/r05_gemm_ws72.txt)
-    static constexpr int RING_BYTES = STAGES * TILE_BYTES + 24 * 128;
+    static constexpr int RING_BYTES = STAGES * SLOT_BYTES + 24 * 128;
     static constexpr int SMEM_BYTES = RING_BYTES > 84 * 1024 ? RING_BYTES : 84 * 1024;
+    static_assert((STAGES - 2) * KT == 2, "the loaders' counted waits below are written for two k-tiles in flight behind the current slot");
 
     template <int LW>  // W pieces of this loader wave (3 for loader 0, 2 for the others)
     static __device__ __forceinline__ void loader(const GemmArgs& a, int block_id, int lw, int lane, int m0, int n0, int kt0, int nk,
                                                   unsigned char* smem, float* ln_sm) {
         constexpr int LA = 2, LPT = LA + LW;
-        static_assert((STAGES - 1) * LPT < 64, "ring depth");
+        static_assert((STAGES - 1) * KT * LPT < 56, "ring depth");
         auto stamp = [&](int i) {
             if (PROF && lane == 0 && lw == 0 && i < 32) a.prof[(size_t)block_id * 64 + 32 + i] = wall_clock64();
         };
@@ -1157,15 +1162,22 @@ struct Ws72 {
             n = n < a.N ? n : a.N - 1;
             gW[j] = W + (size_t)n * a.ldw + c * 8 + (size_t)kt0 * BK;
         }
-        auto issue = [&](int kt, int buf) {
-            unsigned char* base = smem + buf * TILE_BYTES;
+        const int nst = (nk + KT - 1) / KT;
+        auto issue = [&](int st, int slot) {  // the k-tiles of slot st that exist (the last slot of an odd count holds one)
 #pragma unroll
-            for (int j = 0; j < LA; ++j)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(gA[j] + (size_t)kt * BK), (lds_void_t*)(base + pA[j] * 1024), 16, 0, 0);
+            for (int t = 0; t < KT; ++t) {
+                const int kt = st * KT + t;
+                if (kt < nk) {
+                    unsigned char* base = smem + slot * SLOT_BYTES + t * TILE_BYTES;
 #pragma unroll
-            for (int j = 0; j < LW; ++j)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(gW[j] + (size_t)kt * BK), (lds_void_t*)(base + BM * 128 + pW[j] * 1024), 16, 0,
-                                                 0);
+                    for (int j = 0; j < LA; ++j)
+                        __builtin_amdgcn_global_load_lds((glb_void_t*)(gA[j] + (size_t)kt * BK), (lds_void_t*)(base + pA[j] * 1024), 16, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < LW; ++j)
+                        __builtin_amdgcn_global_load_lds((glb_void_t*)(gW[j] + (size_t)kt * BK), (lds_void_t*)(base + BM * 128 + pW[j] * 1024),
+                                                         16, 0, 0);
+                }
+            }
         };
         // deferred LayerNorm of the A rows: as in gemm_ws_body (loader lw reduces the partial sums of rows lw * 16 + (lane & 15))
         float2 lp[8];
@@ -1176,20 +1188,30 @@ struct Ws72 {
 #pragma unroll
             for (int i = 0; i < 8; ++i) lp[i] = sp[(size_t)i * 32];
         }
-#pragma unroll
-        for (int st = 0; st < STAGES - 1; ++st)
-            if (st < nk) issue(st, st);
+        int issued = 0;
+        for (; issued < STAGES - 1 && issued < nst; ++issued) issue(issued, issued);
         stamp(1);
-        for (int it = 0; it < nk; ++it) {
-            if (it < 12) stamp(2 + 2 * it);
-            if (nk - 1 - it < STAGES - 2)
-                wait_vmcnt<0>();
-            else
-                wait_vmcnt<(STAGES - 2) * LPT>();
-            if (it < 12) stamp(3 + 2 * it);
+        int slot_next = issued % STAGES;
+        const int st_ln = nst >= 2 ? nst - 2 : 0;
+        for (int st = 0; st < nst; ++st) {
+            if (st < 12) stamp(2 + 2 * st);
+            {   // this wave's pieces of slot st have landed once no more than the pieces of the k-tiles issued BEHIND it are in flight
+                int done = (st + 1) * KT, all = issued * KT;
+                done = done < nk ? done : nk;
+                all = all < nk ? all : nk;
+                const int y = all - done;  // 0, 1 or 2 k-tiles
+                if (y <= 0) wait_vmcnt<0>();
+                else if (y == 1) wait_vmcnt<LPT>();
+                else wait_vmcnt<2 * LPT>();
+            }
+            if (st < 12) stamp(3 + 2 * st);
             __builtin_amdgcn_s_barrier();
-            if (it + STAGES - 1 < nk) issue(it + STAGES - 1, (it + STAGES - 1) % STAGES);
-            if (a.ln_stats && it == nk - 2) {
+            if (issued < nst) {
+                issue(issued, slot_next);
+                ++issued;
+                slot_next = slot_next + 1 == STAGES ? 0 : slot_next + 1;
+            }
+            if (a.ln_stats && st == st_ln) {
                 float s1 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s1 += lp[i].x;
@@ -1272,26 +1294,55 @@ struct Ws72 {
         float bias_pre[1];
         bias_pre[0] = (a.bias && split == 0) ? a.bias[ncl] : 0.f;
         const float ln_cs = a.ln_stats ? a.ln_colsum[ncl] : 0.f;
-        for (int it = 0; it < nk; ++it) {
-            const unsigned boff = (unsigned)((it % STAGES) * TILE_BYTES);
-            if (it < 12) stamp(2 + 2 * it);
+        const int nst = (nk + KT - 1) / KT;
+        unsigned boff = 0;
+        for (int st = 0; st < nst; ++st) {
+            if (st < 12) stamp(2 + 2 * st);
             __builtin_amdgcn_s_barrier();
-            if (it < 12) stamp(3 + 2 * it);
-            u32x4_t fa[4][1], fw[4][1];
+            if (st < 12) stamp(3 + 2 * st);
+            u32x4_t fa[KT][4][1], fw[KT][4][1];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                ds_read128<0>(fa[q][0], aoff[q] + boff);
-                ds_read128<0>(fw[q][0], woff[q] + boff);
+                ds_read128<0>(fa[0][q][0], aoff[q] + boff);
+                ds_read128<0>(fw[0][q][0], woff[q] + boff);
             }
+            const bool two = KT == 2 && st * KT + 1 < nk;  // wave-uniform
+            if (two) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q == 0) wait_lgkm<6>();
-                if (q == 1) wait_lgkm<4>();
-                if (q == 2) wait_lgkm<2>();
-                if (q == 3) wait_lgkm<0>();
-                __builtin_amdgcn_sched_barrier(0);
-                FragMma<bf16, 1, 1>::run(acc, fa[q], fw[q]);
+                for (int q = 0; q < 4; ++q) {
+                    ds_read128<0>(fa[KT - 1][q][0], aoff[q] + boff + TILE_BYTES);
+                    ds_read128<0>(fw[KT - 1][q][0], woff[q] + boff + TILE_BYTES);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q == 0) wait_lgkm<14>();
+                    if (q == 1) wait_lgkm<12>();
+                    if (q == 2) wait_lgkm<10>();
+                    if (q == 3) wait_lgkm<8>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    FragMma<bf16, 1, 1>::run(acc, fa[0][q], fw[0][q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q == 0) wait_lgkm<6>();
+                    if (q == 1) wait_lgkm<4>();
+                    if (q == 2) wait_lgkm<2>();
+                    if (q == 3) wait_lgkm<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    FragMma<bf16, 1, 1>::run(acc, fa[KT - 1][q], fw[KT - 1][q]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q == 0) wait_lgkm<6>();
+                    if (q == 1) wait_lgkm<4>();
+                    if (q == 2) wait_lgkm<2>();
+                    if (q == 3) wait_lgkm<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    FragMma<bf16, 1, 1>::run(acc, fa[0][q], fw[0][q]);
+                }
             }
+            boff = boff + SLOT_BYTES == STAGES * SLOT_BYTES ? 0u : boff + SLOT_BYTES;
         }
         stamp(28);
         if (a.ln_stats) {
@@ -1315,19 +1366,23 @@ struct Ws72 {
     }
 };
 
-template <typename OutT, bool PROF = false>
+template <typename OutT, bool PROF = false, int KT = 2>
 __global__ __launch_bounds__(640) void gemm_ws72_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Ws72<OutT, PROF>::SMEM_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Ws72<OutT, PROF, KT>::SMEM_BYTES];
     __shared__ __attribute__((aligned(16))) float ln_sm[128];
-    Ws72<OutT, PROF>::body(a, blockIdx.x, gridDim.x, smem, ln_sm);
+    Ws72<OutT, PROF, KT>::body(a, blockIdx.x, gridDim.x, smem, ln_sm);
 }
 
 template <typename OutT> static int launch_ws72(const GemmArgs& a, hipStream_t s) {
     const int tiles = ceil_div(a.M, 64) * ceil_div(a.N, 72);
-    if (a.prof)
-        hipLaunchKernelGGL((gemm_ws72_kernel<OutT, true>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
-    else
-        hipLaunchKernelGGL((gemm_ws72_kernel<OutT, false>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
+    static const int kt = getenv("DIMX_WS72_KT") ? atoi(getenv("DIMX_WS72_KT")) : 1;  // k-tiles per barrier; 2 measured SLOWER (1624 vs 1653 clips/s, profiles/r05_gemm_ws72.txt)
+    if (a.prof) {
+        if (kt == 1) hipLaunchKernelGGL((gemm_ws72_kernel<OutT, true, 1>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
+        else hipLaunchKernelGGL((gemm_ws72_kernel<OutT, true, 2>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
+    } else {
+        if (kt == 1) hipLaunchKernelGGL((gemm_ws72_kernel<OutT, false, 1>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
+        else hipLaunchKernelGGL((gemm_ws72_kernel<OutT, false, 2>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
+    }
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }
@@ -1473,7 +1528,7 @@ static inline void cfg_tile(int cfg, int& bm, int& bn) {
         case 17: case 18: case 27: case 31: bm = 256; bn = 128; break;
         case 19: case 28: bm = 256; bn = 256; break;
         case 8: bm = 64; bn = 128; break;
-        case 72: case 73: bm = 64; bn = 72; break;
+        case 72: bm = 64; bn = 72; break;
         default: bm = 64; bn = 64; break;
     }
 }
@@ -1533,9 +1588,6 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
             a.vt_pack4 = pack ? 1 : 0;
         }
     }
-    if constexpr (sizeof(T) == 2) {
-        if ((cfg == 72 && a.cfg == 0 && gemm_dec_eligible(a)) || cfg == 73) return launch_gemm_dec(a, s);
-    }
     return launch_by_cfg<T, OutT>(a, cfg, s);
 }
 
@@ -1581,7 +1633,7 @@ int gemm_plan_splits(const GemmArgs& a) {
         return best;
     }
     if (tiles >= 256) return 1;
-    if (cfg == 72 || cfg == 73) {
+    if (cfg == 72) {
         // one block per CU and no more (round 5, profiles/r05_gemm_blocks.txt): the largest split count that keeps the launch within
         // 256 blocks with at least min_nk k-tiles per block
         static const int min_nk72 = getenv("DIMX_SPLIT_MINNK") ? atoi(getenv("DIMX_SPLIT_MINNK")) : 6;

@@ -291,23 +291,6 @@ static int pack_linear_scaled(dimx_ctx* c, const std::string& wname, const std::
     return DIMX_OK;
 }
 
-// decode step (bf16): a second copy of a chip-wide projection's weights in MFMA fragment order (gemm_dec.hip); shapes without a
-// fragment form (N % 72, K % 64) keep the row-major copy only
-static int pack_frag(dimx_ctx* c, Linear* L) {
-    L->w_frag = nullptr;
-    static const bool off = getenv("DIMX_NO_GEMM_DEC") != nullptr;
-    if (off || c->at != DIMX_BF16 || !L->w || L->K != L->Kp) return DIMX_OK;
-    const size_t bytes = gemm_dec_frag_bytes(L->N, L->K);
-    if (!bytes) return DIMX_OK;
-    void* p = nullptr;
-    DIMX_HIP(hipMalloc(&p, bytes));
-    c->dev_allocs.push_back(p);
-    DIMX_TRY(launch_pack_w_frag(L->w, L->Kp, L->N, L->K, p, nullptr));
-    DIMX_HIP(hipDeviceSynchronize());
-    L->w_frag = p;
-    return DIMX_OK;
-}
-
 // the feed-forward sublayer's weights as the chunk images of mlp_fused.hip (bf16 perf mode, width 384; DIMX_NO_FUSED_MLP=1 keeps
 // the LayerNorm + two-GEMM form for A/B runs)
 static int pack_mlp(dimx_ctx* c, const std::string& w1, const std::string& b1, const std::string& w2, const void** out) {
@@ -498,12 +481,7 @@ static int ensure_packed(dimx_ctx* c, int need) {
                                                 &c->dec.cross[i].q_ln_colsum));
                     DIMX_TRY(pack_linear_scaled(c, fp + "1.ff.0.0.weight", fp + "0.0.weight", fp + "1.ff.0.0.bias",
                                                 &c->dec.ff[i].f1_ln, &c->dec.ff[i].f1_ln_colsum));
-                    DIMX_TRY(pack_frag(c, &c->dec.ff[i].f1_ln));
                 }
-                // the chip-wide projections of the decode step in fragment order (gemm_dec.hip)
-                DIMX_TRY(pack_frag(c, &c->dec.self_[i].qkv));
-                DIMX_TRY(pack_frag(c, &c->dec.ff[i].f1));
-                DIMX_TRY(pack_frag(c, &c->dec.ff[i].f2));
             }
             DIMX_TRY(upload_f32(c, dp + "attn_layers.final_norm.weight", &c->dec.final_g));
             DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, "", false, &c->dec.logits));
@@ -546,7 +524,6 @@ static int gemm_lin(const dimx_ctx* c, const void* A, int lda, const Linear& L, 
     g.K = L.K;
     g.bias = L.bias;
     g.allow_splitk = c->at == DIMX_BF16 ? 1 : 0;  // parity mode keeps a fixed summation order
-    g.w_frag = M <= 256 ? L.w_frag : nullptr;     // decode-sized launches only (gemm_dec.hip)
     return DIMX_OK;
 }
 
@@ -2390,51 +2367,6 @@ int dimx_op_gemm_ln(int out_dtype, const void* A, const void* Ws, void* C, int M
         g.bias = nullptr;
     }
     gemm_set_plain_out(g, C, N);
-    void* frag = nullptr;
-    const size_t fb = gemm_dec_frag_bytes(N, K);
-    if (fb && !getenv("DIMX_NO_GEMM_DEC")) { /* the decode step's route: fragment-packed weights (gemm_dec.hip) */
-        DIMX_HIP(hipMallocAsync(&frag, fb, (hipStream_t)stream));
-        DIMX_TRY(launch_pack_w_frag(Ws, K, N, K, frag, (hipStream_t)stream));
-        g.w_frag = frag;
-    }
-    const int rc = launch_gemm(g, (hipStream_t)stream);
-    if (frag) DIMX_HIP(hipFreeAsync(frag, (hipStream_t)stream));
-    return rc;
-}
-
-size_t dimx_w_frag_bytes(int N, int K) { return gemm_dec_frag_bytes(N, K); }
-
-int dimx_op_pack_w_frag(const void* W, int ldw, int N, int K, void* w_frag, void* stream) {
-    DIMX_REQUIRE(W && w_frag, DIMX_ERR_ARG, "op_pack_w_frag: null argument");
-    return launch_pack_w_frag(W, ldw, N, K, w_frag, (hipStream_t)stream);
-}
-
-int dimx_op_gemm_dec(const void* A, int lda, const void* w_frag, void* C, int ldc, int out_dtype, int M, int N, int K,
-                     const float* bias, int act, int slabs, const float* ln_stats, const float* ln_colsum, void* prof,
-                     void* stream) {
-    DIMX_REQUIRE(A && w_frag && C && M >= 1 && M <= 256 && slabs >= 0 && slabs <= 8, DIMX_ERR_ARG, "op_gemm_dec: bad argument");
-    GemmArgs g;
-    gemm_args_init(g);
-    g.in_dtype = DIMX_BF16;
-    g.out_dtype = slabs ? DIMX_F32 : out_dtype;
-    g.A = A; g.lda = lda;
-    g.W = w_frag; g.ldw = K;   /* the row-major copy is not needed on this route */
-    g.w_frag = w_frag;
-    g.M = M; g.N = N; g.K = K;
-    g.bias = bias;
-    g.act = act;
-    g.ln_stats = ln_stats;
-    g.ln_colsum = ln_colsum;
-    g.ln_C = K;
-    g.prof = (unsigned long long*)prof;
-    if (slabs) {
-        g.out_slabs = 1;
-        g.allow_splitk = 1;
-        g.force_splitk = slabs;
-        g.slab_stride = (long)M * ldc;
-    }
-    gemm_set_plain_out(g, C, ldc);
-    g.cfg = 73;   /* this kernel or an error, never another route */
     return launch_gemm(g, (hipStream_t)stream);
 }
 

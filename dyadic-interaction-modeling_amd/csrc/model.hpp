@@ -12,7 +12,6 @@ struct Linear {
     void* w = nullptr;  // [N][Kp] in the handle's operand type (bf16 / f32)
     const float* bias = nullptr;
     int N = 0, K = 0, Kp = 0;
-    const void* w_frag = nullptr;  // decoder, bf16 mode: the same weights in MFMA fragment order (gemm_dec.hip) for the decode step
 };
 
 struct VQBlock {

@@ -301,34 +301,6 @@ def op_gemm(a, w, bias=None, act=0, residual=None, bf16=False, out_bf16=False, c
     return out
 
 
-def op_pack_w_frag(w):
-    """w [N,K] -> the same weights (bf16) in MFMA fragment order for op_gemm_dec (csrc/gemm_dec.hip); raises when the shape has no
-    fragment form (N % 72, K % 64)."""
-    lib = L.load()
-    N, K = w.shape
-    nbytes = lib.dimx_w_frag_bytes(N, K)
-    if not nbytes:
-        raise L.DimxError("no fragment form for N=%d K=%d" % (N, K))
-    wb = w.to(torch.bfloat16).contiguous()
-    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    L.check(lib.dimx_op_pack_w_frag(L.ptr(wb), K, N, K, L.ptr(out), L.stream_ptr(w.device)), "dimx_op_pack_w_frag")
-    return out
-
-
-def op_gemm_dec(a, w_frag, N, bias=None, act=0, out_bf16=False, slabs=0, stats=None, colsum=None, prof=None):
-    """the decode step's chip-wide projection: act(a[M,K] . W^T + bias) on fragment-packed weights, M <= 256."""
-    lib = L.load()
-    a_ = a.to(torch.bfloat16).contiguous()
-    M, K = a_.shape
-    if slabs:
-        out = torch.full((slabs, M, N), float("nan"), dtype=torch.float32, device=a.device)
-    else:
-        out = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
-    L.check(lib.dimx_op_gemm_dec(L.ptr(a_), K, L.ptr(w_frag), L.ptr(out), N, L.BF16 if out_bf16 else L.F32, M, N, K, L.ptr(bias),
-                                 act, slabs, L.ptr(stats), L.ptr(colsum), L.ptr(prof), L.stream_ptr(a.device)), "dimx_op_gemm_dec")
-    return out
-
-
 def op_layernorm(x, gamma, beta=None, out_bf16=False):
     lib = L.load()
     M, C = x.shape

@@ -119,10 +119,6 @@ SIGNATURES = {
                               c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dimx_op_chain_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "dimx_w_frag_bytes": (c_size_t, [c_int, c_int]),
-    "dimx_op_pack_w_frag": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "dimx_op_gemm_dec": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
-                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "dimx_op_gemm_ln": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p]),
     "dimx_op_sample": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p,

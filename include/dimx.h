@@ -371,17 +371,6 @@ int dimx_op_chain_ln(const void* A1, int K1, const void* W1, float* x, void* y, 
  * Ws[n][k]; out_dtype DIMX_BF16 / DIMX_F32; M <= 256. */
 int dimx_op_gemm_ln(int out_dtype, const void* A, const void* Ws, void* C, int M, int N, int K, const float* bias, int act,
                     const float* stats, const float* colsum, void* stream);
-/* The decode step's chip-wide projections (csrc/gemm_dec.hip; the fused q/k/v and feed-forward projections of one
- * AutoregressiveWrapper.generate step, reference code/seq2seq_pretrain.py:450): W[N,K] bf16 row-major is packed ONCE into MFMA
- * fragment order (dimx_op_pack_w_frag into dimx_w_frag_bytes(N, K) bytes; 0 = the shape has no fragment form: N % 72, K % 64),
- * then C = act(A[M,K] . W^T + bias) with M <= 256 rows: slabs == 0 -> C[M,ldc] in out_dtype; slabs > 0 -> `slabs` f32 split-K
- * partial sums C[s][M,ldc] that the consumer adds in slab order; act 0 / 3 (erf-GELU); ln_stats / ln_colsum as dimx_op_gemm_ln
- * (W then holds gamma o W); prof: tuning only (NULL). */
-size_t dimx_w_frag_bytes(int N, int K);
-int dimx_op_pack_w_frag(const void* W, int ldw, int N, int K, void* w_frag, void* stream);
-int dimx_op_gemm_dec(const void* A, int lda, const void* w_frag, void* C, int ldc, int out_dtype, int M, int N, int K,
-                     const float* bias, int act, int slabs, const float* ln_stats, const float* ln_colsum, void* prof,
-                     void* stream);
 /* tokens = sampler(logits[R,512]) -- see dimx_generate. */
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise,
                    uint64_t seed, uint64_t step, int32_t* tokens, void* stream);

@@ -129,40 +129,6 @@ def test_gemm_one_block_per_cu_kernel(dev, M, N, K, S, act):
     assert _err(out, ref) < (0.05 if kw.get("out_bf16") else 2e-3)
 
 
-@pytest.mark.parametrize("M,N,K,S,act", [(256, 4608, 1152, 0, 3), (256, 2304, 1152, 2, 0), (256, 1152, 4608, 4, 0),
-                                         (200, 1152, 768, 2, 0), (1, 1152, 1152, 0, 0), (33, 4608, 1152, 0, 3),
-                                         (256, 144, 64, 0, 0), (256, 1152, 4608, 8, 0), (64, 2304, 1152, 3, 0),
-                                         (256, 1152, 448, 0, 0)])
-def test_decode_gemm_on_fragment_packed_weights(dev, M, N, K, S, act):
-    """round 5: gemm_dec_kernel -- the decode step's chip-wide projections with W packed in MFMA fragment order and streamed
-    into registers, A through an LDS ring, two k-halves per column block combined in a fixed order: against float64 on the
-    bf16-rounded operands, against the 64 x 64 LDS kernel (same products, another summation order), reruns bit-identical,
-    ragged M, a single row, one k-tile, odd k-tile counts per split, slabs; row m of a larger batch == row m alone."""
-    from dimx import engine
-    g = torch.Generator().manual_seed(M + N + K + S)
-    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
-    bias = torch.randn(N, generator=g)
-    ref = ACTS[act](_bf(a).double() @ _bf(w).double().t() + bias.double())
-    kw = dict(bf16=True, slabs=S) if S else dict(bf16=True, out_bf16=act == 3)
-    if K % 64:
-        with pytest.raises(RuntimeError):
-            engine.op_pack_w_frag(w.to(dev))
-        return
-    wf = engine.op_pack_w_frag(w.to(dev))
-    kd = dict(slabs=S) if S else dict(out_bf16=act == 3)
-    new = engine.op_gemm_dec(a.to(dev), wf, N, bias.to(dev), act, **kd)
-    again = engine.op_gemm_dec(a.to(dev), wf, N, bias.to(dev), act, **kd)
-    old = engine.op_gemm(a.to(dev), w.to(dev), bias.to(dev), act, None, cfg=3, **kw)
-    assert torch.equal(new, again)
-    out, out_old = (new.sum(0), old.sum(0)) if S else (new.float(), old.float())
-    tol = 0.05 if kw.get("out_bf16") else 2e-3
-    assert _err(out, ref) < tol
-    assert _err(out, out_old) < (0.05 if kw.get("out_bf16") else 2e-5)
-    if M > 8:   # rows are independent of the batch around them (a rank's shard reproduces the whole batch)
-        sub = engine.op_gemm_dec(a[3:7].to(dev), wf, N, bias.to(dev), act, **kd)
-        assert torch.equal(sub, new[:, 3:7] if S else new[3:7])
-
-
 @pytest.mark.parametrize("bf16", [False, True])
 def test_gemm_bf16_out(dev, bf16):
     from dimx import engine

@@ -50,13 +50,13 @@ if len(sys.argv) > 2 and sys.argv[2] == "frag":   # gemm_dec_kernel only (run on
     json.dump(plan, open(sys.argv[1], "w"))
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "ws72":   # the real shapes: 64 x 64 tiles (cfg 34, 288 blocks) vs 64 x 72 (cfg 72, 256 blocks)
-    for cfg, fr in ((34, False), (72, False), (0, True)):
+    for cfg, fr in ((34, False), (72, False)):
         run("ff1 N4608 K1152 gelu bf16-out", 4608, 1152, 3, True, 0, True, cfg=cfg, frag=fr)
-    for cfg, fr in ((34, False), (72, False), (0, True)):
+    for cfg, fr in ((34, False), (72, False)):
         run("ff2 N1152 K4608 4 slabs", 1152, 4608, 0, False, 4, False, cfg=cfg, frag=fr)
-    for cfg, fr in ((34, False), (72, False), (0, True)):
+    for cfg, fr in ((34, False), (72, False)):
         run("qkv N2304 K1152 2 slabs", 2304, 1152, 0, False, 2, False, cfg=cfg, frag=fr)
-    for cfg, fr in ((34, False), (72, False), (0, True)):
+    for cfg, fr in ((34, False), (72, False)):
         run("self-out N1152 K768 2 slabs", 1152, 768, 0, False, 2, False, cfg=cfg, frag=fr)
     json.dump(plan, open(sys.argv[1], "w"))
     sys.exit(0)

@@ -1,4 +1,5 @@
-"""In-kernel wall-clock stamps (100 MHz) of a decode GEMM block, any shape / kernel (round 5):
+"""(the cfg 73 / gemm_dec route exists at commit 044eb4c only)
+In-kernel wall-clock stamps (100 MHz) of a decode GEMM block, any shape / kernel (round 5):
     DIMX_GEMM_PROF=1 python tools/r05_gemm_stamps.py CFG N K SLABS ACT
 CFG 34 = 64 x 64 loader/consumer kernel, 72 = 64 x 72 one-block-per-CU kernel."""
 import os
