@@ -16,7 +16,10 @@
 // The weights of a phase are read once per XCD (8x the chip-wide GEMM's fabric traffic, measured 7 TB/s), which is why
 // only the small projections (attention out / cross-q / logits: 0.6-1.8 MB each) take this path and the feed-forward
 // and fused-qkv GEMMs (5-11 MB) stay chip-wide launches.
+#include <algorithm>
+
 #include "common.hpp"
+#include "decode_attn_body.hpp"
 
 namespace dimx {
 namespace {
@@ -509,6 +512,302 @@ __global__ __launch_bounds__(kThreads) void xcd_chain_kernel(const ChainArgs a) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// xcd_layer_kernel (round 5): the attention half of a decoder layer as ONE launch.
+//
+// Before: self attention | chain A {out-projection + residual, cross-q} | cross attention | chain B {out-projection + residual}
+// = four launches per layer, each paying the launch floor (2.1 us for an empty 256-block kernel, profiles/r05_gemm_dec_experiment.txt),
+// and the two chain launches a 3 us weight burst before their first MFMA.  Clip i of group g is CU slot i of XCD g in the chain
+// kernels already; give that CU the clip's 12 (clip, head) attention waves as well and every hand-off of the four stages stays
+// inside the XCD: four group barriers instead of three kernel boundaries, and the projections' weight slices are requested by
+// a thirteenth wave while the attention waves stream their K/V caches (HBM-bound, 23-38 us: the bursts disappear behind them).
+//   waves 0-11: one (clip, head) pair each during the attentions (decode_attn_body, unchanged: the kernel stays a pure stream);
+//               waves 0-7 run the MFMA phases (8-way split K, fixed-order LDS reduce, as in xcd_chain_kernel)
+//   wave 12:    issues the weight-slice LDS-DMAs (its own vmcnt: nothing the attention waves wait for)
+// Deferred LayerNorm throughout (the form xcd_chain_kernel<.., DEFER> runs): x, bf16(x) and the partial row sums are written by
+// the CU that owns the column slice; cross-q corrects its result with {mean, rstd}; the last stage leaves the statistics for the
+// feed-forward GEMM's epilogue (GemmArgs.ln_stats).  The cross-attention query is read with L1-bypassing loads (QSC1): it was
+// written by the XCD's other CUs during this launch.
+constexpr int kLayerWaves = 13, kLayerThreads = kLayerWaves * 64, kAttnWaves = 12;
+
+// waves 0-7: partial tiles -> LDS -> summed in wave order; + residual slice; x, y = bf16(x), partial statistics of the slice
+// (reduce_store_defer for a block of 13 waves: the block barriers are met by every wave, the work is done by the first 8)
+template <int NCB>
+__device__ __forceinline__ void layer_reduce_defer(const f32x16_t (&acc)[NCB], float* red, const float (&xs)[2 * NCB], float* x, bf16* y,
+                                                   int C, float* stats, int row0, int nrows, int n0, int ncols, int wave, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+    const bool mf = wave < kWaves;
+    __syncthreads();  // every wave is done with the panels the scratch aliases
+    if (mf) {
+#pragma unroll
+        for (int j = 0; j < NCB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[((wave * NCB + j) * 32 + m) * 32 + l31] = acc[j][r];
+            }
+    }
+    __syncthreads();
+    if (!mf) return;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, xv[2 * NCB];
+    bool ok[2 * NCB];
+#pragma unroll
+    for (int i = 0; i < 2 * NCB; ++i) {
+        const int e = threadIdx.x + i * kThreads;
+        const int j = e >> 10, m = (e >> 5) & 31, n = e & 31;
+        float v = red[((0 * NCB + j) * 32 + m) * 32 + n];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[((w * NCB + j) * 32 + m) * 32 + n];
+        const int col = j * 32 + n;
+        ok[i] = col < ncols && m < nrows;
+        xv[i] = 0.f;
+        if (ok[i]) {
+            const float xp = xs[i] + v;
+            const size_t o = (size_t)(row0 + m) * C + n0 + col;
+            x[o] = xp;
+            y[o].x = f32_to_bf16(xp);
+            xv[i] = xp;
+            s1[i & 1] += xp;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        s1[k] = row16_sum(s1[k]);
+        s1[k] += xor_lane_f32<16>(s1[k]);
+    }
+    const float inv_n = 1.0f / (float)ncols;
+#pragma unroll
+    for (int i = 0; i < 2 * NCB; ++i) {
+        const float d = xv[i] - s1[i & 1] * inv_n;
+        if (ok[i]) s2[i & 1] += d * d;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        s2[k] = row16_sum(s2[k]);
+        s2[k] += xor_lane_f32<16>(s2[k]);
+    }
+    if (l31 == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = (threadIdx.x >> 5) + 16 * k;
+            stats[2 * m] = s1[k];
+            stats[2 * m + 1] = s2[k];
+        }
+    }
+}
+
+template <int NCB>
+__device__ __forceinline__ void layer_reduce_ln(const f32x16_t (&acc)[NCB], float* red, float* out, long ld_out, int row0, int nrows,
+                                                int n0, int ncols, const float* mr, const float* colsum, int wave, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+    const bool mf = wave < kWaves;
+    __syncthreads();
+    if (mf) {
+#pragma unroll
+        for (int j = 0; j < NCB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[((wave * NCB + j) * 32 + m) * 32 + l31] = acc[j][r];
+            }
+    }
+    __syncthreads();
+    if (!mf) return;
+    for (int e = threadIdx.x; e < NCB * 1024; e += kThreads) {
+        const int j = e >> 10, m = (e >> 5) & 31, n = e & 31;
+        float v = red[((0 * NCB + j) * 32 + m) * 32 + n];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[((w * NCB + j) * 32 + m) * 32 + n];
+        const int col = j * 32 + n;
+        if (col < ncols && m < nrows) out[(size_t)(row0 + m) * ld_out + n0 + col] = mr[2 * m + 1] * (v - mr[2 * m] * colsum[n0 + col]);
+    }
+}
+
+// group barrier for the 13-wave block: every thread drains its own stores (optionally a wave issues a weight burst between the
+// arrival and the wait), thread 0 arrives and polls; the block meets WITHOUT draining vmcnt when a burst is in flight
+template <typename F>
+__device__ __forceinline__ void layer_barrier(unsigned* ctr, unsigned target, unsigned* err, F&& between) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    between();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((int)(ld_sc1_u32(ctr) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if (spins > (1u << 20) || ((spins & 1023u) == 0 && (ld_sc1_u32(err) & 2u))) {
+                atomicOr(err, 2u);
+                break;
+            }
+        }
+    }
+    lds_barrier();
+}
+
+#define LAYER_STAMP(i)                                                              \
+    do {                                                                            \
+        if (a.prof && threadIdx.x == 0) a.prof[blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+
+template <int NCB_SO, int NCB_CQ, int NCB_CO>
+__global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ float sm_mr[2 * kGroupRows];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = (int)(xcc_id() & (a.fault ? 6u : 7u)), li = blockIdx.x >> 3;
+    const unsigned stamp = (unsigned)(*a.step) + 1u;
+    unsigned seen_old = 0;
+    if (tid == 0) seen_old = atomicExch(a.seen + g * kGroupCUs + li, stamp);
+    const int row0 = g * kGroupRows;
+    const int nrows = a.B - row0 < kGroupRows ? a.B - row0 : kGroupRows;
+    if (nrows <= 0) {  // the whole group leaves (all of its blocks take this branch)
+        if (tid == 0 && seen_old == stamp) atomicOr(a.err, 1u);
+        return;
+    }
+    if (tid == 0 && seen_old == stamp) atomicOr(a.err, 1u);  // two blocks claimed the same (XCD, slot): not a bijection
+    const int r_last = row0 + nrows - 1, C = a.C;
+    unsigned* ctr = a.counters + 16 * g;
+    unsigned target = (unsigned)(*a.step) * (unsigned)(4 * kGroupCUs);
+    const bool has_clip = li < nrows;
+    const int clip = row0 + (has_clip ? li : 0);
+    float* sc = (float*)lds;
+    unsigned char* base = lds + a.off_base;
+    LAYER_STAMP(0);
+
+    // ---- stage 1: self attention of this CU's clip; wave 12 requests the out-projection's weight slice meanwhile
+    if (wave == kAttnWaves) {
+        const int n0 = li * a.g_so.cols;
+        issue_panel_nw<AUX_PLAIN, 1>((const bf16*)a.g_so.W, a.g_so.ldw, n0, n0 + a.g_so.cols - 1, a.g_so.rows_pad, a.g_so.nkt, base + a.off_W1, 0,
+                                     lane);
+    } else if (has_clip) {
+        decode_attn_body<bf16, true, true, 1, kAttnWaves>(a.sa, clip, sc, a.sc_stride, nullptr, nullptr, nullptr);
+    }
+    LAYER_STAMP(1);
+    target += kGroupCUs;
+    layer_barrier(ctr, target, a.err, [] {});
+    LAYER_STAMP(2);
+
+    // ---- stage 2: x += o . Wso^T (this CU's column slice of the group's 32 rows), y = bf16(x), partial row sums
+    {
+        const int n0 = li * a.g_so.cols;
+        if (wave < kWaves)
+            issue_panel<AUX_SC1>((const bf16*)a.o, a.ld_o, row0, r_last, kGroupRows, a.g_so.nkt, base + a.off_A1, wave, lane);
+        float xs[2 * NCB_SO];
+        if (wave < kWaves) {
+#pragma unroll
+            for (int i = 0; i < 2 * NCB_SO; ++i) {
+                const int e = tid + i * kThreads;
+                const int j = e >> 10, m = (e >> 5) & 31, col = j * 32 + (e & 31);
+                const int mm = m < nrows ? m : nrows - 1, cc = col < a.g_so.cols ? col : a.g_so.cols - 1;
+                xs[i] = a.x[(size_t)(row0 + mm) * C + n0 + cc];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows, wave 12: the weight slice
+        __syncthreads();
+        LAYER_STAMP(3);
+        f32x16_t acc[NCB_SO];
+#pragma unroll
+        for (int j = 0; j < NCB_SO; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        if (wave < kWaves) mfma_panel<NCB_SO>(base + a.off_A1, base + a.off_W1, a.g_so.nkt, a.g_so.rows_pad, acc, wave, lane);
+        layer_reduce_defer<NCB_SO>(acc, (float*)(base + a.off_A1), xs, a.x, (bf16*)a.y, C,
+                                   a.stats + ((size_t)(g * kGroupCUs + li) * kGroupRows) * 2, row0, nrows, n0, a.g_so.cols, wave, lane);
+    }
+    LAYER_STAMP(4);
+    target += kGroupCUs;
+    layer_barrier(ctr, target, a.err, [&] {  // the cross-q weight slice goes out between the arrival and the wait, from EVERY wave:
+        // one wave issuing its 54 pieces kept the whole block at the closing block barrier for ~2.5 us (profiles/r05_layer_kernel.txt)
+        const int n2 = li * a.g_cq.cols;
+        issue_panel_nw<AUX_PLAIN, kLayerWaves>((const bf16*)a.g_cq.W, a.g_cq.ldw, n2, n2 + a.g_cq.cols - 1, a.g_cq.rows_pad, a.g_cq.nkt,
+                                               base + a.off_W2, wave, lane);
+    });
+    LAYER_STAMP(5);
+
+    // ---- stage 3: qc = rstd * (x . Wq'^T - mean * colsum) on the un-normalised rows of the group
+    {
+        if (wave < kWaves) issue_panel<AUX_SC1>((const bf16*)a.y, C, row0, r_last, kGroupRows, a.g_cq.nkt, base + a.off_A2, wave, lane);
+        if (tid < 512) {
+            const int m = tid >> 4, part = tid & 15;
+            const float* sp = a.stats + ((size_t)(g * kGroupCUs + 2 * part) * kGroupRows + m) * 2;
+            const float a1 = ld_sc1_f32(sp), b1 = ld_sc1_f32(sp + 2 * kGroupRows);
+            const float a2 = ld_sc1_f32(sp + 1), b2 = ld_sc1_f32(sp + 2 * kGroupRows + 1);
+            const float t1 = row16_sum(a1 + b1);
+            const float mean = t1 * (1.0f / C);
+            const float ncs = (float)a.g_so.cols, inv_n = 1.0f / ncs;
+            const float da = a1 * inv_n - mean, db = b1 * inv_n - mean;
+            const float t2 = row16_sum(a2 + b2 + ncs * (da * da + db * db));
+            if (part == 0) {
+                const float var = t2 * (1.0f / C);
+                sm_mr[2 * m] = mean;
+                sm_mr[2 * m + 1] = rsqrtf(var + 1e-5f);
+                if (m < nrows && mean * mean > 64.0f * var) atomicOr(a.err, 4u);  // bf16(x) too coarse for this row (see above)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        LAYER_STAMP(6);
+        f32x16_t acc[NCB_CQ];
+#pragma unroll
+        for (int j = 0; j < NCB_CQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        if (wave < kWaves) mfma_panel<NCB_CQ>(base + a.off_A2, base + a.off_W2, a.g_cq.nkt, a.g_cq.rows_pad, acc, wave, lane);
+        layer_reduce_ln<NCB_CQ>(acc, (float*)(base + a.off_A2), a.qc, a.ld_qc, row0, nrows, li * a.g_cq.cols, a.g_cq.cols, sm_mr, a.colsum_cq,
+                                wave, lane);
+    }
+    LAYER_STAMP(7);
+    target += kGroupCUs;
+    layer_barrier(ctr, target, a.err, [] {});
+    LAYER_STAMP(8);
+
+    // ---- stage 4: cross attention of this CU's clip (the query rows were written by the XCD's other CUs: L1-bypassing loads);
+    // wave 12 requests the second out-projection's weight slice meanwhile
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), visibly to hipcc: no LDS-DMA of this wave is pending when the attention's
+                                         // LDS traffic starts (behind a possibly pending one it would drain vmcnt in the key loop)
+    if (wave == kAttnWaves) {
+        const int n0 = li * a.g_co.cols;
+        issue_panel_nw<AUX_PLAIN, 1>((const bf16*)a.g_co.W, a.g_co.ldw, n0, n0 + a.g_co.cols - 1, a.g_co.rows_pad, a.g_co.nkt, base + a.off_W3, 0,
+                                     lane);
+    } else if (has_clip) {
+        decode_attn_body<bf16, false, true, 1, kAttnWaves, true>(a.ca, clip, sc, a.sc_stride, nullptr, nullptr, nullptr);
+    }
+    LAYER_STAMP(9);
+    target += kGroupCUs;
+    layer_barrier(ctr, target, a.err, [] {});
+    LAYER_STAMP(10);
+
+    // ---- stage 5: x += o . Wco^T, y = bf16(x), partial row sums for the feed-forward GEMM's epilogue
+    {
+        const int n0 = li * a.g_co.cols;
+        if (wave < kWaves)
+            issue_panel<AUX_SC1>((const bf16*)a.o, a.ld_o, row0, r_last, kGroupRows, a.g_co.nkt, base + a.off_A3, wave, lane);
+        float xs[2 * NCB_CO];
+        if (wave < kWaves) {
+#pragma unroll
+            for (int i = 0; i < 2 * NCB_CO; ++i) {
+                const int e = tid + i * kThreads;
+                const int j = e >> 10, m = (e >> 5) & 31, col = j * 32 + (e & 31);
+                const int mm = m < nrows ? m : nrows - 1, cc = col < a.g_co.cols ? col : a.g_co.cols - 1;
+                xs[i] = a.x[(size_t)(row0 + mm) * C + n0 + cc];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        LAYER_STAMP(11);
+        f32x16_t acc[NCB_CO];
+#pragma unroll
+        for (int j = 0; j < NCB_CO; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        if (wave < kWaves) mfma_panel<NCB_CO>(base + a.off_A3, base + a.off_W3, a.g_co.nkt, a.g_co.rows_pad, acc, wave, lane);
+        layer_reduce_defer<NCB_CO>(acc, (float*)(base + a.off_W3), xs, a.x, (bf16*)a.y, C,
+                                   a.stats + ((size_t)(g * kGroupCUs + li) * kGroupRows) * 2, row0, nrows, n0, a.g_co.cols, wave, lane);
+    }
+    LAYER_STAMP(12);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static void desc_fill(ChainGemmDesc& d) {
     d.cols = d.N / kGroupCUs;
@@ -617,6 +916,60 @@ int launch_chain(const ChainArgs& a0, hipStream_t s) {
     }
 #undef CH
 #undef CHD
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
+
+// LDS plan of xcd_layer_kernel (bytes from the dynamic LDS base): scores [12][sc_stride] f32 | stage area.  Stage 2: A1 | W1 (its
+// reduction scratch aliases A1 / W1 once the MFMAs are done); stage 3: A2 | W2 (W2 is requested after stage 2's reduction: it
+// lies behind that scratch and may overlap the dead W1); stage 5: W3 | A3 (W3 is requested after stage 3; scratch aliases W3).
+static size_t layer_plan(LayerChainArgs& a) {
+    desc_fill(a.g_so);
+    desc_fill(a.g_cq);
+    desc_fill(a.g_co);
+    const size_t sc_bytes = ((size_t)kAttnWaves * a.sc_stride * 4 + 1023) / 1024 * 1024;
+    a.off_base = (int)sc_bytes;
+    auto wbytes = [](const ChainGemmDesc& d) { return (size_t)d.nkt * d.rows_pad * 128 + 4096; };
+    auto abytes = [](const ChainGemmDesc& d) { return (size_t)d.nkt * kGroupRows * 128; };
+    auto rbytes = [](const ChainGemmDesc& d) { return (size_t)kWaves * d.ncb * 4096; };
+    a.off_A1 = 0;
+    a.off_W1 = (int)abytes(a.g_so);
+    const size_t end1 = std::max(a.off_W1 + wbytes(a.g_so), rbytes(a.g_so));
+    a.off_A2 = 0;
+    a.off_W2 = (int)std::max(abytes(a.g_cq), rbytes(a.g_so));  // clear of stage 2's scratch (read while W2 lands) and of A2
+    const size_t end2 = std::max(a.off_W2 + wbytes(a.g_cq), rbytes(a.g_cq));
+    a.off_W3 = 0;
+    a.off_A3 = (int)std::max(wbytes(a.g_co), rbytes(a.g_co));
+    const size_t end3 = a.off_A3 + abytes(a.g_co);
+    return sc_bytes + std::max(end1, std::max(end2, end3));
+}
+
+bool layer_chain_supported(const LayerChainArgs& a0, int cu_count) {
+    LayerChainArgs a = a0;
+    if (cu_count != 8 * kGroupCUs) return false;
+    if (a.B < 1 || a.B > 8 * kGroupRows || a.C > 3 * kThreads || a.C % 64 != 0) return false;
+    if (a.sa.H != kAttnWaves || a.ca.H != kAttnWaves || a.sa.dtype != DIMX_BF16 || a.ca.dtype != DIMX_BF16) return false;
+    if (a.B * kAttnWaves * 2 <= 3072) return false;  // smaller batches split a (clip, head) pair over several waves (decode_attn.hip)
+    if (a.ca.rows_per_clip > 1) return false;
+    for (ChainGemmDesc* d : {&a.g_so, &a.g_cq, &a.g_co}) {
+        if (!d->W || d->N % kGroupCUs != 0 || d->K % 64 != 0 || d->ldw % 8 != 0) return false;
+        desc_fill(*d);
+        if (d->ncb < 1 || d->ncb > 2) return false;
+    }
+    if (a.g_so.N != a.C || a.g_co.N != a.C || a.g_cq.K != a.C || a.g_so.ncb != 2 || a.g_co.ncb != 2 || a.g_cq.ncb != 1) return false;
+    if (a.ld_o % 8 != 0) return false;
+    return layer_plan(a) <= kMaxDynLds;
+}
+
+int launch_layer_chain(const LayerChainArgs& a0, hipStream_t s) {
+    LayerChainArgs a = a0;
+    DIMX_REQUIRE(a.x && a.y && a.o && a.qc && a.stats && a.colsum_cq && a.counters && a.seen && a.step && a.err, DIMX_ERR_ARG,
+                 "layer_chain: null operand");
+    const size_t lds = layer_plan(a);
+    DIMX_REQUIRE(lds <= kMaxDynLds, DIMX_ERR_ARG, "layer_chain: LDS plan %zu bytes", lds);
+    (void)hipFuncSetAttribute((const void*)xcd_layer_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);
+    hipLaunchKernelGGL((xcd_layer_kernel<2, 1, 2>), dim3(8 * kGroupCUs), dim3(kLayerThreads), lds, s, a);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

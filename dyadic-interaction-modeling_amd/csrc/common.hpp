@@ -406,6 +406,33 @@ struct ChainArgs {
     int fault;  // test hook (dimx_debug_chain_fault): the blocks of XCD 2i+1 claim XCD 2i's slots -- a non-bijective placement
     int offA1, offW1, offRed1, offA2, offW2, offRed2;        // LDS plan, set by the launcher
 };
+// The attention half of a decoder layer as ONE launch (chain.hip, xcd_layer_kernel; round 5): self attention -> out-projection +
+// residual -> (deferred LayerNorm) cross-q projection -> cross attention -> out-projection + residual.  Clip i of group g is CU
+// slot i of XCD g for both attentions and all three projections split their columns over the XCD's 32 CUs, so every hand-off
+// stays inside the XCD (four group barriers); the projections' weight slices are requested while the attentions stream.
+struct LayerChainArgs {
+    int B, C;                       // clips (<= 256), model dim
+    DecodeAttnArgs sa, ca;          // self / cross attention, one query row per (clip, head); out = o (bf16 [B, ld_o]); ca.q = qc
+    ChainGemmDesc g_so, g_cq, g_co; // self out-projection [C][inner], cross q (gamma-scaled) [inner][C], cross out-projection [C][inner]
+    const void* o;                  // attention output rows = A operand of the two out-projections
+    int ld_o;
+    float* x;                       // [B, C] f32 residual stream
+    void* y;                        // [B, C] bf16(x), un-normalised
+    float* stats;                   // [8][32][32][2] partial row sums (deferred LayerNorm)
+    const float* colsum_cq;         // [inner] row sums of the gamma-scaled q projection
+    float* qc;                      // [B, ld_qc] f32 cross-attention queries
+    int ld_qc;
+    unsigned* counters;             // this launch site's per-XCD arrival counters [8][16] + claim stamps [8][32]
+    unsigned* seen;
+    const int32_t* step;
+    unsigned* err;
+    int fault;
+    unsigned long long* prof;       // tuning only: [256][16] phase stamps
+    int sc_stride;                  // floats per (clip, head) score row in LDS
+    int off_base, off_A1, off_W1, off_A2, off_W2, off_W3, off_A3;  // LDS plan (bytes), set by the launcher
+};
+bool layer_chain_supported(const LayerChainArgs& a, int cu_count);
+int launch_layer_chain(const LayerChainArgs& a, hipStream_t s);
 size_t chain_plan(ChainArgs& a);
 bool chain_supported(const ChainArgs& a, int cu_count);
 int launch_chain(const ChainArgs& a, hipStream_t s);

@@ -62,6 +62,12 @@ template <int EPC> __device__ __forceinline__ void load_f32_chunk(const float* p
         v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
     }
 }
+// the same through L1-bypassing loads (sc1): rows another CU of this XCD wrote during the SAME launch (the layer kernel of
+// chain.hip: the cross-attention query is the chain's q projection) -- a plain load could be served a stale L1 line
+template <int EPC> __device__ __forceinline__ void load_f32_chunk_sc1(const float* p, float (&v)[EPC]) {
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) v[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // sum of the split-K slabs in slab order (deterministic)
 template <int EPC> __device__ __forceinline__ void load_f32_slabs(const float* p, int nslab, long stride, float (&v)[EPC]) {
     load_f32_chunk<EPC>(p, v);
@@ -87,7 +93,7 @@ template <int EPC> __device__ __forceinline__ void load_f32_slabs(const float* p
 // block that take part (4 in decode_attn_kernel; 8 when a 512-thread launch shares its CUs with GEMM blocks, the fusion
 // probe of gemm.hip); the LDS arrays come from the caller: sc [NW / NSPLIT][sc_stride] scores, red_m / red_l [NW],
 // red_acc [NW][64].
-template <typename T, bool SELF, bool QF32, int NSPLIT, int NW>
+template <typename T, bool SELF, bool QF32, int NSPLIT, int NW, bool QSC1 = false>
 __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, int block_id, float* sc, int sc_stride, float* red_m,
                                                  float* red_l, float* red_acc) {
     constexpr int EPC = 16 / sizeof(T);
@@ -108,7 +114,9 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, int bl
     // store: 8.2 us per launch in round 2, four launches per decode step); issued here the three loads overlap the
     // counter read and each other.
     float qv[EPC], knv[EPC], vnv[EPC];
-    if (QF32)
+    if (QSC1)  // one f32 slab, written by other CUs of this XCD during this launch
+        load_f32_chunk_sc1<EPC>((const float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, qv);
+    else if (QF32)
         load_f32_slabs<EPC>((const float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, a.nslab, a.slab_stride, qv);
     else
         load_chunk<T, EPC>((const T*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, qv);

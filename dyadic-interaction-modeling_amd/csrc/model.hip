@@ -797,6 +797,14 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     const char* nc = getenv("DIMX_NO_CHAIN");
     c->use_chain = (nc && nc[0] == '1') ? 0 : 1;
     c->defer_ln = getenv("DIMX_NO_DEFER_LN") ? 0 : 1;
+    c->use_layer_chain = getenv("DIMX_NO_LAYER_CHAIN") ? 0 : 1;
+    if (getenv("DIMX_LAYER_PROF")) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)8 * 256 * 16 * 8) == hipSuccess) {
+            (void)hipMemset(p, 0, (size_t)8 * 256 * 16 * 8);
+            c->layer_prof_dev = (unsigned long long*)p;
+        }
+    }
     if (const char* gu = getenv("DIMX_GRAPH_UNROLL")) {
         const int u = atoi(gu);
         if (u >= 1 && u <= 64) c->graph_unroll = u;
@@ -1687,6 +1695,38 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         c.fault = h->chain_fault_inject > 0 ? 1 : 0;
         return launch_chain(c, st);
     };
+    // round 5: the attention half of a layer as one XCD-local launch (chain.hip xcd_layer_kernel; DIMX_NO_LAYER_CHAIN=1: the four
+    // launches, for A/B runs)
+    const bool layer_kernel = h->use_layer_chain && chain && defer && S == 1 && 4 * dg.depth + 1 <= kChainSites;
+    auto layer_args = [&](int l, const DecodeAttnArgs& sa, const DecodeAttnArgs& ca, LayerChainArgs& lc) -> bool {
+        const Linear& so = h->dec.self_[l].out;
+        const Linear& cq = h->dec.cross[l].q_ln;
+        const Linear& co = h->dec.cross[l].out;
+        if (!so.w || !cq.w || !co.w || !h->dec.cross[l].q_ln_colsum) return false;
+        lc.B = B;
+        lc.C = DD;
+        lc.sa = sa;
+        lc.ca = ca;
+        lc.g_so.W = so.w; lc.g_so.N = so.N; lc.g_so.K = so.K; lc.g_so.ldw = so.Kp;
+        lc.g_cq.W = cq.w; lc.g_cq.N = cq.N; lc.g_cq.K = cq.K; lc.g_cq.ldw = cq.Kp;
+        lc.g_co.W = co.w; lc.g_co.N = co.N; lc.g_co.K = co.K; lc.g_co.ldw = co.Kp;
+        lc.o = s.o;
+        lc.ld_o = inner;
+        lc.x = s.x;
+        lc.y = s.y;
+        lc.stats = h->chain_stats_dev;
+        lc.colsum_cq = h->dec.cross[l].q_ln_colsum;
+        lc.qc = s.qc;
+        lc.ld_qc = inner;
+        lc.counters = s0.chain_ctr + (size_t)(3 * dg.depth + 1 + l) * kChainSiteWords;
+        lc.seen = lc.counters + 8 * 16;
+        lc.step = s.step;
+        lc.err = h->chain_err_dev;
+        lc.fault = h->chain_fault_inject > 0 ? 1 : 0;
+        lc.sc_stride = (T + 15) / 16 * 16;
+        lc.prof = h->layer_prof_dev ? h->layer_prof_dev + (size_t)l * 256 * 16 : nullptr;
+        return true;
+    };
     int pending = 0;  // slabs of the previous residual projection not yet folded into x
     for (int l = 0; l < dg.depth; ++l) {
         GemmArgs g;
@@ -1695,26 +1735,56 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         if (l > 0 || !fuse_ln0)
             DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.self_[l].ln_g, B, DD, st));
         DIMX_TRY(slab_gemm(s.y, DD, h->dec.self_[l].qkv, s.qkv, s0.st_qkv, &ns));
-        memset(&a, 0, sizeof(a));
-        a.dtype = h->at;
-        a.q = s.qkv;
-        a.q_ld = 3 * inner;
-        a.q_f32 = 1;
-        a.nslab = ns;
-        a.slab_stride = s0.st_qkv;
-        a.knew = s.qkv + inner;
-        a.vnew = s.qkv + 2 * inner;
-        a.kv_ld = 3 * inner;
-        a.kcache = boff(s0.sk[l], (size_t)heads * T * 64 * es);
-        a.vcache = boff(s0.sv[l], (size_t)heads * T * 64 * es);
-        a.Tmax = T;
-        a.out = s.o;
-        a.o_ld = inner;
-        a.B = B;
-        a.H = heads;
-        a.step = s.step;
-        a.scale = scale;
-        DIMX_TRY(launch_decode_attn(a, st));
+        // the two attentions' arguments (self: q / new k / new v are the projection's split-K slabs; cross: the context K/V)
+        DecodeAttnArgs sa, ca;
+        memset(&sa, 0, sizeof(sa));
+        sa.dtype = h->at;
+        sa.q = s.qkv;
+        sa.q_ld = 3 * inner;
+        sa.q_f32 = 1;
+        sa.nslab = ns;
+        sa.slab_stride = s0.st_qkv;
+        sa.knew = s.qkv + inner;
+        sa.vnew = s.qkv + 2 * inner;
+        sa.kv_ld = 3 * inner;
+        sa.kcache = boff(s0.sk[l], (size_t)heads * T * 64 * es);
+        sa.vcache = boff(s0.sv[l], (size_t)heads * T * 64 * es);
+        sa.Tmax = T;
+        sa.out = s.o;
+        sa.o_ld = inner;
+        sa.B = B;
+        sa.H = heads;
+        sa.step = s.step;
+        sa.scale = scale;
+        memset(&ca, 0, sizeof(ca));
+        ca.dtype = h->at;
+        ca.q = s.qc;
+        ca.q_ld = inner;
+        ca.q_f32 = 1;
+        ca.nslab = 1;
+        ca.slab_stride = s0.st_qc;
+        ca.kcache = (unsigned char*)cp.ck[l] + (size_t)clip0 * heads * Tp * 64 * es;
+        ca.vcache = (unsigned char*)cp.cv[l] + (size_t)clip0 * heads * Tp * 64 * es;
+        ca.Tmax = Tp;
+        ca.out = s.o;
+        ca.o_ld = inner;
+        ca.B = S > 1 ? nclip : B;
+        ca.rows_per_clip = S;
+        ca.H = heads;
+        ca.n_keys = T;
+        ca.kmask = ctx_mask;
+        ca.kmask_ld = T;
+        ca.scale = scale;
+        if (defer && layer_kernel) {
+            // round 5: self attention -> out-projection -> cross-q -> cross attention -> out-projection as ONE XCD-local launch
+            LayerChainArgs lc;
+            memset(&lc, 0, sizeof(lc));
+            if (layer_args(l, sa, ca, lc) && layer_chain_supported(lc, h->cu_count)) {
+                DIMX_TRY(launch_layer_chain(lc, st));
+                goto feed_forward;
+            }
+        }
+        DIMX_TRY(launch_decode_attn(sa, st));
         if (chain) {  // self out-projection -> x += . -> LayerNorm -> cross q-projection
             if (defer)
                 DIMX_TRY(chain_site(3 * l, s.o, inner, &h->dec.self_[l].out, 0, h->dec.cross[l].ln_g, &h->dec.cross[l].q_ln,
@@ -1728,32 +1798,15 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
             DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.cross[l].ln_g, B, DD, st));
             DIMX_TRY(slab_gemm(s.y, DD, h->dec.cross[l].qkv, s.qc, s0.st_qc, &ns));
         }
-        memset(&a, 0, sizeof(a));
-        a.dtype = h->at;
-        a.q = s.qc;
-        a.q_ld = inner;
-        a.q_f32 = 1;
-        a.nslab = ns;
-        a.slab_stride = s0.st_qc;
-        a.kcache = (unsigned char*)cp.ck[l] + (size_t)clip0 * heads * Tp * 64 * es;
-        a.vcache = (unsigned char*)cp.cv[l] + (size_t)clip0 * heads * Tp * 64 * es;
-        a.Tmax = Tp;
-        a.out = s.o;
-        a.o_ld = inner;
-        a.B = S > 1 ? nclip : B;
-        a.rows_per_clip = S;
-        a.H = heads;
-        a.n_keys = T;
-        a.kmask = ctx_mask;
-        a.kmask_ld = T;
-        a.scale = scale;
-        DIMX_TRY(launch_decode_attn(a, st));
+        ca.nslab = ns;
+        DIMX_TRY(launch_decode_attn(ca, st));
         if (chain) {  // cross out-projection -> x += . -> LayerNorm (feed-forward input)
             DIMX_TRY(chain_site(3 * l + 1, s.o, inner, &h->dec.cross[l].out, 0, h->dec.ff[l].ln_g, nullptr, nullptr, 0));
         } else {
             DIMX_TRY(slab_gemm(s.o, inner, h->dec.cross[l].out, s.xr, s0.st_xr, &pending));
             DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.ff[l].ln_g, B, DD, st));
         }
+    feed_forward:
         gemm_lin(h, s.y, DD, defer ? h->dec.ff[l].f1_ln : h->dec.ff[l].f1, B, g);
         if (defer) {
             g.ln_stats = h->chain_stats_dev;
@@ -1943,6 +1996,36 @@ int dimx_generate(dimx_handle h, const int32_t* start, const uint8_t* ctx_mask, 
     if (h->chain_fault_inject > 0) --h->chain_fault_inject;
     if (!chain_used) return DIMX_OK;
     DIMX_HIP(hipEventSynchronize(h->chain_err_ev));
+    if (h->layer_prof_dev) {  // tuning: the phase stamps of the LAST step's layer launches (100 MHz wall clock), mean / max over blocks
+        static const char* names[13] = {"start", "self attention done", "barrier 1", "rows + W1 landed", "out-proj stored", "barrier 2",
+                                        "y rows + W2 landed", "cross-q stored", "barrier 3", "cross attention done", "barrier 4",
+                                        "rows + W3 landed", "out-proj stored"};
+        std::vector<unsigned long long> hp((size_t)8 * 256 * 16);
+        DIMX_HIP(hipMemcpy(hp.data(), h->layer_prof_dev, hp.size() * 8, hipMemcpyDeviceToHost));
+        for (int l = 0; l < h->decg.depth; ++l) {
+            const unsigned long long* p = hp.data() + (size_t)l * 256 * 16;
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < 256; ++b)
+                if (p[b * 16] && p[b * 16] < t0) t0 = p[b * 16];
+            if (t0 == ~0ull) continue;
+            fprintf(stderr, "dimx layer-kernel stamps, layer %d (us after the first block's start; mean / max over blocks)\n", l);
+            double prev = 0;
+            for (int i = 0; i < 13; ++i) {
+                double sum = 0, mx = 0;
+                int n = 0;
+                for (int b = 0; b < 256; ++b)
+                    if (p[b * 16 + i]) {
+                        const double v = (double)(p[b * 16 + i] - t0) / 100.0;
+                        sum += v;
+                        mx = v > mx ? v : mx;
+                        ++n;
+                    }
+                if (!n) continue;
+                fprintf(stderr, "  %-24s %7.2f / %7.2f  (+%.2f)\n", names[i], sum / n, mx, sum / n - prev);
+                prev = sum / n;
+            }
+        }
+    }
     const unsigned e = *h->chain_err_host;
     if (!e) return DIMX_OK;
     *h->chain_err_host = 0;

@@ -216,3 +216,38 @@ def test_chain_fault_is_reported_and_repaired_by_the_call_that_suffered_it(full_
     # (deferred LayerNorm rounds differently; after a flip an autoregressive sequence is a different sequence)
     assert torch.equal(ok_tok[:, :8], ref_tok[:, :8])
     e.close()
+
+
+def test_layer_kernel_reproduces_the_four_launches_bit_for_bit(full_sd):
+    """round 5, bf16 mode, > 128 clips: self attention -> out-projection -> cross-q -> cross attention -> out-projection as ONE
+    XCD-local launch per layer (chain.hip xcd_layer_kernel) runs the same arithmetic in the same order as the four launches it
+    replaces (DIMX_NO_LAYER_CHAIN=1): identical tokens, greedy and sampled, ragged context masks, a batch that leaves the last
+    clip group partly empty; no chain fault."""
+    import os
+    from dimx import engine, lib
+    B, T = 200, 48
+    lens = [T - (i * 7) % 20 for i in range(B)]
+    v_s, v_a, z, mask = _case(B, T, lens, seed=31)
+    m8 = mask.to(torch.uint8).cuda()
+    noise = torch.empty(T - 1, B, 512).exponential_(generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run(off):
+        if off:
+            os.environ["DIMX_NO_LAYER_CHAIN"] = "1"
+        try:
+            e = engine.Engine("cuda:0", lib.MODE_PERF_BF16)
+        finally:
+            os.environ.pop("DIMX_NO_LAYER_CHAIN", None)
+        e.load_state_dict(full_sd)
+        e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+        greedy = e.generate(z[:, 0].cuda(), m8, T, 0.0).cpu()
+        e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+        sampled = e.generate(z[:, 0].cuda(), m8, T, 1.0, noise=noise).cpu()
+        faults = e.chain_faults()
+        e.close()
+        return greedy, sampled, faults
+
+    g1, s1, f1 = run(False)
+    g0, s0, f0 = run(True)
+    assert f0 == 0 and f1 == 0
+    assert torch.equal(g1, g0) and torch.equal(s1, s0)
