@@ -292,8 +292,9 @@ def shard_check(make_model, device, rank, world, T=60, per_rank=8):
                                 seed=SEED + 5, return_tokens=True, shard=(a, G), batch_row_offset=a)
         return tok.reshape(b - a, T - 1).to(torch.int32), pred.reshape(b - a, -1).float().contiguous()
     tok, pred = run(lo, lo + per_rank)
-    all_tok = ddist.all_gather_rows(tok)
-    all_pred = ddist.all_gather_rows(pred)
+    # one collective, shard sizes known on every rank (per_rank rows each): no count exchange, no host sync
+    buf = ddist.all_gather_rows(ddist.pack_rows(tok, pred), [per_rank] * world)
+    all_tok, all_pred = ddist.unpack_rows(buf, [((T - 1,), torch.int32), ((pred.shape[1],), torch.float32)])
     out = None
     if rank == 0:
         one_tok, one_pred = run(0, G)
@@ -362,7 +363,8 @@ def main():
     def step(i):
         _, _, pred, tokens = model(v_s, v_l, v_a, mask, mode="val", seed=SEED + i + 1, return_tokens=True,
                                    n_samples=args.samples)
-        gathered = ddist.all_gather_rows(tokens.reshape(-1, T - 1).to(torch.int32))
+        tok = tokens.reshape(-1, T - 1).to(torch.int32)
+        gathered = ddist.all_gather_rows(tok, [tok.shape[0]] * world)   # equal shards: ONE collective, nothing synchronises first
         return pred, gathered
 
     for i in range(args.warmup):

@@ -1,6 +1,9 @@
 """Multi-GPU plumbing: one process per GPU, batch sharded by contiguous rows, weights replicated, and ONE
 collective per evaluation batch -- an all-gather of the generated code indices (and optionally the decoded
-coefficients) so that any rank can run the host-side metrics.
+coefficients, packed into the same buffer) so that any rank can run the host-side metrics.
+Shard sizes follow from ``shard_bounds`` on every rank, so no count exchange and no host synchronisation precede the
+payload collective (the round-4 form all-gathered the row counts and ``.item()``-ed them first);
+``all_gather_rows`` without ``counts`` keeps that exchange for callers whose shards are genuinely unknown.
 
 ``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI inside a node); the same code runs on the
 "gloo" backend for the CPU tests.  Payloads are 150 KB - 2.5 MB per rank: latency-bound, so a single
@@ -65,15 +68,50 @@ def _via_host(t):
     return t.is_cuda and dist.get_backend() == "gloo"
 
 
-def all_gather_rows(t):
-    """Concatenate every rank's rows along dim 0 (shards may differ in length, empty shards included)."""
+def shard_counts(n, w=None):
+    """rows of every rank's contiguous shard of n rows (what shard_bounds gives each of them): known without communication."""
+    w = world_size() if w is None else w
+    return [shard_bounds(n, r, w)[1] - shard_bounds(n, r, w)[0] for r in range(w)]
+
+
+def pack_rows(*tensors):
+    """[n, ...] tensors of 4-byte element types -> one [n, sum of row sizes] int32 buffer (bit patterns), so that several
+    per-row results travel in ONE collective; ``unpack_rows`` undoes it."""
+    n = tensors[0].shape[0]
+    parts = []
+    for t in tensors:
+        assert t.shape[0] == n and t.element_size() == 4, "pack_rows: 4-byte element types, equal row counts"
+        k = 1
+        for d in t.shape[1:]:
+            k *= d
+        parts.append(t.contiguous().view(torch.int32).reshape(n, k))   # explicit row size: an empty shard has no "-1"
+    return torch.cat(parts, 1) if len(parts) > 1 else parts[0]
+
+
+def unpack_rows(buf, like):
+    """inverse of pack_rows: ``like`` = [(shape of one row, dtype), ...]"""
+    out, c = [], 0
+    for shape, dtype in like:
+        k = 1
+        for d in shape:
+            k *= d
+        out.append(buf[:, c:c + k].contiguous().view(dtype).reshape((buf.shape[0],) + tuple(shape)))
+        c += k
+    return out
+
+
+def all_gather_rows(t, counts=None):
+    """Concatenate every rank's rows along dim 0 (shards may differ in length, empty shards included).  ``counts``: the rows of
+    every rank's shard when the caller knows them (``shard_counts``): then this is exactly one collective and no host sync."""
     if world_size() == 1:
         return t
     if _via_host(t):
-        return all_gather_rows(t.cpu()).to(t.device)
+        return all_gather_rows(t.cpu(), counts).to(t.device)
     t = t.contiguous()
     w = world_size()
-    counts = all_gather_counts(t.shape[0], t.device)
+    if counts is None:
+        counts = all_gather_counts(t.shape[0], t.device)
+    assert len(counts) == w and counts[rank()] == t.shape[0], "all_gather_rows: counts do not describe this rank's shard"
     if len(set(counts)) == 1:
         out = torch.empty((w * counts[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t)

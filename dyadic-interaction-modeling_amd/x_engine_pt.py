@@ -102,20 +102,25 @@ def evaluate_finetune_epoch(model, loader, device):
 BATCHED_SAMPLE_COUNTS = (2, 4, 5, 8, 10)
 
 
-def _gather_ragged(best, n_local, width, feat, device):
+def _gather_ragged(best, n_local, width, feat, device, total=None):
     """all-gather a rank's list of [n_j, feat] arrays (None = no candidate was ever better than inf, as in the
-    reference) in shard order; returns the list for the whole batch."""
-    lens = torch.tensor([-1 if b is None else b.shape[0] for b in best], dtype=torch.int64, device=device)
+    reference) in shard order; returns the list for the whole batch.  ONE collective: the valid lengths ride in the same
+    buffer as the padded rows, and with ``total`` (rows of the whole batch) the shard sizes follow from shard_bounds on every
+    rank -- no count exchange, no host synchronisation before the payload."""
+    lens = torch.tensor([-1 if b is None else b.shape[0] for b in best], dtype=torch.int32, device=device).reshape(n_local, 1)
     pad = torch.zeros(n_local, width, feat, dtype=torch.float32, device=device)
     for j, b in enumerate(best):
         if b is not None and b.shape[0]:
             pad[j, :b.shape[0]] = torch.from_numpy(np.ascontiguousarray(b)).to(device)
-    lens = ddist.all_gather_rows(lens).cpu().tolist()
-    pad = ddist.all_gather_rows(pad).cpu().numpy()
-    return [None if n < 0 else pad[j, :n].copy() for j, n in enumerate(lens)]
+    counts = ddist.shard_counts(total) if total is not None else None
+    buf = ddist.all_gather_rows(ddist.pack_rows(lens, pad), counts)
+    lens_all, pad_all = ddist.unpack_rows(buf, [((1,), torch.int32), ((width, feat), torch.float32)])
+    lens_all = lens_all.reshape(-1).cpu().tolist()
+    pad_all = pad_all.cpu().numpy()
+    return [None if n < 0 else pad_all[j, :n].copy() for j, n in enumerate(lens_all)]
 
 
-def _select_device(y_true, y_preds, lens, world, device):
+def _select_device(y_true, y_preds, lens, world, device, total=None):
     """fd_backend="device": distances of all (clip, try) pairs in one batched float64 computation on the GPU; the first minimum
     per clip wins (= the strict '<' of the reference's loop), a clip whose distances are all inf / nan keeps None."""
     from .metrics import frechet_distances_torch
@@ -126,7 +131,7 @@ def _select_device(y_true, y_preds, lens, world, device):
     chosen = y_preds[torch.arange(len(lens), device=y_preds.device), win].cpu().numpy()
     best = [chosen[j][:lens[j]].copy() if ok[j] else None for j in range(len(lens))]
     if world > 1:
-        best = _gather_ragged(best, len(lens), y_preds.shape[2], y_preds.shape[3], device)
+        best = _gather_ragged(best, len(lens), y_preds.shape[2], y_preds.shape[3], device, total)
     return best
 
 
@@ -135,7 +140,7 @@ def _select(pending, skip_degenerate, world, device):
     current best only when its distance is strictly smaller; the first ValueError in that order propagates unless
     skip_degenerate scores it as inf).  The distances come from the worker threads; which candidate wins does not depend
     on how many there are."""
-    futs, samples, lens, nl, width, feat = pending
+    futs, samples, lens, nl, width, feat, total = pending
     cur_best = [float("inf")] * nl
     best = [None] * nl
     for s_i, yp in enumerate(samples):
@@ -147,7 +152,7 @@ def _select(pending, skip_degenerate, world, device):
                 best[j] = yp[j][:lens[j]].copy()
                 cur_best[j] = cfid
     if world > 1:
-        best = _gather_ragged(best, nl, width, feat, device)
+        best = _gather_ragged(best, nl, width, feat, device, total)
     return best
 
 
@@ -209,12 +214,12 @@ def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=Tru
                         y_preds_all.extend(_select(pending, skip_degenerate, world, device))
                         pending = None
                     y_preds_all.extend(_select_device(tgt[lo:hi, 1:], y_preds, [src_len[lo + j] - 1 for j in range(nl)], world,
-                                                      device))
+                                                      device, B))
                     continue
                 yp_all = y_preds.cpu().numpy()
                 samples = [yp_all[:, s_i] for s_i in range(beam_size)]
             elif fd_backend == "device":
-                y_preds_all.extend(_gather_ragged([], 0, tgt.shape[1] - 1, tgt.shape[2], device) if world > 1 else [])
+                y_preds_all.extend(_gather_ragged([], 0, tgt.shape[1] - 1, tgt.shape[2], device, B) if world > 1 else [])
                 continue
             # this batch's distances go to the worker threads; the PREVIOUS batch's are collected now, after this batch's
             # generation has run in the meantime -- host scoring overlaps the GPU
@@ -222,10 +227,33 @@ def evaluate_test_epoch(model, loader, device, beam_size=10, batched_samples=Tru
                 y_preds_all.extend(_select(pending, skip_degenerate, world, device))
             lens = [src_len[lo + j] - 1 for j in range(nl)]
             futs = [[pool.submit(_fd_or_error, y_true[lo + j][:lens[j]], yp[j][:lens[j]]) for j in range(nl)] for yp in samples]
-            pending = (futs, samples, lens, nl, tgt.shape[1] - 1, tgt.shape[2])
+            pending = (futs, samples, lens, nl, tgt.shape[1] - 1, tgt.shape[2], B)
         if pending is not None:
             y_preds_all.extend(_select(pending, skip_degenerate, world, device))
+    _report_epoch(model, device, "evaluate_test_epoch", len(y_trues_all), fd_backend)
     return y_trues_all, y_preds_all, x_all, data_ids_all
+
+
+last_eval_report = {}
+
+
+def _report_epoch(model, device, what, n_clips, fd_backend=None):
+    """What an evaluation epoch leaves behind besides its lists (the reference's return value is kept as it is): the number of
+    generate() calls whose XCD-local chain kernels reported a fault and were repaired by regeneration (csrc/chain.hip) -- a handle
+    on a shared / partitioned GPU silently takes the slower step from then on, so the epoch says so."""
+    faults = 0
+    try:
+        eng = model.engine(device) if hasattr(model, "engine") else None
+        faults = int(eng.chain_faults()) if eng is not None and hasattr(eng, "chain_faults") else 0
+    except Exception:   # a stub model of the host-protocol tests has no engine
+        faults = 0
+    last_eval_report.clear()
+    last_eval_report.update(epoch=what, clips=int(n_clips), chain_faults=faults, fd_backend=fd_backend, world_size=ddist.world_size())
+    if faults:
+        import warnings
+        warnings.warn("%s: %d generate() call(s) of this handle reported a chain-kernel fault; those batches were regenerated on the "
+                      "one-kernel-per-op step and the handle keeps that (slower) step" % (what, faults))
+    return last_eval_report
 
 
 def generate_sharded(model, v_speaker, v_listener, v_audio, mask, **forward_kw):
@@ -256,8 +284,15 @@ def generate_sharded(model, v_speaker, v_listener, v_audio, mask, **forward_kw):
         T = v_speaker.shape[1]
         pred = torch.zeros(0, T - 1, v_listener.shape[2], device=v_speaker.device)
         tokens = torch.zeros(0, T - 1, dtype=torch.int32, device=v_speaker.device)
-    tokens = ddist.all_gather_rows(tokens.to(torch.int32))
-    pred = ddist.all_gather_rows(pred)
+    # ONE collective: the code indices and the decoded coefficients travel in the same buffer; the shard sizes follow from
+    # shard_bounds on every rank (pre_sharded callers exchanged theirs above), so nothing synchronises with the host first
+    if world > 1:
+        counts = counts if pre_sharded else ddist.shard_counts(total)
+        Tm1, F = pred.shape[1], pred.shape[2]
+        buf = ddist.all_gather_rows(ddist.pack_rows(tokens.to(torch.int32), pred.float()), counts)
+        tokens, pred = ddist.unpack_rows(buf, [((Tm1,), torch.int32), ((Tm1, F), torch.float32)])
+    else:
+        tokens = tokens.to(torch.int32)
     return tokens, pred
 
 

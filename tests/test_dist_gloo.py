@@ -35,9 +35,21 @@ def _worker(rank, world, port, q):
     even = torch.arange(8 * 3, dtype=torch.float32).view(8, 3)
     lo, hi = dd.shard_bounds(8, r, w)
     ok2 = torch.equal(dd.all_gather_rows(even[lo:hi].clone()), even)
+    # round 5: shard sizes known on every rank -> exactly ONE collective, no count exchange (all_gather_counts must not run);
+    # several per-row results packed into one buffer
+    lo, hi = dd.shard_bounds(B, r, w)
+    real_counts = dd.all_gather_counts
+    calls = []
+    dd.all_gather_counts = lambda *a, **k: calls.append(1) or real_counts(*a, **k)
+    tok = full[lo:hi].clone()
+    pred = (full[lo:hi].float() * 0.5).reshape(hi - lo, 5, 1).repeat(1, 1, 3)
+    buf = dd.all_gather_rows(dd.pack_rows(tok, pred), dd.shard_counts(B))
+    tok_all, pred_all = dd.unpack_rows(buf, [((5,), torch.int32), ((5, 3), torch.float32)])
+    ok3 = (not calls) and torch.equal(tok_all, full) and torch.equal(pred_all, (full.float() * 0.5).reshape(B, 5, 1).repeat(1, 1, 3))
+    dd.all_gather_counts = real_counts
     mx = dd.max_over_ranks(float(rank + 1))
     dd.barrier()
-    q.put((rank, ok1, ok2, mx))
+    q.put((rank, ok1, ok2 and ok3, mx))
     dist.destroy_process_group()
 
 
