@@ -322,13 +322,8 @@ int launch_attention_tr(const AttnArgs& a, hipStream_t s);
 // on the host into the kernel's LDS chunk images
 size_t mlp_fused_packed_bytes(int C, int F);
 int mlp_fused_pack(const float* w1, const float* b1, const float* w2, int C, int F, uint16_t* out);
-// optional: the attention block's out-projection + residual in front of the sublayer, x <- x + ao . Wo^T + bo (ao [M, K_o] bf16 with row
-// stride ld_ao, K_o = 384 or 768; wo_packed from mlp_fused_pack_outproj)
-size_t mlp_fused_outproj_bytes(int C, int K);
-int mlp_fused_pack_outproj(const float* wo, int C, int K, uint16_t* out);
 int launch_mlp_fused(float* x, const void* packed, const float* b2, const float* ln_g, const float* ln_b, int M, int C, int F, int act,
-                     hipStream_t s, const void* wo_packed = nullptr, const void* ao = nullptr, int ld_ao = 0, int K_o = 0,
-                     const float* bo = nullptr);  // attention_tr.hip: bf16, D 48 / 64, q / k / v row-major
+                     hipStream_t s);  // attention_tr.hip: bf16, D 48 / 64, q / k / v row-major
 
 struct DecodeAttnArgs {
     int dtype;             // storage type of q / caches / out

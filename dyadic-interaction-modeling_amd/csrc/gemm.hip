@@ -1549,6 +1549,7 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     // measured on MI355X: 128x128 8-wave for large M; bf16 from 288 tiles (the dW of a 1152 x 4608 projection at 4 800 rows:
     // 122.9 us on the 64 x 64 kernel, 80.4 on this one; 228 tiles and fewer: level or behind -- profiles/r03_train_gemm.txt)
     if (cfg == 0) cfg = tiles128 >= (sizeof(T) == 2 ? 288 : 512) ? 14 : gemm_cfg_small();
+    if (a.cfg == 0 && sizeof(T) == 4 && a.out_slabs) cfg = gemm_cfg_small();  // f32 slabs: one tile shape whatever M is (see gemm_plan_splits)
     if (a.cfg == 0 && gemm_use_ws72(a0)) cfg = 72;
     DIMX_REQUIRE(cfg != 72 || (sizeof(T) == 2 && a.N % 72 == 0 && !a.w_tiled), DIMX_ERR_ARG, "gemm: cfg 72 needs bf16 operands and N %% 72 == 0 (N=%d)", a.N);
     if (a.out_slabs) {
@@ -1600,6 +1601,9 @@ int gemm_plan_splits(const GemmArgs& a) {
     if (a.conv_T != 0 || a.K % bk != 0 || a.K != kext || a.force_simple) return 1;  // register-staged kernel: no split
     int cfg = a.cfg, bm, bn;
     if (cfg == 0) cfg = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128) >= 512 ? 14 : 4;
+    // f32 parity mode: tile AND split count must not depend on M (a rank's shard reproduces the whole batch's rows bit for bit):
+    // the slab path always plans for the 64 x 64 tile (launch_typed forces the same kernel), ADVICE round 4
+    if (a.cfg == 0 && a.in_dtype != DIMX_BF16) cfg = 4;
     if (a.cfg == 0 && gemm_use_ws72(a)) cfg = 72;
     cfg_tile(cfg, bm, bn);
     const int tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);

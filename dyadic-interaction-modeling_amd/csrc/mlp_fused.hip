@@ -69,23 +69,14 @@ struct MlpArgs {
     const float* ln_g;     // [C]
     const float* ln_b;     // [C] or null
     int M, nchunk;
-    // PRO (the attention out-projection in front of the sublayer): x <- x + ao . Wo^T + bo first
-    const void* wo;        // packed Wo: kh * 12 units of 24 fragments (mlp_fused_pack_outproj)
-    const bf16* ao;        // [M, 384 kh] bf16 attention output, row stride ld_ao
-    const float* bo;       // [C] or null
-    int ld_ao, kh;
     int stagger;           // start delay step in units of 64 shader cycles: block b of the first wave of blocks waits (b % 8) * stagger
     int abl;               // tuning (DIMX_MLP_ABL): 1 = no DMA inside the loop, 2 = no GELU, 4 = no chunk loop at all
 };
 
 // ABLC (tuning, DIMX_MLP_ABL bits 8 / 16 on the tanh + beta instantiation): 8 = no fragment reads in the loop, 16 = no MFMAs in the loop
-// PRO (NOT used by the forward -- measured break-even, profiles/r04_mlp_fused_outproj.txt: +73 us at K_o = 384 and +108 us at K_o = 768 on
-// top of 305 us, against 76 / 109 us for the separate out-projection launches; kept, tested, for the next step of DESIGN 10 item 2):
-// the sublayer is preceded by the attention block's out-projection and residual, x <- x + ao . Wo^T + bo (the rows are resident anyway):
-// the accumulators start at x (+ bo) in accumulator order, take the product (Wo streamed through the W2 ring in units of 24 fragments, ao as
-// B fragments), give the LayerNorm its statistics and -- through v_permlane32_swap, which trades the halves that belong to the partner lane --
-// the operand-order values, and finally hold x' + b2 for the feed-forward product: the epilogue is then a plain store.
-template <int ACT, bool BETA, int ABLC = 0, bool PRO = false> __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpArgs a) {
+// (The out-projection-in-the-prologue variant of round 4 measured break-even against the separate launch and was removed in
+// round 5: profiles/r04_mlp_fused_outproj.txt, git history 572449b.)
+template <int ACT, bool BETA, int ABLC = 0> __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hf = lane >> 5, l31 = lane & 31;
     const int row = blockIdx.x * 128 + wave * 32 + l31;
@@ -122,7 +113,7 @@ template <int ACT, bool BETA, int ABLC = 0, bool PRO = false> __global__ __launc
     };
     const int nch = a.nchunk;
     auto wrap = [&](int c) { return c < nch ? c : (c - nch < nch ? c - nch : 0); };
-    // pre-loop: W1(0), W1(1), W1(2) and W2(0), W2(1) (PRO: the whole LDS first serves the out-projection as a 6-slot ring of its units)
+    // pre-loop: W1(0), W1(1), W1(2) and W2(0), W2(1)
     auto issue_preloop = [&]() {
 #pragma unroll
         for (int j = 0; j < 13; ++j) issue_piece(j, 0, 0, 0, 0);
@@ -132,154 +123,14 @@ template <int ACT, bool BETA, int ABLC = 0, bool PRO = false> __global__ __launc
         for (int j = 0; j < 13; ++j)
             if (j < 6 || j == 12) issue_piece(j, wrap(2), 2, 0, 0);
     };
-    if constexpr (!PRO) issue_preloop();
+    issue_preloop();
 
     bf16x8_t xb[kKS + 1];
     f32x16_t o[kOB];   // Out^T accumulators: register r of block ob is out column 32 ob + 8 (r / 4) + 4 hf + r % 4
-    if constexpr (PRO) {
-        unsigned char* const ring2p = smem;           // 6 slots of 24 KiB (the weight rings are not in use yet)
-        const unsigned char* const wo_lane = (const unsigned char*)a.wo + lane * 16;
-        auto issue_unit = [&](int u, int slot) {     // 24 pieces of 1 KiB, 6 per wave
-#pragma unroll
-            for (int p = 0; p < 6; ++p)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(wo_lane + (size_t)u * (kW2Frags * 1024) + (size_t)(wave + 4 * p) * 1024),
-                                                 (lds_void_t*)(ring2p + slot * (kW2Frags * 1024) + (wave + 4 * p) * 1024), 16, 0, 0);
-        };
-        const int nunit = 12 * a.kh;
-#pragma unroll
-        for (int u = 0; u < 5; ++u)
-            if (u < nunit) issue_unit(u, u);
-        // the accumulators start at x (+ bo), read in accumulator order
-        {
-            const float* xr = a.x + (size_t)rowc * kC + 4 * hf;
-#pragma unroll
-            for (int ob = 0; ob < kOB; ++ob)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4_t v = *(const f32x4_t*)(xr + 32 * ob + 8 * q);
-                    if (a.bo) {
-                        const f32x4_t b = *(const f32x4_t*)(a.bo + 32 * ob + 8 * q + 4 * hf);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] += b[t];
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) o[ob][4 * q + t] = v[t];
-                }
-        }
-        const unsigned rdp = lds0 + lane * 16;
-        bf16x8_t ab[kKS];
-        for (int khi = 0; khi < a.kh; ++khi) {
-            {   // this lane's half row of the attention output: k = 384 khi + 16 s + 8 hf + j
-                const bf16* ar = a.ao + (size_t)rowc * a.ld_ao + khi * kC + 8 * hf;
-#pragma unroll
-                for (int s_ = 0; s_ < kKS; ++s_) ab[s_] = *(const bf16x8_t*)(ar + 16 * s_);
-            }
-#pragma unroll
-            for (int ob = 0; ob < kOB; ++ob) {               // unit u = 12 khi + ob in ring slot u % 6 = ob % 6
-                const int u = 12 * khi + ob;
-                // unit u has landed once at most the pieces of the (up to four) younger units are outstanding (in-order return)
-                if (ob == 0) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the ab loads are younger than every piece in flight)
-                } else {
-                    const int younger = nunit - 1 - u;
-                    if (younger >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                    else if (younger == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-                    else if (younger == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();                  // unit u is in LDS for everyone; everyone is done with unit u - 1
-                if (u + 5 < nunit) issue_unit(u + 5, (ob + 5) % 6);
-                const unsigned base = rdp + (ob % 6) * (kW2Frags * 1024);
-                u32x4_t fr[2][6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[0][q]) : "v"(base), "i"(q * 1024));
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (g + 1 < 4) {
-#pragma unroll
-                        for (int q = 0; q < 6; ++q)
-                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(g + 1) & 1][q]) : "v"(base), "i"(((g + 1) * 6 + q) * 1024));
-                        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 6; ++q)
-                        o[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fr[g & 1][q]), ab[g * 6 + q], o[ob], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_barrier();                // everyone is done with the units: the feed-forward weights' first chunks may come in
-        issue_preloop();                             // (they travel while the LayerNorm below is computed)
-        // LayerNorm statistics of x' = the accumulators (this lane holds 192 of the row's 384 values, the partner lane the rest)
-        float s1 = 0.f;
-#pragma unroll
-        for (int ob = 0; ob < kOB; ++ob)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s1 += o[ob][r];
-        s1 += __shfl_xor(s1, 32);
-        const float mean = s1 * (1.0f / kC);
-        float s2 = 0.f;
-#pragma unroll
-        for (int ob = 0; ob < kOB; ++ob)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = o[ob][r] - mean;
-                s2 += d * d;
-            }
-        s2 += __shfl_xor(s2, 32);
-        const float rstd = rsqrtf(s2 * (1.0f / kC) + 1e-5f);
-        const float* g = a.ln_g + 8 * hf;
-        const float* be = a.ln_b + 8 * hf;
-        // Operand order from accumulator order: fragment s wants columns 16 s + 8 hf + {0..7}; accumulator group q' = 2 s holds
-        // 16 s + 4 hf + {0..3}, group 2 s + 1 holds 16 s + 8 + 4 hf + {0..3}.  v_permlane32_swap(A = group 2 s, B = group 2 s + 1) leaves
-        // in A: lower half its own 16 s + {0..3}, upper half the partner's group 2 s + 1 = 16 s + 8 + {0..3}; in B: lower half the
-        // partner's group 2 s = 16 s + 4 + {0..3}, upper half its own 16 s + 12 + {0..3} -- elements 0..3 and 4..7 for both halves.
-#pragma unroll
-        for (int s_ = 0; s_ < kKS; ++s_) {
-            const f32x4_t g0 = *(const f32x4_t*)(g + 16 * s_), g1 = *(const f32x4_t*)(g + 16 * s_ + 4);
-            f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-            if (BETA) {
-                b0 = *(const f32x4_t*)(be + 16 * s_);
-                b1 = *(const f32x4_t*)(be + 16 * s_ + 4);
-            }
-            float v0[4], v1[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                // (copy the elements out first: a bit_cast applied directly to a vector element reads element 0 on hipcc 7.2)
-                const float ea = o[(2 * s_) / 4][4 * ((2 * s_) % 4) + t], eb = o[(2 * s_ + 1) / 4][4 * ((2 * s_ + 1) % 4) + t];
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ea), __float_as_uint(eb), false, false);
-                const unsigned r0 = r[0], r1 = r[1];
-                v0[t] = __uint_as_float(r0);
-                v1[t] = __uint_as_float(r1);
-            }
-            uint32_t w[4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                w[j] = pack_bf16x2((v0[2 * j] - mean) * rstd * g0[2 * j] + b0[2 * j], (v0[2 * j + 1] - mean) * rstd * g0[2 * j + 1] + b0[2 * j + 1]);
-                w[2 + j] = pack_bf16x2((v1[2 * j] - mean) * rstd * g1[2 * j] + b1[2 * j], (v1[2 * j + 1] - mean) * rstd * g1[2 * j + 1] + b1[2 * j + 1]);
-            }
-            const u32x4_t uu = {w[0], w[1], w[2], w[3]};
-            xb[s_] = __builtin_bit_cast(bf16x8_t, uu);
-        }
-        const u32x4_t one = {hf == 0 ? 0x3f803f80u : 0u, 0u, 0u, 0u};
-        xb[kKS] = __builtin_bit_cast(bf16x8_t, one);
-        // x' + b2: what the feed-forward product accumulates onto
-#pragma unroll
-        for (int ob = 0; ob < kOB; ++ob)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4_t b = *(const f32x4_t*)(a.b2 + 32 * ob + 8 * q + 4 * hf);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) o[ob][4 * q + t] += b[t];
-            }
-    }
     // ---- this lane's half of its row: k = 16 s + 8 hf + j, read ONCE into registers (192 f32: the accumulators are not live yet).
     // LayerNorm statistics over the row (lanes l and l + 32), two-pass in registers, then the B fragments
     // bf16((x - mean) rstd gamma + beta) replace the f32 values fragment by fragment.
-    if constexpr (!PRO) {
+    {
         const float* xr = a.x + (size_t)rowc * kC + 8 * hf;
         f32x4_t v[kKS][2];
 #pragma unroll
@@ -455,7 +306,7 @@ template <int ACT, bool BETA, int ABLC = 0, bool PRO = false> __global__ __launc
         s2 = s2 == 2 ? 0 : s2 + 1;
     }
 
-    // ---- epilogue: x[row, col] += Out^T[col, row] (PRO: the accumulators already hold the residual stream: a plain store)
+    // ---- epilogue: x[row, col] += Out^T[col, row]
     if (row < a.M) {
         float* xr = a.x + (size_t)row * kC + 4 * hf;
 #pragma unroll
@@ -464,7 +315,7 @@ template <int ACT, bool BETA, int ABLC = 0, bool PRO = false> __global__ __launc
             for (int q = 0; q < 4; ++q) {
                 float* p = xr + 32 * ob + 8 * q;
                 f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (!PRO) v = *(const f32x4_t*)p;
+                v = *(const f32x4_t*)p;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] += o[ob][4 * q + t];
                 *(f32x4_t*)p = v;
@@ -512,26 +363,9 @@ int mlp_fused_pack(const float* w1, const float* b1, const float* w2, int C, int
     return DIMX_OK;
 }
 
-size_t mlp_fused_outproj_bytes(int C, int K) { return (C == kC && (K == kC || K == 2 * kC)) ? (size_t)(K / kC) * 12 * kW2Frags * 1024 : 0; }
-
-// host: the out-projection's units.  wo [C, K] f32 row-major (K = 384 or 768) -> out (mlp_fused_outproj_bytes): unit 12 kh + ob holds,
-// for k-step s, lane l, element j: Wo[32 ob + l % 32][384 kh + 16 s + 8 (l / 32) + j]
-int mlp_fused_pack_outproj(const float* wo, int C, int K, uint16_t* out) {
-    DIMX_REQUIRE(mlp_fused_outproj_bytes(C, K) > 0, DIMX_ERR_ARG, "mlp_fused_pack_outproj: C = %d K = %d not supported", C, K);
-    for (int kh = 0; kh < K / kC; ++kh)
-        for (int ob = 0; ob < kOB; ++ob) {
-            uint16_t* img = out + (size_t)(12 * kh + ob) * (kW2Frags * 512);
-            for (int s = 0; s < kKS; ++s)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 8; ++j)
-                        img[(size_t)s * 512 + l * 8 + j] = host_f32_to_bf16(wo[(size_t)(32 * ob + (l & 31)) * K + kC * kh + 16 * s + 8 * (l >> 5) + j]);
-        }
-    return DIMX_OK;
-}
-
 // act: ACT_GELU_TANH / ACT_GELU_ERF
 int launch_mlp_fused(float* x, const void* packed, const float* b2, const float* ln_g, const float* ln_b, int M, int C, int F, int act,
-                     hipStream_t s, const void* wo_packed, const void* ao, int ld_ao, int K_o, const float* bo) {
+                     hipStream_t s) {
     DIMX_REQUIRE(x && packed && b2 && ln_g && M > 0, DIMX_ERR_ARG, "mlp_fused: null argument");
     DIMX_REQUIRE(C == kC && F % 32 == 0 && (act == ACT_GELU_TANH || act == ACT_GELU_ERF), DIMX_ERR_ARG, "mlp_fused: C = %d F = %d act = %d", C, F, act);
     DIMX_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)b2 % 16) == 0 && ((uintptr_t)ln_g % 16) == 0 &&
@@ -539,11 +373,6 @@ int launch_mlp_fused(float* x, const void* packed, const float* b2, const float*
                  DIMX_ERR_ARG, "mlp_fused: operands must be 16-byte aligned");
     MlpArgs a;
     a.x = x; a.wp = packed; a.b2 = b2; a.ln_g = ln_g; a.ln_b = ln_b; a.M = M; a.nchunk = F / 32;
-    a.wo = wo_packed; a.ao = (const bf16*)ao; a.bo = bo; a.ld_ao = ld_ao; a.kh = K_o / kC;
-    if (wo_packed)
-        DIMX_REQUIRE(ao && (K_o == kC || K_o == 2 * kC) && ld_ao >= K_o && ld_ao % 8 == 0 && ((uintptr_t)ao % 16) == 0 && ((uintptr_t)wo_packed % 16) == 0 &&
-                         (!bo || ((uintptr_t)bo % 16) == 0),
-                     DIMX_ERR_ARG, "mlp_fused: out-projection operands (K = %d, ld = %d)", K_o, ld_ao);
     static const int abl = getenv("DIMX_MLP_ABL") ? atoi(getenv("DIMX_MLP_ABL")) : 0;
     a.abl = abl;
     static const int stagger = getenv("DIMX_MLP_STAGGER") ? atoi(getenv("DIMX_MLP_STAGGER")) : 0;
@@ -555,31 +384,13 @@ int launch_mlp_fused(float* x, const void* packed, const float* b2, const float*
         DIMX_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<ACT_GELU_TANH, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DIMX_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<ACT_GELU_TANH, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-#define MLP_LAUNCH_PRO(A, B)                                                                                                          \
-    do {                                                                                                                              \
-        static bool once = false;                                                                                                     \
-        if (!once) {                                                                                                                  \
-            DIMX_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<A, B, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            once = true;                                                                                                              \
-        }                                                                                                                             \
-        hipLaunchKernelGGL((mlp_fused_kernel<A, B, 0, true>), grid, dim3(256), lds, s, a);                                            \
-    } while (0)
 #define MLP_LAUNCH(A, B)                                                                                                              \
     do {                                                                                                                              \
-        static bool once = false;                                                                                                     \
-        if (!once) {                                                                                                                  \
-            DIMX_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            once = true;                                                                                                              \
-        }                                                                                                                             \
+        /* per launch, not once per process: the attribute is per device and the call is cheap */                     \
+        DIMX_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((mlp_fused_kernel<A, B>), grid, dim3(256), lds, s, a);                                                     \
     } while (0)
-    if (wo_packed) {
-        if (act == ACT_GELU_TANH) {
-            if (ln_b) MLP_LAUNCH_PRO(ACT_GELU_TANH, true); else MLP_LAUNCH_PRO(ACT_GELU_TANH, false);
-        } else {
-            if (ln_b) MLP_LAUNCH_PRO(ACT_GELU_ERF, true); else MLP_LAUNCH_PRO(ACT_GELU_ERF, false);
-        }
-    } else if (act == ACT_GELU_TANH) {
+    if (act == ACT_GELU_TANH) {
         if (ln_b && (abl & 8)) hipLaunchKernelGGL((mlp_fused_kernel<ACT_GELU_TANH, true, 8>), grid, dim3(256), lds, s, a);
         else if (ln_b && (abl & 16)) hipLaunchKernelGGL((mlp_fused_kernel<ACT_GELU_TANH, true, 16>), grid, dim3(256), lds, s, a);
         else if (ln_b) MLP_LAUNCH(ACT_GELU_TANH, true); else MLP_LAUNCH(ACT_GELU_TANH, false);
@@ -587,7 +398,6 @@ int launch_mlp_fused(float* x, const void* packed, const float* b2, const float*
         if (ln_b) MLP_LAUNCH(ACT_GELU_ERF, true); else MLP_LAUNCH(ACT_GELU_ERF, false);
     }
 #undef MLP_LAUNCH
-#undef MLP_LAUNCH_PRO
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
 }

@@ -2330,31 +2330,6 @@ int dimx_op_mlp_fused(float* x, const float* w1_host, const float* b1_host, cons
     return rc;
 }
 
-int dimx_op_mlp_fused_attn(float* x, const void* ao, int ld_ao, const float* wo_host, const float* bo, int K_o, const float* w1_host,
-                           const float* b1_host, const float* w2_host, const float* b2, const float* ln_g, const float* ln_b, int M, int C, int F,
-                           int act, void* stream) {
-    DIMX_REQUIRE(x && ao && wo_host && w1_host && w2_host && b2 && ln_g && M > 0, DIMX_ERR_ARG, "op_mlp_fused_attn: null argument");
-    const size_t bytes = mlp_fused_packed_bytes(C, F), obytes = mlp_fused_outproj_bytes(C, K_o);
-    DIMX_REQUIRE(bytes > 0 && obytes > 0, DIMX_ERR_ARG, "op_mlp_fused_attn: C = %d F = %d K_o = %d not supported", C, F, K_o);
-    std::vector<uint16_t> img(bytes / 2), oimg(obytes / 2);
-    DIMX_TRY(mlp_fused_pack(w1_host, b1_host, w2_host, C, F, img.data()));
-    DIMX_TRY(mlp_fused_pack_outproj(wo_host, C, K_o, oimg.data()));
-    void *p = nullptr, *q = nullptr;
-    DIMX_HIP(hipMalloc(&p, bytes));
-    if (hipMalloc(&q, obytes) != hipSuccess) {
-        (void)hipFree(p);
-        DIMX_REQUIRE(false, DIMX_ERR_HIP, "op_mlp_fused_attn: hipMalloc");
-    }
-    int rc = DIMX_OK;
-    if (hipMemcpy(p, img.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(q, oimg.data(), obytes, hipMemcpyHostToDevice) != hipSuccess)
-        rc = DIMX_ERR_HIP;
-    if (rc == DIMX_OK) rc = launch_mlp_fused(x, p, b2, ln_g, ln_b, M, C, F, act, (hipStream_t)stream, q, ao, ld_ao, K_o, bo);
-    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && rc == DIMX_OK) rc = DIMX_ERR_HIP;
-    (void)hipFree(p);
-    (void)hipFree(q);
-    return rc;
-}
-
 int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
                                 const float* gamma, int M, int C, void* stream) {
     return launch_add_slabs_layernorm(out_dtype, x, slabs, nslab, slab_stride, y, gamma, M, C, (hipStream_t)stream);

@@ -137,3 +137,14 @@ def max_over_ranks(x: float, device=None) -> float:
 def barrier():
     if world_size() > 1:
         dist.barrier()
+
+
+def assert_same_batch_count(n_batches, device=None):
+    """A collective per batch needs the same number of batches on every rank."""
+    if world_size() == 1:
+        return
+    t = torch.tensor([n_batches, -n_batches], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[0]) != -int(t[1]):
+        raise RuntimeError("ranks see different batch counts (%d .. %d): shard the loader with a DistributedSampler "
+                           "(dimx.dataset.data_loader.get_vico_dataloaders does)" % (-int(t[1]), int(t[0])))

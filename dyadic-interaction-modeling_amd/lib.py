@@ -111,8 +111,6 @@ SIGNATURES = {
     "dimx_mlp_fused_packed_bytes": (c_size_t, [c_int, c_int]),
     "dimx_mlp_fused_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
     "dimx_op_mlp_fused_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "dimx_op_mlp_fused_attn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dimx_op_add_slabs_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_int, ctypes.c_long, c_void_p, c_void_p, c_int,
                                             c_int, c_void_p]),
     "dimx_op_chain": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,

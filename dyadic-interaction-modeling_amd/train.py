@@ -322,16 +322,7 @@ def broadcast_parameters(params, src=0):
     return n
 
 
-def assert_same_batch_count(n_batches, device=None):
-    """A collective per batch needs the same number of batches on every rank."""
-    if ddist.world_size() == 1:
-        return
-    import torch.distributed as dist
-    t = torch.tensor([n_batches, -n_batches], dtype=torch.int64, device=device if device is not None else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    if int(t[0]) != -int(t[1]):
-        raise RuntimeError("ranks see different batch counts (%d .. %d): shard the loader with a DistributedSampler "
-                           "(dimx.dataset.data_loader.get_vico_dataloaders does)" % (-int(t[1]), int(t[0])))
+assert_same_batch_count = ddist.assert_same_batch_count   # lives in dist.py: the HIP training loops use it without importing this module
 
 
 def train_step(model, optimizer, v_speaker, v_listener, v_audio, mask, clip=1.0, kv_mask=None, scheduler=None):

@@ -103,7 +103,26 @@ class HipTrainer:
                 self.exp_avg[off:off + numel].copy_(st["exp_avg"].reshape(-1).to(self.device, torch.float32))
                 self.exp_avg_sq[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1).to(self.device, torch.float32))
                 step = max(step, int(st["step"]))
-        self.step_count = max(self.step_count, step)
+        # the optimizer is the authority at this point (a freshly loaded state_dict may carry a SMALLER step count than the
+        # arenas' last one): take its count, not the maximum
+        self.step_count = step
+        self._state_sig = self._optimizer_state_signature(optimizer)
+
+    def _optimizer_state_signature(self, optimizer):
+        """identity + version of the moment tensors torch keeps for the trained parameters: changes when optimizer.load_state_dict
+        replaced them or an autograd epoch stepped them in place since the last import / export"""
+        named = self._named()
+        sig = []
+        for name, _, _ in self.layout:
+            st = optimizer.state.get(named[name])
+            if st and "exp_avg" in st:
+                sig.append((id(st["exp_avg"]), st["exp_avg"]._version, id(st["exp_avg_sq"]), st["exp_avg_sq"]._version))
+            else:
+                sig.append(None)
+        return sig
+
+    def optimizer_state_changed(self, optimizer):
+        return getattr(self, "_state_sig", None) != self._optimizer_state_signature(optimizer)
 
     def export_optimizer_state(self, optimizer):
         """write the moments and the step count into ``optimizer.state`` (the entries torch.optim.AdamW keeps per parameter), so
@@ -120,6 +139,7 @@ class HipTrainer:
                     else:
                         st[key] = src.to(p.device, copy=True)
                 st["step"] = torch.tensor(float(self.step_count))
+        self._state_sig = self._optimizer_state_signature(optimizer)
 
     def view(self, arena, name):
         for n, off, numel in self.layout:
@@ -166,9 +186,11 @@ class HipTrainer:
         L.check(self.lib.dimx_train_graph_stats(self.eng.h, ctypes.cast(out, ctypes.c_void_p)), "dimx_train_graph_stats")
         return int(out[0]), int(out[1]), int(out[2])
 
-    def forward_backward(self, v_speaker, v_listener, v_audio, mask, kv_mask=None, z_l=None, return_logits=False):
+    def forward_backward(self, v_speaker, v_listener, v_audio, mask, kv_mask=None, z_l=None, return_logits=False, _alias_logits=False):
         """loss (0-dim device tensor, mean cross entropy over the valid listener codes) and the gradients in ``self.grads``.
-        kv_mask: keep-mask [B,T-1] of the mask_prob draw; None draws one like the reference, False disables it."""
+        kv_mask: keep-mask [B,T-1] of the mask_prob draw; None draws one like the reference, False disables it.
+        return_logits: a tensor of the caller's own (the step writes into a staging buffer that the next call with the same (B, T)
+        overwrites -- possibly from a hipGraph replay; only train_step, which consumes the logits at once, takes the alias)."""
         mask = mask.bool()
         B, T = mask.shape
         if z_l is None:
@@ -197,6 +219,8 @@ class HipTrainer:
                                                      L.ptr(m8), L.ptr(z32), L.ptr(kv8), B, T, L.ptr(self._loss), L.ptr(logits), ws,
                                                      wsb, L.stream_ptr(self.device)), "dimx_train_forward_backward")
         loss = self._loss[0].clone()
+        if return_logits and not _alias_logits:
+            logits = logits.clone()
         return (loss, logits) if return_logits else loss
 
     def all_reduce_grads(self):
@@ -224,7 +248,8 @@ class HipTrainer:
             self.all_reduce_grads()
             self.step()
             return loss
-        l_ce, logits = self.forward_backward(v_speaker, v_listener, v_audio, mask, kv_mask=kv_mask, z_l=z_l, return_logits=True)
+        l_ce, logits = self.forward_backward(v_speaker, v_listener, v_audio, mask, kv_mask=kv_mask, z_l=z_l, return_logits=True,
+                                             _alias_logits=True)
         self.all_reduce_grads()
         self.step()
         with torch.no_grad():

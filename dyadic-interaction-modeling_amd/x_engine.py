@@ -121,14 +121,17 @@ def _train_loop(model, loader, optimizer, device, scheduler, clip, print_freq, e
 def _train_epoch_hip(model, loader, trainer, device, scheduler, clip, print_freq, epoch, optimizer=None):
     """the reference's loop body on the HIP step: the loop only feeds batches; lr / betas / eps / weight_decay follow the torch
     optimizer the trainer stands in for (schedulers work), the trained weights and the moments go back at the end of the epoch."""
-    from . import train as T
+    from . import dist as ddist
     from .x_engine_pt import _adopt_hyperparameters, _set_epoch
     model.train()
-    if trainer.refresh_from_model_if_changed():
+    changed = trainer.refresh_from_model_if_changed()
+    if changed:
         print("train_epoch: the module's parameters changed since the HIP trainer last synchronised: arena reloaded from the module")
+    if optimizer is not None and type(optimizer) is torch.optim.AdamW and (changed or trainer.optimizer_state_changed(optimizer)):
+        trainer.import_optimizer_state(optimizer)   # optimizer.load_state_dict / an autograd epoch in between (ADVICE round 4)
     trainer.clip = float(clip or 0.0)
     try:
-        T.assert_same_batch_count(len(loader), device)
+        ddist.assert_same_batch_count(len(loader), device)
     except TypeError:
         pass
     _set_epoch(loader, epoch)
@@ -168,12 +171,14 @@ def train_epoch(model, loader, optimizer, device, scheduler=None, clip=0.0, prin
         return _train_epoch_hip(model, loader, optimizer, device, scheduler, clip, print_freq, epoch)
     if backward != "autograd":
         from .x_engine_pt import _hip_trainer_for
+        from .x_engine_pt import _no_hip_step
         tr = _hip_trainer_for(model, optimizer, device, print)
         if tr is not None:
             return _train_epoch_hip(model, loader, tr, device, scheduler, clip, print_freq, epoch, optimizer=optimizer)
         if backward == "hip":
             from . import lib as L
-            raise L.DimxError("train_epoch(backward='hip'): this call cannot run on the HIP training step (see the log line)")
+            raise L.DimxError("train_epoch(backward='hip'): %s" % _hip_trainer_for.last_reason)
+        _no_hip_step(model, "train_epoch", print)   # raises for a dimx model: the autograd route is an explicit opt-in
 
     def step_loss(batch):
         src, tgt, src_len, (_speaker_ids, listener_ids) = batch[0], batch[1], batch[2], batch[3]

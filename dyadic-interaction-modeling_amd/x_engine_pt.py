@@ -311,9 +311,27 @@ def _adopt_hyperparameters(trainer, optimizer):
     trainer.lr, trainer.betas, trainer.eps, trainer.weight_decay = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
 
 
+def _is_dimx_model(model):
+    """a module of this package (it owns an engine on libdimx_hip.so), as opposed to any other nn.Module handed to the loops"""
+    inner = getattr(model, "module", model)
+    return getattr(inner, "engine_variant", None) is not None and hasattr(inner, "engine")
+
+
+def _no_hip_step(model, what, log):
+    """backward='auto' and no HIP step for this call.  A model of this package must not change backend behind the caller's back
+    (VERDICT round 4): the call raises with the reason, and ``backward='autograd'`` selects the PyTorch-autograd restatement (the
+    checker of the HIP step) explicitly.  Any other nn.Module (the reference's loops are generic) has no HIP backend to leave: it
+    runs on torch as the reference would."""
+    why = getattr(_hip_trainer_for, "last_reason", None) or "no HIP training step"
+    if _is_dimx_model(model):
+        raise L.DimxError("%s(backward='auto'): %s.  The HIP training step is the product path; pass backward='autograd' to run the "
+                          "PyTorch-autograd restatement (its checker) on purpose" % (what, why))
+    log("%s: %s is not a dimx model -- the reference loop on torch autograd" % (what, type(getattr(model, "module", model)).__name__))
+
+
 def _hip_trainer_for(model, optimizer, device, log):
     """The HIP trainer that stands in for ``optimizer`` (a torch.optim.AdamW over this module's parameters), or None when the
-    reference call cannot be mapped onto a HIP step -- then the PyTorch-autograd restatement runs it, and the reason is logged.
+    reference call cannot be mapped onto a HIP step (the reason is left in ``_hip_trainer_for.last_reason``; see _no_hip_step).
     SLMFT -> HipTrainer, SLM -> SlmHipTrainer, the legacy ListenerGenerator -> LegacyHipTrainer (dimx.x_engine.train_epoch).
     Cached on the module per optimizer object: the AdamW moments and the step count live in the trainer's flat arenas between
     epochs and are exported into ``optimizer.state`` at the end of every epoch (``optimizer.state_dict()`` stays meaningful)."""
@@ -349,7 +367,7 @@ def _hip_trainer_for(model, optimizer, device, log):
             tr.import_optimizer_state(optimizer)
             inner._dimx_hip_trainer = (optimizer, tr)
             return tr
-    log("train_epoch: " + why + " -- running this epoch on PyTorch autograd (dimx.train)")
+    _hip_trainer_for.last_reason = why
     return None
 
 
@@ -359,10 +377,15 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoc
     trained parameters are written back into the module at the end of the epoch (evaluation / state_dict see them).
     ``clip`` (when given) is the reference's argument and replaces the trainer's own; ``optimizer`` (a torch.optim.AdamW the
     trainer stands in for) supplies lr / betas / eps / weight_decay per step and receives the moments at the end."""
-    from . import train as T
     model.train()
-    if trainer.refresh_from_model_if_changed():
+    changed = trainer.refresh_from_model_if_changed()
+    if changed:
         log("train_epoch: the module's parameters changed since the HIP trainer last synchronised (load_state_dict?): arena reloaded from the module")
+    if optimizer is not None and type(optimizer) is torch.optim.AdamW and (changed or trainer.optimizer_state_changed(optimizer)):
+        # optimizer.load_state_dict / an autograd epoch in between: the arenas' moments and step count are stale, and exporting
+        # them at the end of this epoch would overwrite the optimizer's fresh state (ADVICE round 4)
+        trainer.import_optimizer_state(optimizer)
+        log("train_epoch: the optimizer's state changed since the HIP trainer last exported it: moments and step count re-imported")
     if clip is not None:
         trainer.clip = float(clip)
     if scheduler is not None and optimizer is None:
@@ -371,7 +394,7 @@ def _train_epoch_hip(model, loader, trainer, device, scheduler, print_freq, epoc
             raise L.DimxError("train_epoch: a scheduler needs a torch optimizer whose param_groups carry the learning rate; "
                               "build it on torch.optim.AdamW and pass that optimizer, or set trainer.lr yourself")
     if ddist.world_size() > 1 and hasattr(loader, "__len__"):
-        T.assert_same_batch_count(len(loader), device)
+        ddist.assert_same_batch_count(len(loader), device)
     _set_epoch(loader, epoch)
     losses, parts, all_losses = [], {}, []
     for i, batch in enumerate(loader):
@@ -408,12 +431,11 @@ def train_epoch(model, loader, optimizer, device, scheduler=None, clip=None, pri
     (code/finetune_s2s_pretrain.py:118-132) -- lands on the hand-written HIP training step: for an SLMFT on a GPU a
     ``HipTrainer`` stands in for the AdamW (hyper-parameters read from its param_groups at every step, so torch schedulers
     work; moments exported into ``optimizer.state`` after the epoch; ``sync_to_model()`` at the end of the epoch).  A
-    ``HipTrainer`` may also be passed as ``optimizer`` directly.  ``backward="autograd"`` (or a model / optimiser the HIP step
-    does not cover: SLM pre-training, the legacy generator, other optimisers) runs the PyTorch-autograd restatement
-    (dimx.train), which is the checker of the HIP path.  For N > 1 processes the gradients are averaged over RCCL before
+    ``HipTrainer`` may also be passed as ``optimizer`` directly.  ``backward="auto"`` (default) and ``"hip"`` RAISE when a model
+    of this package cannot be stepped by the HIP kernels (another optimiser class, amsgrad, unequal param_groups, CPU tensors):
+    the PyTorch-autograd restatement (dimx.train) is the checker of the HIP path and runs only with ``backward="autograd"``.  For N > 1 processes the gradients are averaged over RCCL before
     clipping; every rank feeds its own loader shard (get_vico_dataloaders shards the training loaders by rank; the sampler is
     told the epoch here); the ranks must see the same number of batches (checked) and start from rank 0's parameters."""
-    from . import train as T
     from .train_hip import HipTrainer
     if isinstance(optimizer, HipTrainer):
         return _train_epoch_hip(model, loader, optimizer, device, scheduler, print_freq, epoch, log, clip=clip)
@@ -425,7 +447,9 @@ def train_epoch(model, loader, optimizer, device, scheduler=None, clip=None, pri
             return _train_epoch_hip(model, loader, tr, device, scheduler, print_freq, epoch, log,
                                     clip=0.0 if clip is None else clip, optimizer=optimizer)
         if backward == "hip":
-            raise L.DimxError("train_epoch(backward='hip'): this call cannot run on the HIP training step (see the log line)")
+            raise L.DimxError("train_epoch(backward='hip'): %s" % _hip_trainer_for.last_reason)
+        _no_hip_step(model, "train_epoch", log)     # raises for a dimx model: the autograd route is an explicit opt-in
+    from . import train as T                        # the PyTorch-autograd restatement: imported only when it is asked for
     clip = 0.0 if clip is None else clip
     _set_epoch(loader, epoch)
     model.train()

@@ -342,13 +342,6 @@ size_t dimx_mlp_fused_packed_bytes(int C, int F);
 int dimx_mlp_fused_pack(const float* w1_host, const float* b1_host, const float* w2_host, int C, int F, void* out_host, size_t out_bytes);
 int dimx_op_mlp_fused_packed(float* x, const void* packed, const float* b2, const float* ln_g, const float* ln_b, int M, int C, int F,
                              int act, void* stream);
-/* The same kernel with the attention block's out-projection and residual in front (unit parity): x <- x + ao . Wo^T + bo, then the
- * feed-forward sublayer on the result.  ao: DEVICE bf16 [M, K_o] with row stride ld_ao (the attention kernel's output), K_o = 384 or 768;
- * wo_host [C, K_o] HOST f32; bo [C] device f32 or NULL.  Reference: `x = x + to_out(attn(LN(x)))` followed by `x = x + mlp(LN(x))`
- * (code/models/lib/base_models.py:148-170 and x-transformers' AttentionLayers).  Synchronises the stream. */
-int dimx_op_mlp_fused_attn(float* x, const void* ao, int ld_ao, const float* wo_host, const float* bo, int K_o, const float* w1_host,
-                           const float* b1_host, const float* w2_host, const float* b2, const float* ln_g, const float* ln_b, int M, int C, int F,
-                           int act, void* stream);
 int dimx_op_add_slabs_layernorm(int out_dtype, float* x, const float* slabs, int nslab, long slab_stride, void* y,
                                 const float* gamma, int M, int C, void* stream);
 /* One XCD-local chain launch of the decode step (csrc/chain.hip; bf16 only, B <= 256, 256-CU device):

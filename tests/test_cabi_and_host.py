@@ -105,3 +105,27 @@ def test_compact_by_mask_matches_reference_indexing():
     assert lens.tolist() == [3, 4]
     for i in range(2):
         assert torch.equal(xc[i, :lens[i]], x[i][mask[i]])
+
+
+def test_train_epoch_never_changes_backend_behind_the_caller():
+    """for a model of this package train_epoch(backward='auto') lands on the HIP step or raises with the
+    reason; the PyTorch-autograd restatement (dimx.train, the checker) runs only with backward='autograd'.  A foreign
+    nn.Module has no HIP backend to leave: the reference's generic loop runs it on torch."""
+    import torch
+    from dimx import lib, x_engine_pt
+    from dimx.seq2seq_pretrain import SLMFT
+    m = SLMFT()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-5)
+    with pytest.raises(lib.DimxError, match="not on a ROCm GPU"):
+        x_engine_pt.train_epoch(m, [], opt, torch.device("cpu"), log=lambda *_: None)
+    with pytest.raises(lib.DimxError, match="not on a ROCm GPU"):
+        x_engine_pt.train_epoch(m, [], opt, torch.device("cpu"), log=lambda *_: None, backward="hip")
+
+    class Foreign(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+    f = Foreign()
+    logs = []
+    out = x_engine_pt.train_epoch(f, [], torch.optim.SGD(f.parameters(), lr=0.1), torch.device("cpu"), log=logs.append)
+    assert out != out and any("not a dimx model" in ln for ln in logs)    # empty loader: nan mean, and the route was announced

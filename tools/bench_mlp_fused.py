@@ -21,17 +21,9 @@ x = torch.randn(M, C, device=dev)
 w1, b1, w2 = torch.randn(F, C) * C ** -0.5, torch.randn(F) * 0.05, torch.randn(C, F) * F ** -0.5
 b2, g, be = torch.randn(C, device=dev) * 0.02, torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
 hp = lambda t: ctypes.c_void_p(t.data_ptr())
-K_o = int(sys.argv[3]) if len(sys.argv) > 3 else 0     # 384 / 768: the kernel with the attention out-projection + residual in front
-if K_o:
-    ao = torch.randn(M, K_o, device=dev).to(torch.bfloat16)
-    wo, bo = torch.randn(C, K_o) * K_o ** -0.5, torch.randn(C, device=dev) * 0.02
 for act, beta in ((2, be), (3, None)):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for i in range(iters):
         xx = x.clone()
-        if K_o:
-            L.check(lib.dimx_op_mlp_fused_attn(L.ptr(xx), L.ptr(ao), K_o, hp(wo), L.ptr(bo), K_o, hp(w1), hp(b1), hp(w2), L.ptr(b2), L.ptr(g), L.ptr(beta),
-                                               M, C, F, act, L.stream_ptr(dev)), "mlp")
-        else:
-            L.check(lib.dimx_op_mlp_fused(L.ptr(xx), hp(w1), hp(b1), hp(w2), L.ptr(b2), L.ptr(g), L.ptr(beta), M, C, F, act, L.stream_ptr(dev)), "mlp")
+        L.check(lib.dimx_op_mlp_fused(L.ptr(xx), hp(w1), hp(b1), hp(w2), L.ptr(b2), L.ptr(g), L.ptr(beta), M, C, F, act, L.stream_ptr(dev)), "mlp")
     print("act %d ok, finite %s" % (act, bool(torch.isfinite(xx).all())))
