@@ -320,6 +320,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1, help="generations per clip in one pass (best-of-N protocol)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-mode-compare", action="store_true", help="skip the bf16-vs-f32 motion statistics (part of the parity-mode leg)")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--no-shard-check", action="store_true")
@@ -435,9 +436,14 @@ def main():
     if world == 1 and args.mode == "bf16" and not args.no_parity_mode and args.samples == 1:
         # the same workload in the mode that meets north_star's tolerance (f32 operands, exact-f32 MFMA; VQ indices
         # and generated tokens bit-identical to the oracle): 2 warm-ups + 5 timed steps
+        pm = SLMFT(synthetic_seed=SEED, numeric_mode=L.MODE_PARITY_F32).eval()
+        if not args.no_mode_compare:
+            # what the bf16 mode costs in the quantities the reference reports (per-clip FD / MSE / variance / STS of the generated
+            # motion): same clips, same sampler seed, both modes -- against the spread two sampler seeds give in the f32 mode
+            from dimx.mode_compare import compare_modes
+            out["bf16_vs_f32"] = compare_modes(model, pm, v_s, v_l, v_a, mask, seed=SEED + 777)
         del model, eng
         torch.cuda.empty_cache()
-        pm = SLMFT(synthetic_seed=SEED, numeric_mode=L.MODE_PARITY_F32).eval()
         PM_WARM, PM_STEPS = 2, 5
         for i in range(PM_WARM):
             pm(v_s, v_l, v_a, mask, mode="val", seed=SEED + i)
