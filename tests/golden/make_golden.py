@@ -184,7 +184,7 @@ def main():
     print(json.dumps(report, indent=1, sort_keys=True))
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--legacy", "--mymetrics", "--postprocess", "--host-protocol",
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--legacy", "--mymetrics", "--metrics-256", "--postprocess", "--host-protocol",
                                                              "--train-protocol")):
     main()
 
@@ -273,6 +273,46 @@ def mymetrics_fixture():
 
 if __name__ == "__main__" and "--mymetrics" in sys.argv:
     mymetrics_fixture()
+
+
+def metrics_256_fixture():
+    """``metrics_256.npz`` -- the reference's print_metrics / print_metrics_full (code/mymetrics.py:7-130) on a
+    full evaluation batch of 256 seeded per-clip lists (ragged lengths 20..299, the size BASELINE C3 evaluates), every scalar they
+    print + print_metrics' return value.  The inputs are regenerated from the integer PRNG by the test (the fixture stores the
+    lengths and the numbers only)."""
+    import contextlib
+    import io
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import mymetrics as ref_mm
+    finally:
+        os.chdir(cwd)
+    lens = [int(v) for v in prng.integers(SEED, "golden.m256.lens", (256,), 20, 300)]
+    gts = [prng.normal(SEED, "golden.m256.gt%d" % i, (n, 56)).astype(np.float64) for i, n in enumerate(lens)]
+    prs = [0.6 * g + 0.5 * prng.normal(SEED, "golden.m256.pr%d" % i, g.shape) for i, g in enumerate(gts)]
+    xs = [prng.normal(SEED, "golden.m256.x%d" % i, (n, 56)).astype(np.float64) for i, n in enumerate(lens)]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ret = ref_mm.print_metrics(gts, prs, xs)
+        ref_mm.print_metrics_full(gts, prs, xs)
+    labels, values = [], []
+    for line in buf.getvalue().strip().splitlines():
+        k, v = line.split(":")
+        labels.append(k.strip())
+        values.append([float(t) for t in v.split()])
+    width = max(len(v) for v in values)
+    arr = np.full((len(values), width), np.nan)
+    for i, v in enumerate(values):
+        arr[i, :len(v)] = v
+    np.savez_compressed(os.path.join(HERE, "metrics_256.npz"), lens=np.asarray(lens, np.int32), labels=np.asarray(labels),
+                        values=arr, ret=np.asarray([float(ret[0]), float(ret[1])]))
+    print("metrics_256:", dict(zip(labels, values)), "return", ret)
+
+
+if __name__ == "__main__" and "--metrics-256" in sys.argv:
+    metrics_256_fixture()
 
 
 def postprocess_fixture():

@@ -36,6 +36,29 @@ def test_print_metrics_match_reference(golden_dir):
     assert np.allclose(ret, exp["return"], rtol=1e-6)
 
 
+def test_print_metrics_match_reference_on_a_full_evaluation_batch(golden_dir):
+    """SURVEY Appendix C's metrics_256.npz: 256 ragged clips (20..299 frames), every scalar print_metrics / print_metrics_full of the
+    imported reference printed for them (tests/golden/make_golden.py --metrics-256) and print_metrics' return value."""
+    g = np.load(os.path.join(golden_dir, "metrics_256.npz"))
+    lens = [int(v) for v in g["lens"]]
+    gts = [prng.normal(SEED, "golden.m256.gt%d" % i, (n, 56)).astype(np.float64) for i, n in enumerate(lens)]
+    prs = [0.6 * a + 0.5 * prng.normal(SEED, "golden.m256.pr%d" % i, a.shape) for i, a in enumerate(gts)]
+    xs = [prng.normal(SEED, "golden.m256.x%d" % i, (n, 56)).astype(np.float64) for i, n in enumerate(lens)]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        ret = mymetrics.print_metrics(gts, prs, xs)
+        mymetrics.print_metrics_full(gts, prs, xs)
+    got = {}
+    for line in buf.getvalue().strip().splitlines():
+        k, v = line.split(":")
+        got[k.strip()] = [float(t) for t in v.split()]
+    exp = {str(k): [x for x in row if not np.isnan(x)] for k, row in zip(g["labels"], g["values"])}
+    assert list(got) == [str(k) for k in g["labels"]]          # same labels in the same order
+    for k, v in got.items():
+        assert np.allclose(v, exp[k], rtol=1e-6, atol=1e-9), (k, v, exp[k])
+    assert np.allclose(ret, g["ret"], rtol=1e-6)
+
+
 def test_pad_collate_and_synthetic_loader():
     batch = []
     for i, n in enumerate([7, 12, 5]):
