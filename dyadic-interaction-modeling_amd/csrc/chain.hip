@@ -656,7 +656,8 @@ __global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerCha
     __shared__ float sm_mr[2 * kGroupRows];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = (int)(xcc_id() & (a.fault ? 6u : 7u)), li = blockIdx.x >> 3;
-    const unsigned stamp = (unsigned)(*a.step) + 1u;
+    const unsigned epoch = (unsigned)((a.step ? *a.step : 0) + a.epoch_add);
+    const unsigned stamp = epoch + 1u;
     unsigned seen_old = 0;
     if (tid == 0) seen_old = atomicExch(a.seen + g * kGroupCUs + li, stamp);
     const int row0 = g * kGroupRows;
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerCha
     if (tid == 0 && seen_old == stamp) atomicOr(a.err, 1u);  // two blocks claimed the same (XCD, slot): not a bijection
     const int r_last = row0 + nrows - 1, C = a.C;
     unsigned* ctr = a.counters + 16 * g;
-    unsigned target = (unsigned)(*a.step) * (unsigned)(4 * kGroupCUs);
+    unsigned target = epoch * (unsigned)(4 * kGroupCUs);
     const bool has_clip = li < nrows;
     const int clip = row0 + (has_clip ? li : 0);
     float* sc = (float*)lds;
@@ -964,7 +965,7 @@ bool layer_chain_supported(const LayerChainArgs& a0, int cu_count) {
 
 int launch_layer_chain(const LayerChainArgs& a0, hipStream_t s) {
     LayerChainArgs a = a0;
-    DIMX_REQUIRE(a.x && a.y && a.o && a.qc && a.stats && a.colsum_cq && a.counters && a.seen && a.step && a.err, DIMX_ERR_ARG,
+    DIMX_REQUIRE(a.x && a.y && a.o && a.qc && a.stats && a.colsum_cq && a.counters && a.seen && a.err, DIMX_ERR_ARG,
                  "layer_chain: null operand");
     const size_t lds = layer_plan(a);
     DIMX_REQUIRE(lds <= kMaxDynLds, DIMX_ERR_ARG, "layer_chain: LDS plan %zu bytes", lds);

@@ -419,7 +419,8 @@ struct LayerChainArgs {
     int ld_qc;
     unsigned* counters;             // this launch site's per-XCD arrival counters [8][16] + claim stamps [8][32]
     unsigned* seen;
-    const int32_t* step;
+    const int32_t* step;            // epoch of the monotonic counters: launches on one counter set must see 0, 1, 2, ... (the decode
+    int epoch_add;                  // step counter in dimx_generate; nullptr + epoch_add = the call index in dimx_op_layer_chain)
     unsigned* err;
     int fault;
     unsigned long long* prof;       // tuning only: [256][16] phase stamps

@@ -2428,6 +2428,48 @@ int dimx_op_gemm_ln(int out_dtype, const void* A, const void* Ws, void* C, int M
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int dimx_op_layer_chain(const float* qkv, int nslab, long slab_stride, void* sk, void* sv, int T, const void* ck, const void* cv,
+                        int Tp, int n_keys, const uint8_t* kmask, const void* w_so, const void* w_cq, const float* colsum_cq,
+                        const void* w_co, float* x, void* y, void* o, float* qc, float* stats, int B, const int32_t* step,
+                        int call_index, float scale, void* scratch, void* prof, void* stream) {
+    DIMX_REQUIRE(qkv && sk && sv && ck && cv && w_so && w_cq && colsum_cq && w_co && x && y && o && qc && stats && step && scratch,
+                 DIMX_ERR_ARG, "op_layer_chain: null argument");
+    constexpr int H = 12, D = 64, inner = H * D, C = 1152;
+    LayerChainArgs lc;
+    memset(&lc, 0, sizeof(lc));
+    lc.B = B;
+    lc.C = C;
+    DecodeAttnArgs& sa = lc.sa;
+    sa.dtype = DIMX_BF16;
+    sa.q = qkv; sa.q_ld = 3 * inner; sa.q_f32 = 1; sa.nslab = nslab; sa.slab_stride = slab_stride;
+    sa.knew = qkv + inner; sa.vnew = qkv + 2 * inner; sa.kv_ld = 3 * inner;
+    sa.kcache = sk; sa.vcache = sv; sa.Tmax = T;
+    sa.out = o; sa.o_ld = inner; sa.B = B; sa.H = H; sa.step = step; sa.scale = scale;
+    DecodeAttnArgs& ca = lc.ca;
+    ca.dtype = DIMX_BF16;
+    ca.q = qc; ca.q_ld = inner; ca.q_f32 = 1; ca.nslab = 1; ca.slab_stride = (long)B * inner;
+    ca.kcache = (void*)ck; ca.vcache = (void*)cv; ca.Tmax = Tp;
+    ca.out = o; ca.o_ld = inner; ca.B = B; ca.H = H; ca.n_keys = n_keys; ca.kmask = kmask; ca.kmask_ld = n_keys; ca.scale = scale;
+    lc.g_so.W = w_so; lc.g_so.N = C; lc.g_so.K = inner; lc.g_so.ldw = inner;
+    lc.g_cq.W = w_cq; lc.g_cq.N = inner; lc.g_cq.K = C; lc.g_cq.ldw = C;
+    lc.g_co.W = w_co; lc.g_co.N = C; lc.g_co.K = inner; lc.g_co.ldw = inner;
+    lc.o = o; lc.ld_o = inner;
+    lc.x = x; lc.y = y; lc.stats = stats; lc.colsum_cq = colsum_cq;
+    lc.qc = qc; lc.ld_qc = inner;
+    lc.counters = (unsigned*)scratch;
+    lc.seen = lc.counters + 8 * 16;
+    lc.err = lc.counters + 768;
+    lc.step = nullptr;          // the counters' epoch is the call index; the self-attention reads its own step pointer (sa.step)
+    lc.epoch_add = call_index;
+    lc.prof = (unsigned long long*)prof;
+    lc.sc_stride = ((T > n_keys ? T : n_keys) + 15) / 16 * 16;
+    int cu = 0, dev = 0;
+    DIMX_HIP(hipGetDevice(&dev));
+    DIMX_HIP(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev));
+    DIMX_REQUIRE(layer_chain_supported(lc, cu), DIMX_ERR_ARG, "op_layer_chain: not supported here (B = %d needs 129..256 clips, a 256-CU device)", B);
+    return launch_layer_chain(lc, (hipStream_t)stream);
+}
+
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise, uint64_t seed,
                    uint64_t step, int32_t* tokens, void* stream) {
     // exp_noise here is the [R,512] slice of this step (step only salts the on-device generator)

@@ -117,6 +117,9 @@ SIGNATURES = {
                               c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dimx_op_chain_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dimx_op_layer_chain": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "dimx_op_gemm_ln": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p]),
     "dimx_op_sample": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p,

@@ -29,6 +29,7 @@ PROFILES = os.path.join(os.path.dirname(HERE), "profiles")
 
 
 DECODE_ATTN_SOURCES = ("decode_attn.hip", "decode_attn_body.hpp")   # the kernel body lives in the header since round 3
+LAYER_CHAIN_SOURCES = ("chain.hip", "decode_attn_body.hpp")          # xcd_layer_kernel (round 5): the attention bodies + the chain phases
 
 
 def kernel_source_hash(name=DECODE_ATTN_SOURCES):
@@ -51,6 +52,18 @@ def pmc_traffic(B, T, mode):
     if (rec.get("B"), rec.get("T"), rec.get("mode")) != (B, T, mode):
         return None
     return float(rec["traffic_bytes"])
+
+def pmc_traffic_layer(B, T, mode):
+    """HBM bytes per launch of the layer kernel (xcd_layer_kernel) from the PMC pass recorded for THIS source (tools/pmc_record.py)."""
+    path = os.path.join(PROFILES, "pmc_layer_chain_%s.json" % kernel_source_hash(LAYER_CHAIN_SOURCES))
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    if (rec.get("B"), rec.get("T"), rec.get("mode")) != (B, T, mode):
+        return None
+    return float(rec["traffic_bytes"])
+
 
 HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
@@ -89,6 +102,91 @@ def decode_attention(B, T, mode, device, iters=200):
     return {"kernel": "decode_attn_kernel<%s, false, true, 1> (cross-attention form, %d keys)" % ("dimx::bf16" if mode == "bf16" else "float", T), "bound": "hbm",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sec * 1e6}
+
+
+def layer_chain(B, T, device, iters=120, n_self=None, prof=None):
+    """The attention half of a decoder layer as dimx_generate launches it for 128 < B <= 256 clips in the bf16 mode (round 5:
+    chain.hip xcd_layer_kernel = self attention -> out-projection -> cross-q -> cross attention -> out-projection, one XCD-local
+    launch), at the MEAN self-attention cache fill of the loop (T / 2 keys), rotating over four layers' worth of caches and
+    weights (4 x {236 MB cross + 236 MB self} exceed the 256 MB Infinity Cache like they do in the loop).
+    Algorithmic bytes per launch: cross K/V B*12*T*64*2*2 + self K/V B*12*n*64*2*2 (+ the appended row) + the q/k/v slabs read
+    + o / qc / x / y rows + the three weight matrices ONCE (each XCD really reads its own copy: 8 x; `traffic` shows it)."""
+    from . import lib as L
+    lib = L.load()
+    H, D, C = 12, 64, 1152
+    inner = H * D
+    Tp = (T + 7) // 8 * 8
+    n = T // 2 if n_self is None else n_self
+    layers, nslab = 4, 2
+    bf = torch.bfloat16
+    ck = [torch.randn(B, H, Tp, D, device=device).to(bf) for _ in range(layers)]
+    cv = [torch.randn(B, H, Tp, D, device=device).to(bf) for _ in range(layers)]
+    sk = [torch.randn(B, H, T, D, device=device).to(bf) for _ in range(layers)]
+    sv = [torch.randn(B, H, T, D, device=device).to(bf) for _ in range(layers)]
+    wso = [(torch.randn(C, inner, device=device) / inner ** 0.5).to(bf) for _ in range(layers)]
+    wcq = [(torch.randn(inner, C, device=device) / C ** 0.5).to(bf) for _ in range(layers)]
+    wco = [(torch.randn(C, inner, device=device) / inner ** 0.5).to(bf) for _ in range(layers)]
+    cs = [w.float().sum(1).contiguous() for w in wcq]
+    qkv = torch.randn(nslab, B, 3 * inner, device=device) * 0.5
+    x0 = torch.randn(B, C, device=device)
+    x = x0.clone()
+    y = torch.empty(B, C, device=device, dtype=bf)
+    o = torch.empty(B, inner, device=device, dtype=bf)
+    qc = torch.empty(B, inner, device=device)
+    stats = torch.zeros(8, 32, 32, 2, device=device)
+    km = torch.ones(B, T, dtype=torch.uint8, device=device)
+    step = torch.tensor([n], dtype=torch.int32, device=device)
+    scratch = torch.zeros(1024, dtype=torch.int32, device=device)
+    calls = [0]
+
+    def run(i):
+        j = i % layers
+        if calls[0] % 64 == 0:
+            x.copy_(x0)          # the residual stream grows by two projections per call: keep it in range (outside nothing: a copy per 64 launches)
+        L.check(lib.dimx_op_layer_chain(L.ptr(qkv), nslab, B * 3 * inner, L.ptr(sk[j]), L.ptr(sv[j]), T, L.ptr(ck[j]), L.ptr(cv[j]), Tp, T,
+                                        L.ptr(km), L.ptr(wso[j]), L.ptr(wcq[j]), L.ptr(cs[j]), L.ptr(wco[j]), L.ptr(x), L.ptr(y), L.ptr(o),
+                                        L.ptr(qc), L.ptr(stats), B, L.ptr(step), calls[0], 0.125, L.ptr(scratch), L.ptr(prof),
+                                        L.stream_ptr(device)), "dimx_op_layer_chain")
+        calls[0] += 1
+    sec = _time_launches(run, 40, iters)
+    flags = int(scratch[768].item())
+    kv = B * H * 64 * 2 * 2
+    alg = kv * T + kv * n + kv                      # cross K/V, cached self K/V, the appended row
+    alg += nslab * B * 3 * inner * 4                # q / k / v slabs
+    alg += 2 * (B * inner * 2 * 2)                  # o written + read, twice
+    alg += B * inner * 4 * 2                        # qc written + read
+    alg += 2 * (B * C * 4 * 2 + B * C * 2)          # x read + written, y written, twice
+    alg += B * C * 2                                # y read by the q projection
+    alg += 3 * C * inner * 2                        # the three weight matrices, once
+    gbs = alg / sec / 1e9
+    return {"kernel": "xcd_layer_kernel<2, 1, 2> (one decoder layer's attention half: self attention at %d cached keys -> out-projection -> cross-q -> "
+                      "cross attention over %d keys -> out-projection; B = %d)" % (n, T, B),
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": pmc_traffic_layer(B, T, "bf16"), "algorithmic_bytes_per_launch": alg, "avg_launch_us": sec * 1e6,
+            "error_flags": flags,
+            "note": "the launch contains two HBM streams (attention, ~0.85 of the launch) and three latency-bound projections with four "
+                    "XCD-local group barriers; `phases` (bench.py) splits it with in-kernel stamps"}
+
+
+def layer_chain_phases(B, T, device, n_self=None):
+    """in-kernel wall-clock stamps (100 MHz) of one xcd_layer_kernel launch: phase ends in us after the first block's start, mean and
+    max over the 256 blocks, and the HBM rate of the two attention phases including the group barrier that closes them."""
+    prof = torch.zeros(256 * 16, dtype=torch.int64, device=device)
+    layer_chain(B, T, device, iters=24, n_self=n_self, prof=prof)
+    p = prof.view(256, 16).cpu().double()
+    t0 = p[:, 0][p[:, 0] > 0].min()
+    us = (p[:, :13] - t0) / 100.0
+    names = ["start", "self attention done", "barrier 1", "rows + W1 landed", "out-proj stored", "barrier 2", "y rows + W2 landed",
+             "cross-q stored", "barrier 3", "cross attention done", "barrier 4", "rows + W3 landed", "out-proj stored"]
+    out = {"stamps_us_mean_max": {"%02d %s" % (i, nm): [float(us[:, i].mean()), float(us[:, i].max())] for i, nm in enumerate(names)}}
+    n = T // 2 if n_self is None else n_self
+    kv = B * 12 * 64 * 2 * 2
+    self_us = float(us[:, 2].mean() - us[:, 0].mean())
+    cross_us = float(us[:, 10].mean() - us[:, 8].mean())
+    out["self_attention_phase"] = {"us_incl_barrier": self_us, "GBps": kv * n / self_us / 1e3, "frac_of_hbm_peak": kv * n / self_us / 1e3 / HBM_PEAK_GBS}
+    out["cross_attention_phase"] = {"us_incl_barrier": cross_us, "GBps": kv * T / cross_us / 1e3, "frac_of_hbm_peak": kv * T / cross_us / 1e3 / HBM_PEAK_GBS}
+    out["projections_and_barriers_us"] = float(us[:, 12].mean() - us[:, 0].mean()) - self_us - cross_us
+    return out
 
 
 def decode_self_attention(B, T, mode, device, iters=40):
@@ -329,6 +427,16 @@ def dominant_kernel(eng, B, T, mode):
     dev = eng.device
     att = decode_attention(B, T, mode, dev)
     gem = decode_gemm(B, mode, dev)
+    if mode == "bf16" and 128 < B <= 256:
+        # round 5: for this batch range the attentions run inside xcd_layer_kernel (4 launches per decode step, ~70 % of it): THAT
+        # is the dominant kernel of the trace; the standalone attention kernel (smaller batches, several samples per clip, the f32
+        # mode) stays on the line under `others` with its own PMC traffic record
+        first = layer_chain(B, T, dev)
+        first["phases"] = layer_chain_phases(B, T, dev)
+        first["secondary"] = gem
+        first["others"] = [att, decode_self_attention(B, T, mode, dev), decode_layernorm(B, mode, dev)]
+        first["others"] += prefill_mlp_fused(B, T, dev)
+        return first
     # per decode step: 8 attention launches vs 16 small-M GEMM launches of comparable size
     att_share = 8 * att["avg_launch_us"]
     gem_share = 16 * gem["avg_launch_us"]

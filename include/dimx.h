@@ -364,6 +364,21 @@ int dimx_op_chain_ln(const void* A1, int K1, const void* W1, float* x, void* y, 
  * Ws[n][k]; out_dtype DIMX_BF16 / DIMX_F32; M <= 256. */
 int dimx_op_gemm_ln(int out_dtype, const void* A, const void* Ws, void* C, int M, int N, int K, const float* bias, int act,
                     const float* stats, const float* colsum, void* stream);
+/* The attention half of one decoder layer of the decode step as ONE XCD-local launch (csrc/chain.hip xcd_layer_kernel; what
+ * dimx_generate runs per layer for 128 < B <= 256 clips in the bf16 mode; x-transformers Decoder layer, reference
+ * code/seq2seq_pretrain.py:413-419, one step of AutoregressiveWrapper.generate :450):
+ *   o = self-attention(q, k, v of this step summed from the nslab f32 slabs qkv[s][B, 3*768]; keys = *step cached rows of
+ *       sk / sv [B,12,T,64] bf16, the new row is appended);   x += o . Wso^T;   y = bf16(x);   qc = LN(x) . Wq^T in its deferred
+ *   form (w_cq = gamma o Wq, colsum_cq its row sums);   o = cross-attention(qc, ck / cv [B,12,Tp,64] bf16, n_keys, kmask [B,n_keys]);
+ *   x += o . Wco^T;   y = bf16(x);   stats = the partial row sums of x for the consumer's deferred LayerNorm.
+ * w_so / w_co [1152][768], w_cq [768][1152] bf16 row-major; x [B,1152] f32, y [B,1152] bf16, o [B,768] bf16, qc [B,768] f32,
+ * stats [8][32][32][2] f32; *step = cached self-attention keys; scratch >= 4096 bytes, zeroed by the caller before the first call
+ * (arrival counters, claim stamps, error flags at word 768: 0 = ok); call_index = 0, 1, 2, ... on the same scratch (the epoch
+ * of its monotonic counters). */
+int dimx_op_layer_chain(const float* qkv, int nslab, long slab_stride, void* sk, void* sv, int T, const void* ck, const void* cv,
+                        int Tp, int n_keys, const uint8_t* kmask, const void* w_so, const void* w_cq, const float* colsum_cq,
+                        const void* w_co, float* x, void* y, void* o, float* qc, float* stats, int B, const int32_t* step,
+                        int call_index, float scale, void* scratch, void* prof, void* stream);
 /* tokens = sampler(logits[R,512]) -- see dimx_generate. */
 int dimx_op_sample(const float* logits, int R, int top_k, float temperature, const float* exp_noise,
                    uint64_t seed, uint64_t step, int32_t* tokens, void* stream);

@@ -9,5 +9,6 @@ import dimx  # noqa
 from dimx import roofline
 
 dev = torch.device("cuda:0")
-print(json.dumps({"attn": roofline.decode_attention(256, 300, "bf16", dev, iters=20),
+print(json.dumps({"layer": roofline.layer_chain(256, 300, dev, iters=20),
+                  "attn": roofline.decode_attention(256, 300, "bf16", dev, iters=20),
                   "gemm": roofline.decode_gemm(256, "bf16", dev, iters=20)}))
