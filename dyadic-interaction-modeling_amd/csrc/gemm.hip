@@ -1286,14 +1286,25 @@ struct Ws72 {
         f32x16_t acc[1][1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-        // the lane's column: bias and (deferred LayerNorm) the column sum of the gamma-scaled weights are requested NOW -- the
-        // consumers wait ~1.5 us for the first tile anyway; as dependent loads behind the main loop they cost 0.5 us per launch
+        // Everything the epilogue needs is fetched NOW -- the consumers wait ~1.5 us for the first tile anyway: the lane's bias and
+        // (deferred LayerNorm) column sum (as dependent loads behind the main loop they cost 0.5 us per launch), and the kernel
+        // arguments of the store (destination, row stride, slab offset, activation: behind the loop their scalar loads were another
+        // 0.4 us, tools/r05_gemm_stamps.py).  The kernel only takes plain row-major destinations (gemm_use_ws72), so the epilogue is
+        // 16 stores per lane and nothing else.
         const int n_lim = n0 + BN < a.N ? n0 + BN : a.N;
         const int ncol = n0 + wn * 32 + l31;
-        const int ncl = ncol < n_lim ? ncol : n_lim - 1;
-        float bias_pre[1];
-        bias_pre[0] = (a.bias && split == 0) ? a.bias[ncl] : 0.f;
+        const bool col_ok = ncol < n_lim;
+        const int ncl = col_ok ? ncol : n_lim - 1;
+        const float bias_v = (a.bias && split == 0) ? a.bias[ncl] : 0.f;
         const float ln_cs = a.ln_stats ? a.ln_colsum[ncl] : 0.f;
+        const int ldc = (int)a.seg[0].st;
+        const int row_base = m0 + wm * 32 + 4 * half;
+        OutT* cptr = (OutT*)a.seg[0].ptr + (a.out_slabs ? (size_t)split * a.slab_stride : 0) + (size_t)row_base * ldc + ncl;
+        const float* rptr = a.residual ? a.residual + (size_t)row_base * a.ldr + ncl : nullptr;
+        const int ldr = a.ldr;
+        const int mrem = a.M - row_base;
+        const int act = a.act;
+        const bool has_ln = a.ln_stats != nullptr;
         const int nst = (nk + KT - 1) / KT;
         unsigned boff = 0;
         for (int st = 0; st < nst; ++st) {
@@ -1345,7 +1356,7 @@ struct Ws72 {
             boff = boff + SLOT_BYTES == STAGES * SLOT_BYTES ? 0u : boff + SLOT_BYTES;
         }
         stamp(28);
-        if (a.ln_stats) {
+        if (has_ln) {
             const float* strip = ln_sm + wm * 32;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1357,9 +1368,52 @@ struct Ws72 {
                 acc[0][0][4 * q + 3] = rq.w * (acc[0][0][4 * q + 3] - mq.w * ln_cs);
             }
         }
-        epilogue<bf16, OutT, 1, 1>(a, acc, m0 + wm * 32, n0 + wn * 32, half, l31, split,
-                                   (PROF && wave == 0 && lane == 0) ? a.prof + (size_t)block_id * 64 : nullptr, n_lim, bias_pre);
+        if (PROF && wave == 0 && lane == 0) a.prof[(size_t)block_id * 64 + 24] = wall_clock64();
+        float v[16];
+        switch (act) {
+            case ACT_GELU_ERF:
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = act_fn<ACT_GELU_ERF, true>(acc[0][0][r] + bias_v);
+                break;
+            case ACT_GELU_TANH:
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = act_fn<ACT_GELU_TANH, true>(acc[0][0][r] + bias_v);
+                break;
+            case ACT_LEAKY:
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = act_fn<ACT_LEAKY, true>(acc[0][0][r] + bias_v);
+                break;
+            default:
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[0][0][r] + bias_v;
+                break;
+        }
+        if (PROF && wave == 0 && lane == 0) a.prof[(size_t)block_id * 64 + 25] = wall_clock64();
+        if (col_ok) {
+            if (rptr) {  // all residual loads in flight together; rows past M read the last valid row (never stored)
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int off = (r & 3) + 8 * (r >> 2);
+                    off = off < mrem ? off : mrem - 1;
+                    rv[r] = rptr[(size_t)off * ldr];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += rv[r];
+            }
+            if (mrem > 27) {  // the lane's last row is row_base + 27: no per-row checks for interior tiles
+#pragma unroll
+                for (int r = 0; r < 16; ++r) store_from_f32<OutT>(cptr + (size_t)((r & 3) + 8 * (r >> 2)) * ldc, v[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    if (off < mrem) store_from_f32<OutT>(cptr + (size_t)off * ldc, v[r]);
+                }
+            }
+        }
         if (PROF) {
+            if (wave == 0 && lane == 0) a.prof[(size_t)block_id * 64 + 26] = wall_clock64();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(29);
         }
@@ -1551,7 +1605,9 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
     if (cfg == 0) cfg = tiles128 >= (sizeof(T) == 2 ? 288 : 512) ? 14 : gemm_cfg_small();
     if (a.cfg == 0 && sizeof(T) == 4 && a.out_slabs) cfg = gemm_cfg_small();  // f32 slabs: one tile shape whatever M is (see gemm_plan_splits)
     if (a.cfg == 0 && gemm_use_ws72(a0)) cfg = 72;
-    DIMX_REQUIRE(cfg != 72 || (sizeof(T) == 2 && a.N % 72 == 0 && !a.w_tiled), DIMX_ERR_ARG, "gemm: cfg 72 needs bf16 operands and N %% 72 == 0 (N=%d)", a.N);
+    DIMX_REQUIRE(cfg != 72 || (sizeof(T) == 2 && a.N % 72 == 0 && !a.w_tiled && a.nseg == 1 && a.seg[0].sd == 1 && a.seg[0].sh == 0 &&
+                               a.seg[0].sb == a.seg[0].st * (long)a.rowT && a.rowadd_mode == 0),
+                 DIMX_ERR_ARG, "gemm: cfg 72 needs bf16 operands, N %% 72 == 0 (N=%d) and a plain row-major destination", a.N);
     if (a.out_slabs) {
         a.splitk = gemm_plan_splits(a0);
         a.residual = nullptr;
@@ -1673,6 +1729,8 @@ static bool gemm_use_ws72(const GemmArgs& a) {
     const int kext = a.kloop ? a.kloop : a.ldw;
     if (a.conv_T != 0 || a.K % 64 != 0 || a.K != kext || a.force_simple || a.w_tiled) return false;
     if (a.M > 256 || a.N % 72 != 0) return false;
+    // its epilogue stores to a plain row-major destination only (what gemm_set_plain_out builds; the decode step's GEMMs)
+    if (a.nseg != 1 || a.seg[0].sd != 1 || a.seg[0].sh != 0 || a.seg[0].sb != a.seg[0].st * (long)a.rowT || a.rowadd_mode != 0) return false;
     return ceil_div(a.M, 64) * (a.N / 72) <= 256;
 }
 

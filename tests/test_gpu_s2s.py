@@ -251,3 +251,30 @@ def test_layer_kernel_reproduces_the_four_launches_bit_for_bit(full_sd):
     g0, s0, f0 = run(True)
     assert f0 == 0 and f1 == 0
     assert torch.equal(g1, g0) and torch.equal(s1, s0)
+
+
+def test_layer_kernel_fault_is_reported_and_repaired(full_sd):
+    """the layer kernel answers for its placement like the chain kernels do: with a forced non-bijective (XCD, CU slot) claim the
+    SAME generate() call notices, regenerates the batch on the one-kernel-per-op step and counts the event."""
+    import os
+    from dimx import engine, lib
+    B, T = 160, 24
+    v_s, v_a, z, mask = _case(B, T, [T] * B, seed=41)
+    m8 = mask.to(torch.uint8).cuda()
+    os.environ["DIMX_NO_CHAIN"] = "1"
+    try:
+        ref_eng = engine.Engine("cuda:0", lib.MODE_PERF_BF16)
+    finally:
+        os.environ.pop("DIMX_NO_CHAIN", None)
+    ref_eng.load_state_dict(full_sd)
+    ref_eng.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+    ref_tok = ref_eng.generate(z[:, 0].cuda(), m8, T, 0.0).cpu()
+    ref_eng.close()
+    e = engine.Engine("cuda:0", lib.MODE_PERF_BF16)
+    e.load_state_dict(full_sd)
+    e.debug_chain_fault(1)
+    e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+    tok = e.generate(z[:, 0].cuda(), m8, T, 0.0).cpu()
+    assert e.chain_faults() == 1
+    assert torch.equal(tok, ref_tok)
+    e.close()
