@@ -260,8 +260,9 @@ def decode_gemm(B, mode, device, iters=40):
     flops = 2.0 * M * N * K
     tf = flops / sec / 1e12
     peak = MFMA_PEAK_TFLOPS[mode]
-    return {"kernel": "gemm_ws_kernel<%s,float> M=%d N=%d K=%d (decode FF down-projection, split-K slabs; latency-bound: "
-                      "4.7 MB of weights per launch)" % (mode, M, N, K),
+    name = "gemm_ws72_kernel<float> (64 x 72 tiles, one block per CU)" if (bf and M <= 256) else "gemm_ws_kernel<%s,float>" % mode
+    return {"kernel": "%s M=%d N=%d K=%d (decode FF down-projection, split-K slabs; latency-bound: "
+                      "4.7 MB of weights per launch)" % (name, M, N, K),
             "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
             "algorithmic_flops_per_launch": flops, "avg_launch_us": sec * 1e6}
 
@@ -401,10 +402,21 @@ def cross_attn_bundle(B, T, mode, device, roof, kv):
     MFMA-bound member (`cross_attn_mfma`).  `teacher_forced_cross_attention` is the same attention in mode='train'."""
     assert mode == "bf16"
     depth, steps = 4, T - 1
-    att = roof if "decode_attn" in roof.get("kernel", "") else roof.get("secondary", {})
-    t_att = att["avg_launch_us"]
-    t_a = _chain_launch_us(B, device, True)
-    t_b = _chain_launch_us(B, device, False)
+    layer = roof.get("phases") if "xcd_layer_kernel" in roof.get("kernel", "") else None
+    if layer is not None:
+        # round 5: the decode step's cross attention and its two projections are phases of xcd_layer_kernel -- their time comes
+        # from its in-kernel stamps (means over the 256 blocks): cross-q = barrier 2 -> barrier 3, the attention = barrier 3 ->
+        # barrier 4, the out-projection = barrier 4 -> end
+        st = {k[:2]: v[0] for k, v in layer["stamps_us_mean_max"].items()}
+        t_att = st["10"] - st["08"]
+        t_a = 2.0 * (st["08"] - st["05"])       # charged half below, like the chain launch that also held the self out-projection
+        t_b = st["12"] - st["10"]
+    else:
+        att = roof if "decode_attn" in roof.get("kernel", "") else next(
+            (o for o in [roof.get("secondary", {})] + roof.get("others", []) if "decode_attn" in o.get("kernel", "")), {})
+        t_att = att["avg_launch_us"]
+        t_a = _chain_launch_us(B, device, True)
+        t_b = _chain_launch_us(B, device, False)
     f_kv = 2.0 * B * T * (depth * 1536) * 1152
     f_proj = 2.0 * B * 1152 * 768                    # one projection of one layer-step
     f_att = 4.0 * B * 768 * T                        # scores + AV of one layer-step
@@ -415,7 +427,8 @@ def cross_attn_bundle(B, T, mode, device, roof, kv):
             "util_pct": 100.0 * tf / MFMA_PEAK_TFLOPS["bf16"], "time_ms_per_batch": t_total / 1e3,
             "parts_us": {"kv_projection (1 launch, 4 layers)": kv["avg_launch_us"], "decode_cross_attention (per launch)": t_att,
                          "chain: self out-proj + residual + cross q-proj (per launch, half charged)": t_a,
-                         "chain: cross out-proj + residual (per launch)": t_b, "launches_per_batch": depth * steps},
+                         "chain: cross out-proj + residual (per launch)": t_b, "launches_per_batch": depth * steps,
+                         "source": "phases of xcd_layer_kernel (in-kernel stamps)" if layer is not None else "separate launches (HIP events)"},
             "parts_gflop_per_clip": {"kv_projection": f_kv / B / 1e9, "q_and_out_projections": depth * steps * 2 * f_proj / B / 1e9,
                                      "scores_and_av": depth * steps * f_att / B / 1e9},
             "teacher_forced_cross_attention": prefill_cross_attention(B, T, device)}

@@ -28,14 +28,7 @@ def run(label, N, K, act, out_bf16, slabs, bias_on, iters=24, ncopies=8, cfg=0, 
     out = torch.empty(max(slabs, 1) * M, N, device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     flags = ((5 | (slabs << 16)) if slabs else 0) | (cfg << 8)
     warm = 4
-    if frag:   # gemm_dec_kernel: weights packed once, outside the measured launches
-        from dimx import engine
-        wfs = [engine.op_pack_w_frag(w) for w in ws]
-        torch.cuda.synchronize()
-        for i in range(warm + iters):
-            L.check(lib.dimx_op_gemm_dec(L.ptr(a), K, L.ptr(wfs[i % ncopies]), L.ptr(out), N, L.BF16 if out_bf16 else L.F32, M, N, K,
-                                         L.ptr(bias), act, slabs, None, None, None, L.stream_ptr(dev)), "gemm_dec")
-    for i in range(0 if frag else warm + iters):
+    for i in range(warm + iters):
         L.check(lib.dimx_op_gemm(L.BF16, L.BF16 if out_bf16 else L.F32, L.ptr(a), K, L.ptr(ws[i % ncopies]), K, L.ptr(out), N, M, N, K,
                                  L.ptr(bias), act, None, N, 0, None, flags, L.stream_ptr(dev)), "gemm")
     torch.cuda.synchronize()
@@ -43,12 +36,6 @@ def run(label, N, K, act, out_bf16, slabs, bias_on, iters=24, ncopies=8, cfg=0, 
     plan.append((label, "N%d/s%d/c%d%s" % (N, slabs, cfg, "/frag" if frag else ""), warm, iters))
 
 
-if len(sys.argv) > 2 and sys.argv[2] == "frag":   # gemm_dec_kernel only (run once per DIMX_DEC_ABL setting)
-    run("ff1 N4608 K1152 gelu bf16-out", 4608, 1152, 3, True, 0, True, frag=True)
-    run("ff2 N1152 K4608 4 slabs", 1152, 4608, 0, False, 4, False, frag=True)
-    run("qkv N2304 K1152 2 slabs", 2304, 1152, 0, False, 2, False, frag=True)
-    json.dump(plan, open(sys.argv[1], "w"))
-    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "ws72":   # the real shapes: 64 x 64 tiles (cfg 34, 288 blocks) vs 64 x 72 (cfg 72, 256 blocks)
     for cfg, fr in ((34, False), (72, False)):
         run("ff1 N4608 K1152 gelu bf16-out", 4608, 1152, 3, True, 0, True, cfg=cfg, frag=fr)
