@@ -29,6 +29,7 @@ PROFILES = os.path.join(os.path.dirname(HERE), "profiles")
 
 
 DECODE_ATTN_SOURCES = ("decode_attn.hip", "decode_attn_body.hpp")   # the kernel body lives in the header since round 3
+PREFILL_MFMA_SOURCES = ("mlp_fused.hip", "attention_tr.hip")         # tools/pmc_prefill_record.py
 LAYER_CHAIN_SOURCES = ("chain.hip", "decode_attn_body.hpp")          # xcd_layer_kernel (round 5): the attention bodies + the chain phases
 
 
@@ -99,7 +100,9 @@ def decode_attention(B, T, mode, device, iters=200):
     # HBM bytes per launch from the PMC pass recorded for this kernel source (FETCH_SIZE doubled for 16-B/lane
     # streaming reads on gfx950 per MI355X_MICROARCH.md + WRITE_SIZE), else null
     traffic = pmc_traffic(B, T, mode)
-    return {"kernel": "decode_attn_kernel<%s, false, true, 1> (cross-attention form, %d keys)" % ("dimx::bf16" if mode == "bf16" else "float", T), "bound": "hbm",
+    pairs = B * H   # waves per (clip, head): launch_decode_attn's rule (csrc/decode_attn.hip)
+    nsplit = (4 if pairs * 4 <= 3072 else 2 if pairs * 2 <= 3072 else 1) if mode == "bf16" else (4 if Tp >= 1024 else 2 if Tp >= 512 else 1)
+    return {"kernel": "decode_attn_kernel<%s, false, true, %d> (cross-attention form, %d keys)" % ("dimx::bf16" if mode == "bf16" else "float", nsplit, T), "bound": "hbm",
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": sec * 1e6}
 
@@ -336,6 +339,19 @@ def _chain_launch_us(B, device, with_q, iters=60):
     return sec * 1e6
 
 
+def pmc_prefill_busy(kernel_prefix):
+    """MFMA busy % of a prefill kernel from the PMC pass recorded for the current sources (tools/pmc_prefill_record.py), else None"""
+    path = os.path.join(PROFILES, "pmc_prefill_mfma_%s.json" % kernel_source_hash(PREFILL_MFMA_SOURCES))
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    for k, v in rec.get("kernels", {}).items():
+        if k.startswith(kernel_prefix):
+            return v.get("mfma_busy_pct")
+    return None
+
+
 def prefill_cross_attention(B, T, device, iters=10):
     """The teacher-forced cross attention (mode='train': 299 queries x 300 context keys, 12 heads x 64, context mask) on the
     prefill attention kernel: MFMA utilisation = 4 B H Lq Lk 64 flops / time / 2.5 PFLOP/s."""
@@ -355,7 +371,8 @@ def prefill_cross_attention(B, T, device, iters=10):
     flops = 4.0 * B * H * Lq * Lk * D
     tf = flops / sec / 1e12
     return {"kernel": "attn_tr_kernel<64, 2> (persistent, row-major q / k / v, Lq %d x Lk %d, 12 heads x 64, context mask)" % (Lq, Lk),
-            "avg_launch_us": sec * 1e6, "achieved": tf, "unit": "TFLOP/s", "util_pct": 100.0 * tf / MFMA_PEAK_TFLOPS["bf16"]}
+            "avg_launch_us": sec * 1e6, "achieved": tf, "unit": "TFLOP/s", "util_pct": 100.0 * tf / MFMA_PEAK_TFLOPS["bf16"],
+            "pmc_mfma_busy_pct": pmc_prefill_busy("attn_tr_kernel<64")}
 
 
 def prefill_mlp_fused(B, T, device, iters=8):
@@ -387,7 +404,7 @@ def prefill_mlp_fused(B, T, device, iters=8):
         out.append({"kernel": "mlp_fused_kernel (x += W2 gelu(W1 LN(x) + b1) + b2 in one launch, M %d x 384 -> 1536 -> 384; %s)" % (M, name),
                     "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS["bf16"],
                     "traffic": None, "algorithmic_flops_per_launch": 4.0 * M * C * F, "algorithmic_bytes_per_launch": 3 * M * C * 4,
-                    "avg_launch_us": sec * 1e6})
+                    "avg_launch_us": sec * 1e6, "pmc_mfma_busy_pct": pmc_prefill_busy("mlp_fused_kernel<%d" % act)})
     return out
 
 
@@ -449,6 +466,9 @@ def dominant_kernel(eng, B, T, mode):
         first["secondary"] = gem
         first["others"] = [att, decode_self_attention(B, T, mode, dev), decode_layernorm(B, mode, dev)]
         first["others"] += prefill_mlp_fused(B, T, dev)
+        pa = prefill_cross_attention(B, T, dev)
+        pa.update(bound="mfma", peak=MFMA_PEAK_TFLOPS["bf16"], frac=pa["util_pct"] / 100.0, traffic=None)
+        first["others"].append(pa)
         return first
     # per decode step: 8 attention launches vs 16 small-M GEMM launches of comparable size
     att_share = 8 * att["avg_launch_us"]

@@ -28,6 +28,7 @@ python tools/pmc_gemm256_record.py $O/r05_pmc_mfma_cross_kv.txt $O/r05_cross_kv_
 # MFMA busy of the two other MFMA kernels of the prefill (fused feed-forward sublayer, prefill attention), same counters
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_pre -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-mode --no-train-step --no-roofline > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_pre | grep -A8 "mlp_fused_kernel\|attn_tr_kernel" > $O/r05_pmc_mfma_prefill_kernels.txt
+python tools/pmc_prefill_record.py $O/r05_pmc_mfma_prefill_kernels.txt $COMMIT >> $O/r05_pmc_record.txt 2>&1
 cp profiles/pmc_*.json $O/ 2>/dev/null
 MISSING=0
 python - <<PY || MISSING=1
@@ -36,7 +37,7 @@ sys.path.insert(0, ".")
 import dimx
 from dimx import roofline as R
 need = ["pmc_layer_chain_%s.json" % R.kernel_source_hash(R.LAYER_CHAIN_SOURCES), "pmc_decode_attn_%s.json" % R.kernel_source_hash(),
-        "pmc_gemm256_%s.json" % R.kernel_source_hash("gemm256.hip")]
+        "pmc_gemm256_%s.json" % R.kernel_source_hash("gemm256.hip"), "pmc_prefill_mfma_%s.json" % R.kernel_source_hash(R.PREFILL_MFMA_SOURCES)]
 miss = [n for n in need if not os.path.exists(os.path.join(R.PROFILES, n))]
 print("PMC records:", "all present" if not miss else "MISSING " + ", ".join(miss))
 sys.exit(1 if miss else 0)
