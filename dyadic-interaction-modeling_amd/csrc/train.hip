@@ -359,6 +359,9 @@ struct Step {
     float* pool = nullptr;   // their partial rows: a region of its own (they outlive the sublayers' rolled-back scratch)
     size_t pool_off = 0, pool_cap = 0;
     bool pool_overflow = false;
+    // An overflow hands the pool base back so that the walk can finish, and the run ends in DIMX_ERR_STATE.  No kernel ever
+    // writes through such a pointer: every entry point runs the sizing pass (ws == nullptr, nothing launched) first, that pass
+    // makes the same pool_f32 calls with the same pool_cap, and its failure returns before the live pass starts.
     float* pool_f32(size_t n_) {
         n_ = (n_ + 63) / 64 * 64;
         if (pool_off + n_ > pool_cap) {
