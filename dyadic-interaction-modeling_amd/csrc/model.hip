@@ -14,6 +14,7 @@
 // device-resident step counter.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <set>
 
 #include "model.hpp"
 
@@ -177,6 +178,28 @@ static std::vector<KeySpec> all_keys(const dimx_dims& d) {
     return k;
 }
 
+static bool ends_with(const std::string& n, const char* suf) {
+    const size_t l = strlen(suf);
+    return n.size() >= l && n.compare(n.size() - l, l, suf) == 0;
+}
+
+// SURVEY A.2 marks three details of x-transformers 1.30.16 [XT?] (restated from the library's published source, not verifiable
+// here): project_in and to_logits are bias-free Linears and LayerNorm has no bias.  A checkpoint written by another release
+// of the library carries them, so they are OPTIONAL tensors: a project_in.bias / to_logits.bias is applied when it is loaded;
+// a LayerNorm bias (the zero `beta` buffer the reference's loader renames to `bias`, code/finetune_s2s_pretrain.py:49-57) is
+// accepted when it is zero and refused otherwise -- never dropped in silence.
+enum { OPT_NONE = 0, OPT_LINEAR_BIAS = 1, OPT_NORM_BIAS = 2 };
+static int optional_key(const std::map<std::string, std::vector<int64_t>>& spec, const std::string& n, std::vector<int64_t>* shape) {
+    if (!ends_with(n, ".bias")) return OPT_NONE;
+    const std::string w = n.substr(0, n.size() - 4) + "weight";
+    auto it = spec.find(w);
+    if (it == spec.end()) return OPT_NONE;
+    *shape = {it->second[0]};
+    if (ends_with(w, "project_in.weight") || ends_with(w, "to_logits.weight")) return OPT_LINEAR_BIAS;
+    if (w.find("attn_layers.") != std::string::npos && it->second.size() == 1) return OPT_NORM_BIAS;
+    return OPT_NONE;
+}
+
 static bool ignorable_key(const std::string& n) {
     static const char* pre[] = {"encoder_l.", "norm_l.", "norm.", "patch_embed_l", "patch_embed_dec_l",
                                 // legacy ListenerGenerator tensors that are not on the ids=None path
@@ -184,8 +207,7 @@ static bool ignorable_key(const std::string& n) {
                                 "listener_embeddings.", "fc_speaker.", "fc_listener."};
     for (const char* p : pre)
         if (n.rfind(p, 0) == 0) return true;
-    const std::string suf = ".project_out.weight";
-    return n.size() >= suf.size() && n.compare(n.size() - suf.size(), suf.size(), suf) == 0;
+    return ends_with(n, ".project_out.weight") || ends_with(n, ".project_out.bias");
 }
 
 // ------------------------------------------------------------------ packing
@@ -383,7 +405,8 @@ static int pack_xff(dimx_ctx* c, const std::string& p, XFF* f) {
     return DIMX_OK;
 }
 static int pack_xenc(dimx_ctx* c, const std::string& pre, XEnc* e) {
-    DIMX_TRY(pack_linear(c, {pre + "project_in.weight"}, "", false, &e->proj_in));
+    DIMX_TRY(pack_linear(c, {pre + "project_in.weight"}, c->host.count(pre + "project_in.bias") ? pre + "project_in.bias" : "", false,
+                         &e->proj_in));   // the bias: optional tensor ([XT?], see optional_key)
     DIMX_TRY(upload_f32(c, pre + "pos_emb.emb.weight", &e->pos_emb));
     for (int i = 0; i < c->encg[0].depth; ++i) {
         DIMX_TRY(pack_xattn(c, xl(pre, 2 * i), false, &e->attn[i]));
@@ -484,7 +507,8 @@ static int ensure_packed(dimx_ctx* c, int need) {
                 }
             }
             DIMX_TRY(upload_f32(c, dp + "attn_layers.final_norm.weight", &c->dec.final_g));
-            DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, "", false, &c->dec.logits));
+            DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, c->host.count(dp + "to_logits.bias") ? dp + "to_logits.bias" : "", false,
+                                 &c->dec.logits));
             {
                 std::vector<std::string> parts;
                 for (int i = 0; i < c->decg.depth; ++i) {
@@ -857,12 +881,30 @@ int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n) {
     spec.clear();
     for (const auto& k : all_keys(h->d)) spec[k.name] = k.shape;
     bool dirty = false;
+    std::set<std::string> seen;   // names of this call
     for (int i = 0; i < n; ++i) {
         const dimx_weight_desc& w = descs[i];
         DIMX_REQUIRE(w.name && w.data && w.ndim >= 1 && w.ndim <= 4, DIMX_ERR_ARG, "dimx_load_weights: bad desc %d", i);
         const std::string name(w.name);
+        seen.insert(name);
         auto it = spec.find(name);
         if (it == spec.end()) {
+            std::vector<int64_t> oshape;
+            const int opt = optional_key(spec, name, &oshape);
+            if (opt != OPT_NONE) {
+                DIMX_REQUIRE(w.ndim == 1 && w.shape[0] == oshape[0], DIMX_ERR_WEIGHT, "%s: expected %lld values", w.name, (long long)oshape[0]);
+                if (opt == OPT_NORM_BIAS) {
+                    for (int64_t k = 0; k < w.shape[0]; ++k)
+                        DIMX_REQUIRE(w.data[k] == 0.f, DIMX_ERR_WEIGHT,
+                                     "%s: a non-zero LayerNorm bias -- this x-transformers variant is not the one the path implements", w.name);
+                    continue;
+                }
+                HostTensor& t = h->host[name];
+                t.shape.assign(w.shape, w.shape + 1);
+                t.data.assign(w.data, w.data + w.shape[0]);
+                dirty = true;
+                continue;
+            }
             DIMX_REQUIRE(ignorable_key(name), DIMX_ERR_WEIGHT, "unknown weight key %s", w.name);
             continue;
         }
@@ -878,6 +920,17 @@ int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n) {
         t.shape.assign(w.shape, w.shape + w.ndim);
         t.data.assign(w.data, w.data + cnt);
         dirty = true;
+    }
+    // an optional bias belongs to the checkpoint that brought it: a call that replaces the Linear's weight without naming the bias
+    // again (another checkpoint) removes it
+    for (auto it = h->host.begin(); it != h->host.end();) {
+        const std::string& nm = it->first;
+        if (!spec.count(nm) && ends_with(nm, ".bias") && !seen.count(nm) && seen.count(nm.substr(0, nm.size() - 4) + "weight")) {
+            it = h->host.erase(it);
+            dirty = true;
+        } else {
+            ++it;
+        }
     }
     if (dirty) {  // re-pack lazily; device copies of the old tensors are released now
         (void)hipSetDevice(h->device);
@@ -1821,7 +1874,8 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         DIMX_TRY(slab_gemm(s.f, DD * dg.ff_mult, h->dec.ff[l].f2, s.xr, s0.st_xr, &pending));
     }
     int nlg = 0;
-    if (chain) {  // x += feed-forward slabs -> final LayerNorm -> logits
+    if (chain && !h->dec.logits.bias) {  // x += feed-forward slabs -> final LayerNorm -> logits (the chain kernel has no bias input:
+                                         // a checkpoint with the optional to_logits.bias takes the two launches below)
         DIMX_TRY(chain_site(3 * dg.depth, nullptr, 0, nullptr, pending, h->dec.final_g, &h->dec.logits, s.logits, V));
         nlg = 1;
     } else {

@@ -58,6 +58,13 @@ struct TrainPlan {
 // stack (deterministic: the caller's arenas are laid out by it)
 int build_plan(dimx_handle h, TrainPlan& p) {
     const dimx_dims& d = h->d;
+    // the optional tensors of another x-transformers release (model.hip: optional_key) are on the inference path only: the step
+    // below has no gradient for them, so it refuses them instead of training around them
+    for (const auto& kv : h->host) {
+        const std::string& nm = kv.first;
+        const bool opt = nm.size() > 16 && (nm.compare(nm.size() - 15, 15, "project_in.bias") == 0 || nm.compare(nm.size() - 14, 14, "to_logits.bias") == 0);
+        DIMX_REQUIRE(!opt, DIMX_ERR_STATE, "train: %s is loaded; the training step implements the bias-free project_in / to_logits only", nm.c_str());
+    }
     // a tensor the engine itself does not hold (the id-conditioning tables of the legacy generator are training-only): fixed shape
     auto add_free = [&](const std::string& name, int rows, int cols) -> int {
         PInfo pi{name, p.total, (long)rows * cols, rows, cols};

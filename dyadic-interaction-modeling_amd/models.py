@@ -45,6 +45,49 @@ class _EngineOwner(nn.Module):
         self._engine_version = None
         self._engine_pin = 0          # > 0: inside a forward whose first engine() call already checked the weights
 
+    # ------------------------------------------------------------------ checkpoints of other x-transformers releases
+    _OPTIONAL_LINEAR_BIAS = ("project_in.bias", "to_logits.bias")
+
+    def _adopt_optional_tensors(self, state_dict):
+        """SURVEY A.2 marks three details of x-transformers 1.30.16 [XT?]: bias-free ``project_in`` / ``to_logits`` and a
+        LayerNorm without bias.  A checkpoint written with another release carries those tensors, and the reference loads its
+        checkpoints with ``strict=False`` (code/finetune_s2s_pretrain.py:57), which would drop them without a word.  Here:
+        a ``project_in.bias`` / ``to_logits.bias`` next to a weight this module owns becomes a parameter (the engine applies
+        it); a LayerNorm ``bias`` inside ``attn_layers`` -- the zero ``beta`` buffer that loader renames -- is dropped when it
+        is zero and refused otherwise.  Returns the state dict to hand to ``nn.Module.load_state_dict``."""
+        own = self.state_dict(keep_vars=True)
+        out = {}
+        for k, v in state_dict.items():
+            if k in own or not k.endswith(".bias") or (k[:-4] + "weight") not in own:
+                out[k] = v
+                continue
+            w = own[k[:-4] + "weight"]
+            if k.endswith(self._OPTIONAL_LINEAR_BIAS):
+                if tuple(v.shape) != (w.shape[0],):
+                    raise L.DimxError("%s: shape %s, expected (%d,)" % (k, tuple(v.shape), w.shape[0]))
+                mod = self
+                for part in k.split(".")[:-1]:
+                    mod = mod._modules[part]
+                mod.register_parameter("bias", torch.nn.Parameter(torch.zeros_like(w[:, 0]), requires_grad=False))
+                out[k] = v
+            elif ".attn_layers." in k and w.dim() == 1:
+                if bool((v != 0).any()):
+                    raise L.DimxError("%s: a non-zero LayerNorm bias -- this checkpoint was written by an x-transformers "
+                                      "variant the path does not implement" % k)
+            else:
+                out[k] = v
+        # a bias adopted from an earlier checkpoint does not survive a checkpoint without it
+        for k in list(own):
+            if k.endswith(self._OPTIONAL_LINEAR_BIAS) and k not in state_dict and (k[:-4] + "weight") in state_dict:
+                mod = self
+                for part in k.split(".")[:-1]:
+                    mod = mod._modules[part]
+                del mod._parameters["bias"]
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        return super().load_state_dict(self._adopt_optional_tensors(state_dict), strict=strict, **kw)
+
     def _weights_version(self):
         return tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict(keep_vars=True).items())
 

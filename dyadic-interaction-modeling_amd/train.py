@@ -69,7 +69,7 @@ def _ff(x, P, pre):
 def xt_encoder(P, pre, x, mask, causal, depth, heads):
     """ContinuousTransformerWrapper(..., return_embeddings=True) with an Encoder of (attention, feed-forward) x depth."""
     T = x.shape[1]
-    h = F.linear(x, P[pre + "project_in.weight"])
+    h = F.linear(x, P[pre + "project_in.weight"], P.get(pre + "project_in.bias"))   # optional tensor: models._adopt_optional_tensors
     h = h + P[pre + "pos_emb.emb.weight"][:T] * (h.shape[-1] ** -0.5)
     am = torch.ones(T, T, dtype=torch.bool, device=x.device).tril() if causal else None
     L = pre + "attn_layers.layers."
@@ -98,7 +98,7 @@ def xt_decoder_logits(P, pre, tokens, context, context_mask, self_kv_mask, depth
         h = h + _attention(y, context, P, L + "%d.1." % (3 * i + 1), heads, context_mask, None)
         h = h + _ff(_ln(h, P[L + "%d.0.0.weight" % (3 * i + 2)]), P, L + "%d.1." % (3 * i + 2))
     h = _ln(h, P[pre + "attn_layers.final_norm.weight"])
-    return F.linear(h, P[pre + "to_logits.weight"])
+    return F.linear(h, P[pre + "to_logits.weight"], P.get(pre + "to_logits.bias"))
 
 
 def slmft_loss(P, dims, v_speaker, v_audio, mask, z_l, kv_mask=None):

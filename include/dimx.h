@@ -84,8 +84,11 @@ int dimx_numeric_mode(dimx_handle h);
 /* Upload + pack weights (fused QKV, conv tap-major, bf16 copies, K padding).  May be called
  * several times; every key of the hot path must have been supplied before the first stage call
  * that needs it.  Unknown keys that belong to the reference surface but not to the path
- * (encoder_l.*, norm_l.*, norm.*, patch_embed_l, patch_embed_dec_l, *.project_out.weight) are
- * accepted and ignored.  Synchronous. */
+ * (encoder_l.*, norm_l.*, norm.*, patch_embed_l, patch_embed_dec_l, *.project_out.weight / .bias) are
+ * accepted and ignored.  OPTIONAL tensors (SURVEY A.2 [XT?]: details of x-transformers that differ between releases):
+ * <encoder>.project_in.bias and <decoder>.to_logits.bias are applied when supplied and forgotten again by a call that supplies the
+ * Linear's weight without them; a LayerNorm bias under *.attn_layers.* must be all zero (DIMX_ERR_WEIGHT otherwise).  Any other
+ * unknown key is DIMX_ERR_WEIGHT.  Synchronous. */
 int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n);
 /* number of hot-path tensors still missing (0 = ready) */
 int dimx_missing_weights(dimx_handle h);

@@ -227,10 +227,12 @@ def _xt_norm(x, sd, key):
 
 def xt_encoder(sd, prefix, x, mask, causal=True, depth=4, heads=12, zero_masked_queries=True):
     """ContinuousTransformerWrapper.forward(x, mask, attn_mask, return_embeddings=True):
-    project_in (no bias) + learned abs pos emb * dim^-0.5 + depth x {attn, ff} pre-norm
+    project_in (bias-free in x-transformers 1.30.16 as restated in SURVEY A.2; that detail is marked [XT?] there, so a
+    ``project_in.bias`` / ``to_logits.bias`` tensor in the state dict is applied when present) + learned abs pos emb *
+    dim^-0.5 + depth x {attn, ff} pre-norm
     + final norm; project_out is skipped.  Call sites code/seq2seq_pretrain.py:439-440."""
     B, T, _ = x.shape
-    h = F.linear(x, sd[prefix + "project_in.weight"])
+    h = F.linear(x, sd[prefix + "project_in.weight"], sd.get(prefix + "project_in.bias"))
     dim = h.shape[-1]
     h = h + sd[prefix + "pos_emb.emb.weight"][:T] * (dim ** -0.5)
     attn_mask = None
@@ -305,7 +307,7 @@ def xt_decoder_logits(sd, tokens, context, context_mask, self_kv_mask=None,
     h = sd[prefix + "token_emb.emb.weight"][tokens]
     causal = ~torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1)
     h = xt_decoder_layers(sd, prefix, h, context, context_mask, causal, self_kv_mask, depth, heads)
-    return F.linear(h, sd[prefix + "to_logits.weight"])
+    return F.linear(h, sd[prefix + "to_logits.weight"], sd.get(prefix + "to_logits.bias"))
 
 
 def ar_kv_mask(B, T, mask_prob=0.15, generator=None):
@@ -360,7 +362,7 @@ def ar_generate(sd, start, seq_len, context, context_mask, noise=None, temperatu
         if cached:
             h = sd[prefix + "token_emb.emb.weight"][out[:, -1:]]
             h = xt_decoder_layers(sd, prefix, h, context, context_mask, None, None, depth, heads, cache)
-            logits = F.linear(h[:, -1], sd[prefix + "to_logits.weight"])
+            logits = F.linear(h[:, -1], sd[prefix + "to_logits.weight"], sd.get(prefix + "to_logits.bias"))
         else:
             logits = xt_decoder_logits(sd, out, context, context_mask, None, prefix, depth, heads)[:, -1]
         if return_logits:
@@ -455,7 +457,7 @@ def legacy_decoder_logits(sd, tokens, context, context_mask, prefix="generator.d
     h = legacy_decoder_embed(sd, tokens, prefix)
     causal = ~torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1)
     h = xt_decoder_layers(sd, prefix, h, context, context_mask, causal, None, depth, heads)
-    return F.linear(h, sd[prefix + "to_logits.weight"])
+    return F.linear(h, sd[prefix + "to_logits.weight"], sd.get(prefix + "to_logits.bias"))
 
 
 def legacy_generate(sd, start, seq_len, context, context_mask, noise=None, temperature=1.0, k=52,
@@ -470,7 +472,7 @@ def legacy_generate(sd, start, seq_len, context, context_mask, noise=None, tempe
         h = sd[prefix + "token_emb.emb.weight"][out[:, -1:]]
         h = h + pos[t:t + 1] * (h.shape[-1] ** -0.5)
         h = xt_decoder_layers(sd, prefix, h, context, context_mask, None, None, depth, heads, cache)
-        logits = F.linear(h[:, -1], sd[prefix + "to_logits.weight"])
+        logits = F.linear(h[:, -1], sd[prefix + "to_logits.weight"], sd.get(prefix + "to_logits.bias"))
         tok = sample_tokens(logits, None if noise is None else noise[t], temperature, k)
         out = torch.cat([out, tok.view(B, 1)], dim=1)
     return out[:, 1:]
@@ -578,7 +580,7 @@ def slm_decoder_tf(sd, z, context, context_mask, prefix="decoder_joint.net.", de
     h = h + sd[prefix + "pos_emb.emb.weight"][:n] * (h.shape[-1] ** -0.5)
     causal = ~torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1)
     h = xt_decoder_layers(sd, prefix, h, context, context_mask, causal, None, depth, heads)
-    logits = F.linear(h, sd[prefix + "to_logits.weight"])
+    logits = F.linear(h, sd[prefix + "to_logits.weight"], sd.get(prefix + "to_logits.bias"))
     loss = F.cross_entropy(logits.permute(0, 2, 1), target, ignore_index=-100)
     return loss, logits
 

@@ -40,6 +40,42 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 4, 56), torch.zeros(1, 4, 56), torch.zeros(1, 4, 768), torch.ones(1, 4, dtype=torch.bool))
 
 
+def test_checkpoints_of_other_xtransformers_releases_are_never_loaded_in_part():
+    """SURVEY A.2 [XT?]: project_in.bias / to_logits.bias are adopted as parameters, a zero LayerNorm bias (the renamed `beta`
+    buffer of code/finetune_s2s_pretrain.py:49-57) is dropped, a non-zero one is refused -- also under strict=False, which
+    is how the reference loads its checkpoints."""
+    from dimx.seq2seq_pretrain import SLMFT
+    m = SLMFT()
+    base = {k: v.clone() for k, v in m.state_dict().items()}
+    sd = dict(base)
+    sd["encoder_s.project_in.bias"] = torch.full((384,), 0.25)
+    sd["decoder_joint.net.to_logits.bias"] = torch.arange(512, dtype=torch.float32)
+    sd["encoder_joint.attn_layers.layers.0.0.0.bias"] = torch.zeros(384)
+    sd["decoder_joint.net.attn_layers.final_norm.bias"] = torch.zeros(1152)
+    v0 = m._weights_version()
+    m.load_state_dict(sd, strict=False)
+    own = m.state_dict()
+    assert torch.equal(own["encoder_s.project_in.bias"], sd["encoder_s.project_in.bias"])
+    assert torch.equal(own["decoder_joint.net.to_logits.bias"], sd["decoder_joint.net.to_logits.bias"])
+    assert "encoder_joint.attn_layers.layers.0.0.0.bias" not in own and m._weights_version() != v0
+    assert "decoder_joint.net.to_logits.bias" in dict(m.named_parameters())
+    # strict load of the same dict works too (the zero LayerNorm biases are not "unexpected")
+    m.load_state_dict(sd, strict=True)
+    bad = dict(base)
+    bad["encoder_s.attn_layers.final_norm.bias"] = torch.full((384,), 1e-3)
+    for strict in (True, False):
+        with pytest.raises(lib.DimxError):
+            m.load_state_dict(bad, strict=strict)
+    # a checkpoint without the optional tensors takes them away again
+    m.load_state_dict(base, strict=True)
+    assert set(m.state_dict()) == set(base)
+    wrong = dict(base)
+    wrong["encoder_s.project_in.bias"] = torch.zeros(56)
+    with pytest.raises(lib.DimxError):
+        m.load_state_dict(wrong, strict=False)
+    assert set(m.state_dict()) == set(base)
+
+
 def test_config_surface(golden_dir, tmp_path):
     cfg = config.load_cfg_from_cfg_file(config.DEFAULT_CONFIG)
     ref = json.load(open(os.path.join(golden_dir, "cfg_roundtrip.json")))["reference_flat_cfg"]

@@ -278,3 +278,70 @@ def test_layer_kernel_fault_is_reported_and_repaired(full_sd):
     assert e.chain_faults() == 1
     assert torch.equal(tok, ref_tok)
     e.close()
+
+
+def test_optional_bias_tensors_of_other_xtransformers_releases(full_sd):
+    """SURVEY A.2 [XT?]: a state dict that carries project_in.bias / to_logits.bias is computed WITH them (encoder, teacher-forced
+    logits, cached generation against the oracle reading the same dict; the bf16 decode step leaves its last chain kernel, which
+    has no bias input, for two launches); a zero LayerNorm bias is accepted, a non-zero one refused; a later state dict without
+    the tensors restores the bias-free results bit for bit; the training step refuses the tensors."""
+    from dimx import engine, lib, prng
+    from oracle import ref_cpu
+    B, T, lens = 3, 40, [40, 33, 7]
+    v_s, v_a, z, mask = _case(B, T, lens, seed=17)
+    sd = dict(full_sd)
+    sd["encoder_s.project_in.bias"] = torch.from_numpy(prng.normal(5, "xt.b0", (384,))) * 0.3
+    sd["encoder_joint.project_in.bias"] = torch.from_numpy(prng.normal(5, "xt.b1", (384,))) * 0.3
+    sd["decoder_joint.net.to_logits.bias"] = torch.from_numpy(prng.normal(5, "xt.b2", (512,))) * 0.5
+    sd["decoder_joint.net.attn_layers.final_norm.bias"] = torch.zeros(1152)
+    m8 = mask.to(torch.uint8).cuda()
+
+    def oracle(d):
+        x_s = ref_cpu.slmft_forward_encoder(d, v_s, mask)
+        ctx = ref_cpu.slmft_context(d, x_s, v_a)
+        _, lg = ref_cpu.ar_forward(d, z, ctx, mask, None)
+        tok = ref_cpu.ar_generate(d, z[:, 0], T - 1, ctx, mask, None)
+        return x_s, lg, tok
+
+    def run(e):
+        x_s = e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, False, return_x_s=True).cpu()
+        lg = e.decode_tf(z.cuda(), m8, None)[0].cpu()
+        e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+        tok = e.generate(z[:, 0].cuda(), m8, T, 0.0).cpu().long()
+        return x_s, lg, tok
+
+    e = engine.Engine("cuda:0", lib.MODE_PARITY_F32)
+    e.load_state_dict(full_sd)
+    x0, lg0, tok0 = run(e)
+    e.load_state_dict(sd)
+    x1, lg1, tok1 = run(e)
+    rx, rlg, rtok = oracle(sd)
+    for b, n in enumerate(lens):
+        assert (x1[b, :n] - rx[b, :n]).abs().max() < 1e-4
+    assert (lg1 - rlg).abs().max() < LOGIT_TOL and torch.equal(tok1, rtok)
+    assert (lg1 - lg0).abs().max() > 0.1          # the tensors are not decoration
+    bad = dict(full_sd)
+    bad["encoder_s.attn_layers.layers.0.0.0.bias"] = torch.full((384,), 1e-3)
+    with pytest.raises(lib.DimxError):
+        e.load_state_dict(bad)
+    e.load_state_dict(full_sd)                      # names the weights, not the biases: they go
+    x2, lg2, tok2 = run(e)
+    assert torch.equal(x2, x0) and torch.equal(lg2, lg0) and torch.equal(tok2, tok0)
+    e.close()
+
+    # bf16 decode step: the logits of generate() move by the bias (the rest of the step is the chain path it always was)
+    only = dict(full_sd)
+    only["decoder_joint.net.to_logits.bias"] = sd["decoder_joint.net.to_logits.bias"]
+    e = engine.Engine("cuda:0", lib.MODE_PERF_BF16)
+    e.load_state_dict(full_sd)
+    e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+    _, a = e.generate(z[:, 0].cuda(), m8, T, 0.0, return_logits=True)
+    e.load_state_dict(only)
+    e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True)
+    _, b = e.generate(z[:, 0].cuda(), m8, T, 0.0, return_logits=True)
+    d = (b[:, 0] - a[:, 0]).cpu() - only["decoder_joint.net.to_logits.bias"]
+    print("bf16 step-0 logits: |(with - without) - bias| max = %.3g" % d.abs().max())
+    assert d.abs().max() < 2e-2 and e.chain_faults() == 0
+    # the training step has no gradient for these tensors: it refuses them
+    assert e.lib.dimx_train_num_params(e.h) == -4 and b"to_logits.bias" in e.lib.dimx_last_error()   # DIMX_ERR_STATE
+    e.close()
