@@ -146,6 +146,17 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     const int rng_tot = dev_params && dev_params[5] > 0 ? dev_params[5] : rows_total;
     if (row < R) {
     const float* lr = logits + (size_t)row * ld;
+    // the fused pre-norm's weight does not depend on the token: its loads go out with the logits' (behind the token's embedding
+    // row they were one more exposed L2 round trip at the tail of every decode step)
+    float2 gam[16];
+    const bool fast_embed = x_next && emb_C / 2 <= 16 * 64;
+    if (y_next && fast_embed) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = lane + 64 * k;
+            gam[k] = ((const float2*)y_gamma)[i < emb_C / 2 ? i : emb_C / 2 - 1];
+        }
+    }
     float v[8];
     float mx = -3.0e38f;
     int mi = 0;
@@ -311,12 +322,11 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                         qs += a0 * a0 + b0 * b0;
                     }
                 const float rstd = rsqrtf((y_bf16 ? wave_sum_sel<true>(qs) : wave_sum_sel<false>(qs)) * inv_c + 1e-5f);
-                const float2* g2 = (const float2*)y_gamma;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int i = lane + 64 * k;
                     if (i < nv) {
-                        const float2 g = g2[i];
+                        const float2 g = gam[k];
                         const float o0 = (v[k].x - mean) * rstd * g.x, o1 = (v[k].y - mean) * rstd * g.y;
                         if (y_bf16)
                             *(uint32_t*)((bf16*)y_next + (size_t)row * emb_C + 2 * i) = pack_bf16x2(o0, o1);
