@@ -17,7 +17,6 @@
 // only the small projections (attention out / cross-q / logits: 0.6-1.8 MB each) take this path and the feed-forward
 // and fused-qkv GEMMs (5-11 MB) stay chip-wide launches.
 #include <algorithm>
-#include <type_traits>
 
 #include "common.hpp"
 #include "decode_attn_body.hpp"
@@ -810,329 +809,6 @@ __global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerCha
     LAYER_STAMP(12);
 }
 
-// ------------------------------------------------------------------------------------------------
-// xcd_layer2_kernel (round 5, second form): the same attention half of a layer with the XCD's 32 clips as TWO half-groups one
-// phase apart, so that the HBM streams never stop for the projections.
-//
-// xcd_layer_kernel's stamps (profiles/r05_layer_kernel_stamps_last_step.txt): the two K/V streams take 2 x 34.5 us, and between
-// them the chip's HBM idles ~14 us (barrier, out-projection, barrier, cross-q, barrier) + 5 us behind the second stream -- every
-// phase waits for the one before it.  Two INDEPENDENT halves do not: while half A's projections run, half B streams.
-//   * rows [32 g, 32 g + 16) of XCD g are half A, rows [32 g + 16, 32 g + 32) half B (no permutation of anything: a half is
-//     a contiguous row range of the group).  CU slot i serves pair p = i >> 1 -- clip 32 g + p of A and clip 32 g + 16 + p of
-//     B -- with heads 6 (i & 1) .. + 6: every CU streams during EVERY attention phase (half the CUs streaming twice as much
-//     does not work: 12 waves pull at most ~37 GB/s through a CU, profiles/r05_attn_halfchip.txt).
-//   * waves 0-11: (head, key part) = (w % 6, w / 6) of the CU's six heads -- decode_attn_part_body, no block barrier -- for
-//     A.self, B.self, A.cross, B.cross back to back; a cross phase starts when the control wave has raised its half's
-//     `q ready` flag in LDS.
-//   * wave 12 (control): everything else for both halves in turn -- the group barriers (one per half and hand-off, on the
-//     half's own monotonic counter), the LDS-DMA of row panels and weight slices, the MFMAs of the three projections (ONE wave
-//     holds the whole K sum: 96 / 72 MFMAs = 1.5 / 1.1 us, off the streams' path) and their epilogues (residual + bf16(x) +
-//     partial row sums; the deferred-LayerNorm correction of cross-q).
-// Waves talk through LDS words (phase counters, flags) and never meet at s_barrier after the first instruction.
-constexpr int kHalfRows = 16;
-
-template <int NCB>
-__device__ __forceinline__ void mfma_panel_1w(const unsigned char* Apan, int a_rows_pad, const unsigned char* Wpan, int w_rows_pad, int nkt,
-                                              f32x16_t (&acc)[NCB], int lane) {
-    const int half = lane >> 5, l31 = lane & 31;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const unsigned char* At = Apan + (size_t)kt * a_rows_pad * 128;
-        const unsigned char* Wt = Wpan + (size_t)kt * w_rows_pad * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kc = 2 * ks + half;
-            const uint4 fa = *(const uint4*)(At + lds_off(l31, kc));   // rows >= a_rows_pad: the next tile's bytes, their results are dropped
-#pragma unroll
-            for (int j = 0; j < NCB; ++j) {
-                const uint4 fw = *(const uint4*)(Wt + lds_off(j * 32 + l31, kc));
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fw), acc[j], 0,
-                                                                 0, 0);
-            }
-        }
-    }
-}
-
-// issue_panel_nw for ONE wave without the per-piece division (a single wave pays ~40 scalar-latency-bound instructions for it, per
-// piece): the 8-row groups' source rows are fixed per lane, the k-tile advances by 128 bytes
-template <int AUX>
-__device__ __forceinline__ void issue_panel_1w(const bf16* base, int ld, int r_begin, int r_last, int rows_pad, int nkt, unsigned char* dst,
-                                               int lane) {
-    const int groups = rows_pad >> 3;
-    const bf16* src[8];
-#pragma unroll
-    for (int gr = 0; gr < 8; ++gr) {
-        const int row = gr * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        int r = r_begin + row;
-        r = r <= r_last ? r : r_last;
-        src[gr] = base + (size_t)r * ld + c * 8;
-    }
-    unsigned char* d = dst;
-    for (int kt = 0; kt < nkt; ++kt) {
-#pragma unroll
-        for (int gr = 0; gr < 8; ++gr) {
-            if (gr < groups) {
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(src[gr] + kt * 64), (lds_void_t*)d, 16, 0, AUX);
-                d += 1024;
-            }
-        }
-    }
-}
-
-// bounded wait on an LDS word (another wave of this block raises it)
-__device__ __forceinline__ bool lds_wait_ge(volatile int* w, int want) {
-    unsigned spins = 0;
-    while (*w < want) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 22)) return false;
-    }
-    asm volatile("" ::: "memory");
-    return true;
-}
-
-#define LAYER2_STAMP(i)                                                          \
-    do {                                                                         \
-        if (a.prof && lane == 0) a.prof[(i) < 16 ? blockIdx.x * 16 + (i) : 256 * 16 + blockIdx.x * 16 + (i) - 16] = wall_clock64(); \
-    } while (0)
-
-template <int NCB_SO, int NCB_CQ, int NCB_CO>
-__global__ __launch_bounds__(kLayerThreads) void xcd_layer2_kernel(const LayerChainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int g = (int)(xcc_id() & (a.fault ? 6u : 7u)), li = blockIdx.x >> 3;
-    const unsigned epoch = (unsigned)((a.step ? *a.step : 0) + a.epoch_add);
-    const unsigned stamp = epoch + 1u;
-    unsigned seen_old = 0;
-    if (tid == 0) seen_old = atomicExch(a.seen + g * kGroupCUs + li, stamp);
-    const int row0 = g * kGroupRows;
-    const int nrows = a.B - row0 < kGroupRows ? a.B - row0 : kGroupRows;
-    if (tid == 0 && seen_old == stamp) atomicOr(a.err, 1u);  // two blocks claimed the same (XCD, slot)
-    if (nrows <= 0) return;                                    // the whole group leaves
-    const int nhalf[2] = {nrows < kHalfRows ? nrows : kHalfRows, nrows > kHalfRows ? nrows - kHalfRows : 0};
-    const int C = a.C;
-    // LDS words: [0..3] part-0 waves done with attention phase k; [4..5] cross query of half X ready; [8 + 6 s + pair] merge flags
-    volatile int* flags = (volatile int*)(lds + a.off_sync);
-    float* mrg_base = (float*)(lds + a.off_sync + 256);
-    if (tid < 64) flags[tid] = 0;
-    __syncthreads();   // the only block barrier of the kernel
-
-    if (wave < kAttnWaves) {
-        // ------------------------------------------------------------------------------------------------ attention waves
-        const int pair = li >> 1, hsel = li & 1;
-        const int hl = wave % 6, part = wave / 6, head = 6 * hsel + hl;
-        float* s = (float*)lds + (size_t)wave * a.sc_stride;
-        if (wave == 0) LAYER2_STAMP(12);
-#pragma unroll 1
-        for (int ph = 0; ph < 4; ++ph) {
-            const int X = ph & 1;
-            if (nhalf[X] == 0) continue;   // a group of <= 16 rows has no half B (all of its CUs agree)
-            const bool active = pair < nhalf[X];
-            const int clip = row0 + kHalfRows * X + (active ? pair : 0);
-            float* mrg = mrg_base + (size_t)(X * 6 + hl) * 72;
-            volatile int* mf = flags + 8 + X * 6 + hl;
-            if (ph >= 2) {
-                lds_wait_ge(flags + 4 + X, 1);
-                if (wave == 0) LAYER2_STAMP(ph == 2 ? 14 : 15);
-                decode_attn_part_body<false, true>(a.ca, clip, head, part, active, s, mrg, mf, ph + 1);
-            } else {
-                decode_attn_part_body<true, false>(a.sa, clip, head, part, active, s, mrg, mf, ph + 1);
-                if (wave == 0 && ph == 1) LAYER2_STAMP(13);
-            }
-            if (part == 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // o (and the appended k / v rows) are in the XCD's L2
-                if (lane == 0) __hip_atomic_fetch_add((int*)(flags + ph), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------------------------- control wave
-    __builtin_amdgcn_s_setprio(3);   // one wave against three streaming waves on its SIMD: everything it does is on the halves' critical path
-    unsigned char* const R = lds + a.off_R;
-    unsigned char* const W = lds + a.off_W;
-    float* const mr = (float*)(lds + a.off_sync + 128);   // {mean, rstd} of the half's 16 rows
-    const int half = lane >> 5, l31 = lane & 31;
-    unsigned target[2] = {epoch * (unsigned)(4 * kGroupCUs), epoch * (unsigned)(4 * kGroupCUs)};
-    auto group_barrier = [&](int X) {
-        target[X] += kGroupCUs;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores (the attention waves drained theirs before they signalled)
-        if (lane == 0) {
-            unsigned* ctr = a.counters + 16 * g + X;
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while ((int)(ld_sc1_u32(ctr) - target[X]) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
-                if (spins > (1u << 20) || ((spins & 1023u) == 0 && (ld_sc1_u32(a.err) & 2u))) {
-                    atomicOr(a.err, 2u);
-                    break;
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-    };
-    auto issue_w = [&](const ChainGemmDesc& d) {
-        asm volatile("" ::: "memory");
-        const int n0 = li * d.cols;
-        issue_panel_1w<AUX_PLAIN>((const bf16*)d.W, d.ldw, n0, n0 + d.cols - 1, d.rows_pad, d.nkt, W, lane);
-    };
-    // x += rows . W^T on the half's rows (this CU's column slice), y = bf16(x), partial row sums of the slice
-    auto out_projection = [&](const ChainGemmDesc& d, int X, auto ncb_tag, int fine) {
-        constexpr int NCB = decltype(ncb_tag)::value;
-        const int r0 = row0 + kHalfRows * X, nr = nhalf[X], n0 = li * d.cols;
-        asm volatile("" ::: "memory");
-        issue_panel_1w<AUX_SC1>((const bf16*)a.o, a.ld_o, r0, r0 + nr - 1, kHalfRows, d.nkt, R, lane);
-        float xs[NCB][8];
-#pragma unroll
-        for (int j = 0; j < NCB; ++j)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * half, col = j * 32 + l31;
-                const int mm = m < nr ? m : nr - 1, cc = col < d.cols ? col : d.cols - 1;
-                xs[j][r] = a.x[(size_t)(r0 + mm) * C + n0 + cc];
-            }
-        if (X == 0) LAYER2_STAMP(fine);
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the weight slice, the rows, the residual slice
-        if (X == 0) LAYER2_STAMP(fine + 1);
-        f32x16_t acc[NCB];
-#pragma unroll
-        for (int j = 0; j < NCB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        mfma_panel_1w<NCB>(R, kHalfRows, W, d.rows_pad, d.nkt, acc, lane);
-        if (X == 0) LAYER2_STAMP(fine + 2);
-        float xp[NCB][8], s1[8], s2[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            float t = 0.f;
-#pragma unroll
-            for (int j = 0; j < NCB; ++j) {
-                const int col = j * 32 + l31;
-                const bool ok = col < d.cols && m < nr;
-                xp[j][r] = xs[j][r] + acc[j][r];
-                if (ok) {
-                    const size_t o = (size_t)(r0 + m) * C + n0 + col;
-                    a.x[o] = xp[j][r];
-                    ((bf16*)a.y)[o].x = f32_to_bf16(xp[j][r]);
-                    t += xp[j][r];
-                }
-            }
-            t = row16_sum(t);
-            s1[r] = t + xor_lane_f32<16>(t);
-        }
-        const float inv_n = 1.0f / (float)d.cols;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            float t = 0.f;
-#pragma unroll
-            for (int j = 0; j < NCB; ++j) {
-                const int col = j * 32 + l31;
-                const float dv = xp[j][r] - s1[r] * inv_n;
-                if (col < d.cols && m < nr) t += dv * dv;
-            }
-            t = row16_sum(t);
-            s2[r] = t + xor_lane_f32<16>(t);
-        }
-        if (l31 == 0) {
-            float* st = a.stats + ((size_t)(g * kGroupCUs + li) * kGroupRows + kHalfRows * X) * 2;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                st[2 * m] = s1[r];
-                st[2 * m + 1] = s2[r];
-            }
-        }
-    };
-    // qc = rstd * (bf16(x) . Wq'^T - mean * colsum) on the half's rows
-    auto cross_q = [&](int X) {
-        const ChainGemmDesc& d = a.g_cq;
-        const int r0 = row0 + kHalfRows * X, nr = nhalf[X], n0 = li * d.cols;
-        asm volatile("" ::: "memory");
-        issue_panel_1w<AUX_SC1>((const bf16*)a.y, C, r0, r0 + nr - 1, kHalfRows, d.nkt, R, lane);
-        {   // {mean, rstd} of the 16 rows from the 32 CUs' partial sums: lane = (row m, quarter q of the CUs)
-            const int m = lane >> 2, q = lane & 3;
-            float p1[8], p2[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float* sp = a.stats + ((size_t)(g * kGroupCUs + 8 * q + c) * kGroupRows + kHalfRows * X + m) * 2;
-                p1[c] = ld_sc1_f32(sp);
-                p2[c] = ld_sc1_f32(sp + 1);
-            }
-            float t1 = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) t1 += p1[c];
-            t1 += dpp_f32<DPP_XOR1>(t1);
-            t1 += dpp_f32<DPP_XOR2>(t1);
-            const float mean = t1 * (1.0f / C);
-            const float ncs = (float)a.g_so.cols, inv_n = 1.0f / ncs;
-            float t2 = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float dm = p1[c] * inv_n - mean;
-                t2 += p2[c] + ncs * dm * dm;
-            }
-            t2 += dpp_f32<DPP_XOR1>(t2);
-            t2 += dpp_f32<DPP_XOR2>(t2);
-            const float var = t2 * (1.0f / C);
-            if (q == 0) {
-                mr[2 * m] = mean;
-                mr[2 * m + 1] = rsqrtf(var + 1e-5f);
-                if (m < nr && mean * mean > 64.0f * var) atomicOr(a.err, 4u);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        f32x16_t acc[NCB_CQ];
-#pragma unroll
-        for (int j = 0; j < NCB_CQ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        mfma_panel_1w<NCB_CQ>(R, kHalfRows, W, d.rows_pad, d.nkt, acc, lane);
-#pragma unroll
-        for (int j = 0; j < NCB_CQ; ++j)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * half, col = j * 32 + l31;
-                if (col < d.cols && m < nr)
-                    a.qc[(size_t)(r0 + m) * a.ld_qc + n0 + col] = mr[2 * m + 1] * (acc[j][r] - mr[2 * m] * a.colsum_cq[n0 + col]);
-            }
-    };
-
-    LAYER2_STAMP(0);
-    issue_w(a.g_so);
-#pragma unroll 1
-    for (int X = 0; X < 2; ++X) {
-        if (nhalf[X] == 0) continue;
-        lds_wait_ge(flags + X, 6);                         // the CU's six heads of X.self are stored
-        LAYER2_STAMP(1 + 4 * X);
-        group_barrier(X);                                  // ... and so are the other 31 CUs'
-        if (X == 0) LAYER2_STAMP(16);
-        out_projection(a.g_so, X, std::integral_constant<int, NCB_SO>(), 17);
-        if (X == 0) LAYER2_STAMP(20);
-        issue_w(a.g_cq);                                   // the slice is consumed: the next one lands behind the epilogue and the barrier
-        LAYER2_STAMP(2 + 4 * X);
-        group_barrier(X);
-        if (X == 0) LAYER2_STAMP(21);
-        cross_q(X);
-        if (X == 0) LAYER2_STAMP(22);
-        if (X == 0 && nhalf[1] > 0) issue_w(a.g_so); else issue_w(a.g_co);
-        LAYER2_STAMP(3 + 4 * X);
-        group_barrier(X);
-        if (lane == 0) flags[4 + X] = 1;                   // the half's attention waves may start the cross phase
-        LAYER2_STAMP(4 + 4 * X);
-    }
-#pragma unroll 1
-    for (int X = 0; X < 2; ++X) {
-        if (nhalf[X] == 0) continue;
-        lds_wait_ge(flags + 2 + X, 6);
-        LAYER2_STAMP(9 + X);
-        group_barrier(X);
-        out_projection(a.g_co, X, std::integral_constant<int, NCB_CO>(), 24);
-    }
-    LAYER2_STAMP(11);
-}
-
 // ------------------------------------------------------------------------------------------------ host side
 static void desc_fill(ChainGemmDesc& d) {
     d.cols = d.N / kGroupCUs;
@@ -1270,23 +946,6 @@ static size_t layer_plan(LayerChainArgs& a) {
     return sc_bytes + std::max(end1, std::max(end2, end3));
 }
 
-// variant 2 (xcd_layer2_kernel): scores of 12 waves (a wave's own 32-key batches), merge slots + flags, ONE row panel of 16 rows and
-// ONE weight-slice panel (re-filled by the control wave as soon as a projection has consumed it)
-static size_t layer2_plan(LayerChainArgs& a) {
-    desc_fill(a.g_so);
-    desc_fill(a.g_cq);
-    desc_fill(a.g_co);
-    const int keys = std::max(a.sa.Tmax, a.ca.n_keys);
-    a.sc_stride = (keys + 63) / 64 * 32 + 32;
-    const size_t sc_bytes = ((size_t)kAttnWaves * a.sc_stride * 4 + 1023) / 1024 * 1024;
-    a.off_sync = (int)sc_bytes;
-    a.off_R = a.off_sync + 4096;
-    const int nkt = std::max(a.g_so.nkt, std::max(a.g_cq.nkt, a.g_co.nkt));
-    a.off_W = a.off_R + nkt * kHalfRows * 128 + 2048;   // + 2 KiB: the MFMA's A fragments of rows 16-31 of the last k-tile (dropped)
-    auto wbytes = [](const ChainGemmDesc& d) { return (size_t)d.nkt * d.rows_pad * 128 + 4096; };
-    return a.off_W + std::max(wbytes(a.g_so), std::max(wbytes(a.g_cq), wbytes(a.g_co)));
-}
-
 bool layer_chain_supported(const LayerChainArgs& a0, int cu_count) {
     LayerChainArgs a = a0;
     if (cu_count != 8 * kGroupCUs) return false;
@@ -1301,7 +960,6 @@ bool layer_chain_supported(const LayerChainArgs& a0, int cu_count) {
     }
     if (a.g_so.N != a.C || a.g_co.N != a.C || a.g_cq.K != a.C || a.g_so.ncb != 2 || a.g_co.ncb != 2 || a.g_cq.ncb != 1) return false;
     if (a.ld_o % 8 != 0) return false;
-    if (a.variant == 2) return a.sa.H == 12 && layer2_plan(a) <= kMaxDynLds;
     return layer_plan(a) <= kMaxDynLds;
 }
 
@@ -1309,14 +967,6 @@ int launch_layer_chain(const LayerChainArgs& a0, hipStream_t s) {
     LayerChainArgs a = a0;
     DIMX_REQUIRE(a.x && a.y && a.o && a.qc && a.stats && a.colsum_cq && a.counters && a.seen && a.err, DIMX_ERR_ARG,
                  "layer_chain: null operand");
-    if (a.variant == 2) {
-        const size_t lds2 = layer2_plan(a);
-        DIMX_REQUIRE(lds2 <= kMaxDynLds, DIMX_ERR_ARG, "layer_chain (two halves): LDS plan %zu bytes", lds2);
-        (void)hipFuncSetAttribute((const void*)xcd_layer2_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);
-        hipLaunchKernelGGL((xcd_layer2_kernel<2, 1, 2>), dim3(8 * kGroupCUs), dim3(kLayerThreads), lds2, s, a);
-        DIMX_HIP(hipGetLastError());
-        return DIMX_OK;
-    }
     const size_t lds = layer_plan(a);
     DIMX_REQUIRE(lds <= kMaxDynLds, DIMX_ERR_ARG, "layer_chain: LDS plan %zu bytes", lds);
     (void)hipFuncSetAttribute((const void*)xcd_layer_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);

@@ -426,8 +426,6 @@ struct LayerChainArgs {
     unsigned long long* prof;       // tuning only: [256][16] phase stamps
     int sc_stride;                  // floats per (clip, head) score row in LDS
     int off_base, off_A1, off_W1, off_A2, off_W2, off_W3, off_A3;  // LDS plan (bytes), set by the launcher
-    int variant;                    // 0: xcd_layer_kernel; 2: xcd_layer2_kernel (two half-groups one phase apart, chain.hip)
-    int off_sync, off_R, off_W;     // variant 2: merge slots + flags, row panel, weight-slice panel
 };
 bool layer_chain_supported(const LayerChainArgs& a, int cu_count);
 int launch_layer_chain(const LayerChainArgs& a, hipStream_t s);

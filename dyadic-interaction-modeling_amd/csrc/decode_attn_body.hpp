@@ -275,170 +275,5 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, int bl
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The same attention for ONE wave that owns every other 32-key batch of a (clip, head) pair (part 0: batches 0, 2, ...; part 1:
-// batches 1, 3, ...) -- the form the two-half layer kernel of chain.hip runs (xcd_layer2_kernel: 6 heads x 2 parts per CU).  No
-// block barrier anywhere: a wave keeps its scores in a wave-private LDS row (slot of key j: (j >> 6) * 32 + (j & 31)), works with
-// its own running maximum, and the two parts meet ONCE at the end -- part 1 leaves {max, sum, acc[64]} in `mrg` and raises `flag`
-// to `seq`, part 0 waits for it, rescales both partial results to the common maximum, normalises and stores.  bf16 caches, f32
-// query slabs (QSC1: one slab written by other CUs of this XCD during the launch).
-template <bool SELF, bool QSC1>
-__device__ __forceinline__ void decode_attn_part_body(const DecodeAttnArgs& a, int b, int h, int part, bool active, float* s, float* mrg,
-                                                      volatile int* flag, int seq) {
-    constexpr int EPC = 8, LPK = 8, KPI = 8, U = 4, KB = U * KPI;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane / LPK, ch = lane % LPK;
-    float qv[EPC], knv[EPC], vnv[EPC];
-    if (QSC1)
-        load_f32_chunk_sc1<EPC>((const float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, qv);
-    else
-        load_f32_slabs<EPC>((const float*)a.q + (size_t)b * a.q_ld + h * 64 + ch * EPC, a.nslab, a.slab_stride, qv);
-    if (SELF) {
-        load_f32_slabs<EPC>((const float*)a.knew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, a.nslab, a.slab_stride, knv);
-        load_f32_slabs<EPC>((const float*)a.vnew + (size_t)b * a.kv_ld + h * 64 + ch * EPC, a.nslab, a.slab_stride, vnv);
-    }
-    int n = a.n_keys;
-    if (SELF) n = *a.step;
-    if (!active) n = 0;
-    const float scale2 = a.scale * 1.4426950408889634f;
-    const bf16* kc = (const bf16*)a.kcache + ((size_t)(b * a.H + h) * a.Tmax) * 64 + ch * EPC;
-    const bf16* vc = (const bf16*)a.vcache + ((size_t)(b * a.H + h) * a.Tmax) * 64 + ch * EPC;
-    const bool masked = !SELF && a.kmask != nullptr;
-    auto load_batch = [&](const bf16* base, int j0, uint4 (&r)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * KPI + sub;
-            r[u] = ld_stream(base + (size_t)(j < n ? j : (n > 0 ? n - 1 : 0)) * 64);
-        }
-    };
-    const int jfirst = part * KB, jstep = 2 * KB;
-    uint4 cur[U], nxt[U], vfirst[U];
-    if (jfirst < n) {
-        load_batch(kc, jfirst, cur);
-        load_batch(vc, jfirst, vfirst);
-    }
-    if (masked) {  // this wave's keys only: slots [32 t, 32 t + 32) <-> keys jfirst + 64 t + ...
-        for (int jj = lane; ((jj >> 5) << 6) + jfirst < n; jj += 64) {
-            const int j = ((jj >> 5) << 6) + jfirst + (jj & 31);
-            if (j < n) s[jj] = a.kmask[(size_t)b * a.kmask_ld + j] ? 0.f : kNegD;
-        }
-    }
-    float mx = kNegD;
-    for (int j0 = jfirst; j0 < n; j0 += jstep) {
-        if (j0 + jstep < n) load_batch(kc, j0 + jstep, nxt);
-        const int slot0 = (j0 >> 6) << 5;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int jo = u * KPI + sub, j = j0 + jo;
-            float kv[EPC];
-            cvt_chunk<bf16, EPC>(cur[u], kv);
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) d = fmaf(qv[e], kv[e], d);
-            d = group8_sum(d);
-            if (j < n) {
-                float sv = d * scale2;
-                if (masked && s[slot0 + jo] != 0.f) sv = kNegD;
-                if (ch == 0) s[slot0 + jo] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = vfirst[u];
-    float sv_new = kNegD;
-    if (SELF && part == 0 && active) {  // this step's key belongs to part 0
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) d = fmaf(qv[e], knv[e], d);
-        d = group8_sum(d);
-        sv_new = __shfl(d, 0) * scale2;
-        mx = fmaxf(mx, sv_new);
-        if (sub == 0) {
-            const int nn = *a.step;
-            store_chunk<bf16, EPC>((bf16*)a.kcache + ((size_t)(b * a.H + h) * a.Tmax + nn) * 64 + ch * EPC, knv);
-            store_chunk<bf16, EPC>((bf16*)a.vcache + ((size_t)(b * a.H + h) * a.Tmax + nn) * 64 + ch * EPC, vnv);
-        }
-    }
-    mx = wave_max(mx);
-    float lsum = 0.f;
-    for (int jj = lane; ((jj >> 5) << 6) + jfirst < n; jj += 64) {
-        const int j = ((jj >> 5) << 6) + jfirst + (jj & 31);
-        if (j < n) {
-            const float p = exp2f(s[jj] - mx);
-            s[jj] = p;
-            lsum += p;
-        }
-    }
-    lsum = wave_sum_sel<true>(lsum);
-    float pnew = 0.f;
-    if (SELF && part == 0 && active) {
-        pnew = exp2f(sv_new - mx);
-        lsum += pnew;
-    }
-    float acc[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-    for (int j0 = jfirst; j0 < n; j0 += jstep) {
-        if (j0 + jstep < n) load_batch(vc, j0 + jstep, nxt);
-        const int slot0 = (j0 >> 6) << 5;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int jo = u * KPI + sub, j = j0 + jo;
-            float vv[EPC];
-            cvt_chunk<bf16, EPC>(cur[u], vv);
-            const float p = j < n ? s[slot0 + jo] : 0.f;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[e] = fmaf(p, vv[e], acc[e]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-    }
-    if (SELF && part == 0 && sub == 0) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) acc[e] = fmaf(pnew, vnv[e], acc[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        acc[e] += xor_lane_f32<8>(acc[e]);
-        acc[e] += xor_lane_f32<16>(acc[e]);
-        acc[e] += xor_lane_f32<32>(acc[e]);
-    }
-    if (part == 1) {
-        if (sub == 0) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) mrg[2 + ch * EPC + e] = acc[e];
-        }
-        if (lane == 0) {
-            mrg[0] = mx;
-            mrg[1] = lsum;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) *flag = seq;
-        return;
-    }
-    {   // part 0: wait for the other half of the keys (bounded: a lost partner must not hang the GPU; the caller's error word
-        // is raised by the group barrier's timeout in that case)
-        unsigned spins = 0;
-        while (*flag != seq && spins < (1u << 22)) {
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
-        }
-        asm volatile("" ::: "memory");
-    }
-    if (sub == 0) {
-        const float m1 = mrg[0], l1 = mrg[1];
-        const float m = fmaxf(mx, m1);
-        const float f0 = exp2f(mx - m), f1 = exp2f(m1 - m);
-        const float l = lsum * f0 + l1 * f1;
-        const float inv = l > 0.f ? 1.0f / l : 0.f;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) acc[e] = (acc[e] * f0 + mrg[2 + ch * EPC + e] * f1) * inv;
-        if (active) store_chunk<bf16, EPC>((bf16*)a.out + (size_t)b * a.o_ld + h * 64 + ch * EPC, acc);
-    }
-}
-
 }  // namespace
 }  // namespace dimx

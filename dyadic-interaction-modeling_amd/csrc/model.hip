@@ -822,7 +822,6 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     c->use_chain = (nc && nc[0] == '1') ? 0 : 1;
     c->defer_ln = getenv("DIMX_NO_DEFER_LN") ? 0 : 1;
     c->use_layer_chain = getenv("DIMX_NO_LAYER_CHAIN") ? 0 : 1;
-    if (const char* lv = getenv("DIMX_LAYER2")) c->layer_variant = atoi(lv) ? 2 : 0;
     if (getenv("DIMX_LAYER_PROF")) {
         void* p = nullptr;
         if (hipMalloc(&p, (size_t)8 * 256 * 16 * 8) == hipSuccess) {
@@ -1778,7 +1777,6 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         lc.err = h->chain_err_dev;
         lc.fault = h->chain_fault_inject > 0 ? 1 : 0;
         lc.sc_stride = (T + 15) / 16 * 16;
-        lc.variant = h->layer_variant;
         lc.prof = h->layer_prof_dev ? h->layer_prof_dev + (size_t)l * 256 * 16 : nullptr;
         return true;
     };
@@ -2519,7 +2517,6 @@ int dimx_op_layer_chain(const float* qkv, int nslab, long slab_stride, void* sk,
     lc.epoch_add = call_index;
     lc.prof = (unsigned long long*)prof;
     lc.sc_stride = ((T > n_keys ? T : n_keys) + 15) / 16 * 16;
-    if (const char* lv = getenv("DIMX_LAYER2")) lc.variant = atoi(lv) ? 2 : 0;
     int cu = 0, dev = 0;
     DIMX_HIP(hipGetDevice(&dev));
     DIMX_HIP(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev));

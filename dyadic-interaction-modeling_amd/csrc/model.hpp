@@ -163,7 +163,6 @@ struct dimx_ctx {
     float* chain_stats_dev = nullptr;   // [8][32][32][2] partial row sums of the deferred-LayerNorm chain kernels
     int defer_ln = 1;                   // DIMX_NO_DEFER_LN=1 keeps the row-phase LayerNorm inside the chain kernels
     unsigned long long* layer_prof_dev = nullptr;  // DIMX_LAYER_PROF=1 (tuning): [8 layers][256 blocks][16] phase stamps of xcd_layer_kernel
-    int layer_variant = 0;              // DIMX_LAYER2=1: the two-half form of the layer kernel (chain.hip xcd_layer2_kernel)
     int use_layer_chain = 1;            // DIMX_NO_LAYER_CHAIN=1 keeps the attention half of a layer as four launches (round 5)
     unsigned* chain_err_dev = nullptr;  // bit 0: two blocks claimed one (XCD, CU slot), bit 1: a group barrier timed out
     unsigned* chain_err_host = nullptr; // pinned copy, refreshed at the end of every generate call
