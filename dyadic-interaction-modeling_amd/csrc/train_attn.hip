@@ -21,6 +21,8 @@
 //     P and dS are B operands of dV^T = dO^T P and dK^T = Q^T dS with dO^T / Q^T read from transposed LDS tiles.
 // Outputs leave as 16-byte stores (an accumulator holds 4 consecutive head columns of one row).
 // Deterministic: no atomics, every output element is written by exactly one lane.
+#include <atomic>
+
 #include "train.hpp"
 
 namespace dimx {
@@ -494,15 +496,22 @@ __global__ __launch_bounds__(256) void attn_dkv_mfma_kernel(TrAttn a, const floa
     }
 }
 
+// true once per (instantiation, device): one bit per device ordinal (a process-wide flag left the second GPU of a
+// process without its dynamic-LDS limit)
+template <typename T, int WHICH> static bool first_launch_on_this_device() {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const unsigned long long bit = 1ull << dev;
+    return (done.fetch_or(bit) & bit) == 0;
+}
+
 template <typename T> static size_t lds_bytes(int tiles, int extra) { return (size_t)tiles * tile_elems<T>() * sizeof(typename Cfg<T>::E) + extra; }
 
 template <typename T> static int fwd_typed(const TrAttn& t, const float* q, const float* k, const float* v, float* o, float* lse, hipStream_t s) {
     const size_t lds = lds_bytes<T>(2, 0);
-    static bool once = false;
-    if (!once) {
-        once = true;
+    if (first_launch_on_this_device<T, 0>())   // the attribute belongs to (function, device): a second GPU of the process needs its own call
         (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
     hipLaunchKernelGGL(attn_fwd_mfma_kernel<T>, dim3((t.Lq + 127) / 128, t.H, t.B), dim3(256), lds, s, t, q, k, v, o, lse);
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;
@@ -512,9 +521,7 @@ template <typename T>
 static int bwd_typed(const TrAttn& t, const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                      float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, hipStream_t s) {
     const size_t lds_q = lds_bytes<T>(3, 0), lds_kv = lds_bytes<T>(4, 512);
-    static bool once = false;
-    if (!once) {
-        once = true;
+    if (first_launch_on_this_device<T, 1>()) {
         (void)hipFuncSetAttribute((const void*)attn_dq_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         (void)hipFuncSetAttribute((const void*)attn_dkv_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     }
