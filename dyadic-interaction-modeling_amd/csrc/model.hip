@@ -829,6 +829,10 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
             c->layer_prof_dev = (unsigned long long*)p;
         }
     }
+    if (const char* pg = getenv("DIMX_PREFILL_GROUPS")) {
+        const int v = atoi(pg);
+        if (v >= 1 && v <= dimx_ctx::kPreGroups) c->prefill_groups = v;
+    }
     if (const char* gu = getenv("DIMX_GRAPH_UNROLL")) {
         const int u = atoi(gu);
         if (u >= 1 && u <= 64) c->graph_unroll = u;
@@ -853,6 +857,11 @@ int dimx_destroy(dimx_handle h) {
         if (h->ev_join[g]) (void)hipEventDestroy(h->ev_join[g]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int g = 0; g < dimx_ctx::kPreGroups - 1; ++g) {
+        if (h->pre_stream[g]) (void)hipStreamDestroy(h->pre_stream[g]);
+        if (h->pre_join[g]) (void)hipEventDestroy(h->pre_join[g]);
+    }
+    if (h->pre_fork) (void)hipEventDestroy(h->pre_fork);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->chain_err_ev) (void)hipEventDestroy(h->chain_err_ev);
     if (h->chain_err_dev) (void)hipFree(h->chain_err_dev);
@@ -1110,7 +1119,8 @@ static size_t workspace_bytes(const dimx_ctx* c, int B, int T, int S = 1) {
         plan_gen(c, g, B * S, T, gs);
         scratch = g.off > scratch ? g.off : scratch;
     }
-    return persist + align_up(scratch, 256) + 4096;
+    // + 64 KiB: the prefill stages plan their scratch once per clip group (ClipGroups below), every buffer 256-byte aligned
+    return persist + align_up(scratch, 256) + 4096 + 65536;
 }
 
 // x-transformers encoder stack (ContinuousTransformerWrapper, return_embeddings=True)
@@ -1188,6 +1198,66 @@ int legacy_encode_ctx(dimx_handle h, const float* v_speaker, const uint8_t* mask
                       float* enc_out, float* x_speaker_out, int32_t* idx_out, void* ws, size_t ws_bytes,
                       hipStream_t st);
 
+// The prefill-sized stages of a forward are independent per clip, and their kernels leave CUs idle at the end of every launch (the
+// fused feed-forward kernel runs 600 blocks of 128 rows on 256 CUs: the third round is a third full; 128 x 128 and 256 x 256 GEMM
+// tiles end the same way).  As G clip groups on G streams the tails of one group's kernels are filled by another group's blocks:
+// 15.8 -> 14.2 ms for the three stages at 256 x 300 with G = 4 (tools/r05_prefill_streams.py, profiles/r05_prefill_groups.txt).
+// Group 0 runs on the caller's stream, the others on the handle's side streams between a fork and a join event; every group
+// has its own scratch (the same arena, planned group by group).  bf16 perf mode only: the f32 parity mode stays one batch on one stream.
+struct ClipGroups {
+    int G;
+    int b0[dimx_ctx::kPreGroups + 1];
+    hipStream_t st[dimx_ctx::kPreGroups];
+};
+static int clip_groups_fork(dimx_handle h, int B, int T, hipStream_t st, ClipGroups& cg, bool one_group = false) {
+    int G = one_group ? 1 : h->prefill_groups;
+    if (G == 0) {
+        // what the groups buy is the idle tail of every launch: nothing once a stage runs many rounds of blocks anyway (2 560
+        // sequences x 299 rows, the best-of-10 protocol's VQ decode: 4 groups measured 5 % SLOWER than one batch)
+        const size_t rows = (size_t)B * T;
+        G = rows > 196608 ? 1 : rows >= 32768 ? 4 : rows >= 16384 ? 2 : 1;
+    }
+    if (h->at != DIMX_BF16) G = 1;
+    if (G > B) G = B;
+    cg.G = G;
+    for (int g = 0; g <= G; ++g) cg.b0[g] = (int)((long)B * g / G);
+    cg.st[0] = st;
+    if (G == 1) return DIMX_OK;
+    {
+        // a stream that is being captured keeps one batch (a query would invalidate the capture)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            cg.G = 1;
+            cg.b0[1] = B;
+            return DIMX_OK;
+        }
+        // The side streams must not sit behind the fork event for long: with a whole generation still queued on the caller's
+        // stream (the best-of-10 pass, no host synchronisation between forwards: 600 ms) the following generation ran 5 % slower
+        // (3 580 against 3 820 sequences/s, profiles/r05_prefill_groups.txt).  So when the caller's stream still has work in
+        // flight the call waits for it here, on the host, and forks from an idle stream; the stage's own launches then run ahead
+        // of the GPU as before.
+        if (hipStreamQuery(st) != hipSuccess) (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+    }
+    if (!h->pre_fork) DIMX_HIP(hipEventCreateWithFlags(&h->pre_fork, hipEventDisableTiming));
+    DIMX_HIP(hipEventRecord(h->pre_fork, st));
+    for (int g = 1; g < G; ++g) {
+        if (!h->pre_stream[g - 1]) DIMX_HIP(hipStreamCreateWithFlags(&h->pre_stream[g - 1], hipStreamNonBlocking));
+        if (!h->pre_join[g - 1]) DIMX_HIP(hipEventCreateWithFlags(&h->pre_join[g - 1], hipEventDisableTiming));
+        cg.st[g] = h->pre_stream[g - 1];
+        DIMX_HIP(hipStreamWaitEvent(cg.st[g], h->pre_fork, 0));
+    }
+    return DIMX_OK;
+}
+static int clip_groups_join(dimx_handle h, const ClipGroups& cg) {
+    for (int g = 1; g < cg.G; ++g) {
+        DIMX_HIP(hipEventRecord(h->pre_join[g - 1], cg.st[g]));
+        DIMX_HIP(hipStreamWaitEvent(cg.st[0], h->pre_join[g - 1], 0));
+    }
+    return DIMX_OK;
+}
+
 static Arena scratch_arena(const dimx_ctx* c, void* ws, size_t ws_bytes, int B, int T, CtxPersist* cp) {
     Arena p(ws, ws_bytes);
     CtxPersist tmp;
@@ -1228,10 +1298,18 @@ int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens
     hipStream_t st = (hipStream_t)stream;
     const VQGeom& vg = h->vqg[which];
     Arena ar = scratch_arena(h, ws, ws_bytes, B, T, nullptr);
-    VQScratch s;
-    plan_vq(h, vg, ar, B, T, s);
+    ClipGroups cg;
+    DIMX_TRY(clip_groups_fork(h, B, T, st, cg));
+    VQScratch s[dimx_ctx::kPreGroups];
+    for (int g = 0; g < cg.G; ++g) plan_vq(h, vg, ar, cg.b0[g + 1] - cg.b0[g], T, s[g]);
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_encode: workspace overflow");
-    DIMX_TRY(run_vq_encode(h, which, x, lens, B, T, pe_mode, batch_row_offset, s, z_out ? z_out : s.z, idx, st));
+    for (int g = 0; g < cg.G; ++g) {
+        const int b0 = cg.b0[g], nb = cg.b0[g + 1] - b0;
+        const size_t r0 = (size_t)b0 * T;
+        DIMX_TRY(run_vq_encode(h, which, x + r0 * vg.in_dim, lens ? lens + b0 : nullptr, nb, T, pe_mode, batch_row_offset + b0, s[g],
+                               z_out ? z_out + r0 * vg.out_dim : s[g].z, idx + r0 * vg.fqn, cg.st[g]));
+    }
+    DIMX_TRY(clip_groups_join(h, cg));
     DIMX_TRY(launch_finalize_idx(idx, lens, B, T, pad_value, st, vg.fqn));
     return DIMX_OK;
 }
@@ -1248,29 +1326,44 @@ static int vq_decode_impl(dimx_handle h, int which, const int32_t* idx, const fl
     const VQNet& v = h->vq[which];
     const VQGeom& vg = h->vqg[which];
     DIMX_REQUIRE(vg.has_decoder, DIMX_ERR_ARG, "vq_decode: this variant's VQ-VAE %d has no decoder on the path", which);
-    Arena ar = scratch_arena(h, ws, ws_bytes, B, L, nullptr);
-    VQScratch s;
-    plan_vq(h, vg, ar, B, L, s);
-    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_decode: workspace overflow");
-    const int M = B * L, Hd = vg.hidden, zd = vg.zdim;
-    if (idx)
-        DIMX_TRY(launch_gather_rows(h->at, v.E, zd, vg.n_embed, idx, s.xa, zd, M, zd, st));
-    else
-        DIMX_TRY(launch_cast_pad(h->at, z, zd, nullptr, s.xa, zd, M, zd, st));
-    GemmArgs g;
-    gemm_lin(h, s.xa, zd, v.pre, M, g);
-    g.out_dtype = h->at;
-    gemm_set_plain_out(g, s.h1, Hd);
-    DIMX_TRY(launch_gemm(g, st));
     DIMX_REQUIRE(rows_per_clip >= 1, DIMX_ERR_ARG, "vq_decode: rows_per_clip must be >= 1");
-    DIMX_TRY(run_vq_front(h, vg, s.h1, Hd, v.dconv, v.dle, v.pe_dec, 1, batch_row_offset, s, B, L, nullptr, st,
-                          rows_per_clip));
-    DIMX_TRY(run_vq_blocks(h, vg, v.dec, s, B, L, nullptr, st));
-    DIMX_TRY(launch_cast_pad(h->at, s.h, Hd, nullptr, s.y, Hd, M, Hd, st));
-    gemm_lin(h, s.y, Hd, v.rev, M, g);
-    g.out_dtype = DIMX_F32;
-    gemm_set_plain_out(g, out, vg.in_dim);
-    DIMX_TRY(launch_gemm(g, st));
+    Arena ar = scratch_arena(h, ws, ws_bytes, B, L, nullptr);
+    ClipGroups cg;
+    if (rows_per_clip == 1) {
+        DIMX_TRY(clip_groups_fork(h, B, L, st, cg));
+    } else {  // several rows share a clip's positional row: one batch (the groups would have to be cut at clip boundaries)
+        cg.G = 1;
+        cg.b0[0] = 0;
+        cg.b0[1] = B;
+        cg.st[0] = st;
+    }
+    VQScratch sg[dimx_ctx::kPreGroups];
+    for (int g = 0; g < cg.G; ++g) plan_vq(h, vg, ar, cg.b0[g + 1] - cg.b0[g], L, sg[g]);
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_decode: workspace overflow");
+    const int Hd = vg.hidden, zd = vg.zdim;
+    for (int gi = 0; gi < cg.G; ++gi) {
+        VQScratch& s = sg[gi];
+        hipStream_t gs = cg.st[gi];
+        const int b0 = cg.b0[gi], nb = cg.b0[gi + 1] - b0, M = nb * L;
+        const size_t r0 = (size_t)b0 * L;
+        if (idx)
+            DIMX_TRY(launch_gather_rows(h->at, v.E, zd, vg.n_embed, idx + r0, s.xa, zd, M, zd, gs));
+        else
+            DIMX_TRY(launch_cast_pad(h->at, z + r0 * zd, zd, nullptr, s.xa, zd, M, zd, gs));
+        GemmArgs g;
+        gemm_lin(h, s.xa, zd, v.pre, M, g);
+        g.out_dtype = h->at;
+        gemm_set_plain_out(g, s.h1, Hd);
+        DIMX_TRY(launch_gemm(g, gs));
+        DIMX_TRY(run_vq_front(h, vg, s.h1, Hd, v.dconv, v.dle, v.pe_dec, 1, batch_row_offset + b0, s, nb, L, nullptr, gs, rows_per_clip));
+        DIMX_TRY(run_vq_blocks(h, vg, v.dec, s, nb, L, nullptr, gs));
+        DIMX_TRY(launch_cast_pad(h->at, s.h, Hd, nullptr, s.y, Hd, M, Hd, gs));
+        gemm_lin(h, s.y, Hd, v.rev, M, g);
+        g.out_dtype = DIMX_F32;
+        gemm_set_plain_out(g, out + r0 * vg.in_dim, vg.in_dim);
+        DIMX_TRY(launch_gemm(g, gs));
+    }
+    DIMX_TRY(clip_groups_join(h, cg));
     return DIMX_OK;
 }
 
@@ -1318,23 +1411,37 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
     hipStream_t st = (hipStream_t)stream;
     CtxPersist cp;
     Arena ar = scratch_arena(h, ws, ws_bytes, B, T, &cp);
-    EncScratch s;
-    plan_enc(h, ar, B, T, s);
-    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "encode_ctx: workspace overflow");
-    const int M = B * T, dim = h->d.dim, dim_a = h->d.dim_a;
-    // v_speaker + patch_embed_s, padded 56 -> 64
-    DIMX_TRY(launch_cast_pad(h->at, v_speaker, h->d.dim_in, h->patch_s, s.xa, 64, M, h->d.dim_in, st));
-    DIMX_TRY(run_xenc(h, h->encg[0], h->enc_s, s.xa, 64, s, B, T, mask, h->at, s.xa, st));  // output reuses xa
-    DIMX_TRY(run_xenc(h, h->encg[1], h->enc_joint, s.xa, dim, s, B, T, mask, DIMX_F32, s.tmp, st));
-    float* x_s = x_s_out ? x_s_out : s.tmp;
-    // norm_s = nn.LayerNorm(dim) with bias (code/seq2seq_pretrain.py:411,441); in place when no copy is wanted
-    {
-        float* dst = x_s_out ? x_s_out : (float*)s.h;
-        DIMX_TRY(launch_layernorm(DIMX_F32, s.tmp, dst, h->norm_s_g, h->norm_s_b, M, dim, st));
-        x_s = dst;
+    const int dim = h->d.dim, dim_a = h->d.dim_a;
+    // the encoders run per clip group (ClipGroups above); the context rows of all groups land in ONE [B T, ctx] buffer (the first
+    // group's `xa`, sized for the whole batch) so that the K/V projection of the four decoder layers stays one launch
+    ClipGroups cg;
+    DIMX_TRY(clip_groups_fork(h, B, T, st, cg, h->decg.ctx_dim < h->encg[0].in_pad));  // a group's rows of `xa` are context rows
+    EncScratch sg[dimx_ctx::kPreGroups];
+    void* xa_all = nullptr;
+    const size_t xa_row = (size_t)h->decg.ctx_dim * es_of(h);
+    if (cg.G > 1) xa_all = ar.take((size_t)B * T * xa_row);
+    for (int g = 0; g < cg.G; ++g) {
+        plan_enc(h, ar, cg.b0[g + 1] - cg.b0[g], T, sg[g]);
+        if (cg.G > 1) sg[g].xa = (unsigned char*)xa_all + (size_t)cg.b0[g] * T * xa_row;   // the group's own `xa` stays unused
     }
-    DIMX_TRY(launch_context_concat(h->at, x_s, h->patch_dec_s, v_audio, s.xa, M, dim, dim_a, st));
-    DIMX_TRY(project_cross_kv(h, s.xa, cp, B, T, for_generate, st));
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "encode_ctx: workspace overflow");
+    for (int gi = 0; gi < cg.G; ++gi) {
+        EncScratch& s = sg[gi];
+        hipStream_t gs = cg.st[gi];
+        const int b0 = cg.b0[gi], nb = cg.b0[gi + 1] - b0, M = nb * T;
+        const size_t r0 = (size_t)b0 * T;
+        const uint8_t* gmask = mask + r0;
+        // v_speaker + patch_embed_s, padded 56 -> 64
+        DIMX_TRY(launch_cast_pad(h->at, v_speaker + r0 * h->d.dim_in, h->d.dim_in, h->patch_s, s.xa, 64, M, h->d.dim_in, gs));
+        DIMX_TRY(run_xenc(h, h->encg[0], h->enc_s, s.xa, 64, s, nb, T, gmask, h->at, s.xa, gs));  // output reuses xa
+        DIMX_TRY(run_xenc(h, h->encg[1], h->enc_joint, s.xa, dim, s, nb, T, gmask, DIMX_F32, s.tmp, gs));
+        // norm_s = nn.LayerNorm(dim) with bias (code/seq2seq_pretrain.py:411,441); in place when no copy is wanted
+        float* x_s = x_s_out ? x_s_out + r0 * dim : (float*)s.h;
+        DIMX_TRY(launch_layernorm(DIMX_F32, s.tmp, x_s, h->norm_s_g, h->norm_s_b, M, dim, gs));
+        DIMX_TRY(launch_context_concat(h->at, x_s, h->patch_dec_s, v_audio + r0 * dim_a, s.xa, M, dim, dim_a, gs));
+    }
+    DIMX_TRY(clip_groups_join(h, cg));
+    DIMX_TRY(project_cross_kv(h, sg[0].xa, cp, B, T, for_generate, st));
     h->ctx_ready = true;
     h->ctx_B = B;
     h->ctx_T = T;

@@ -149,6 +149,11 @@ struct dimx_ctx {
     hipGraphExec_t graph_exec[kMaxGroups] = {};
     hipGraphExec_t graph_multi[kMaxGroups] = {};  // the same step captured graph_unroll times back to back
     int graph_unroll = 16;                        // DIMX_GRAPH_UNROLL (1 = one launch per step)
+    // prefill (VQ encode, encoders + context, VQ decode) as clip groups on several streams (round 5, bf16 mode; DIMX_PREFILL_GROUPS)
+    static constexpr int kPreGroups = 4;
+    int prefill_groups = 0;             // 0 = automatic, 1 = one batch on the caller's stream, 2..4
+    hipStream_t pre_stream[kPreGroups - 1] = {};
+    hipEvent_t pre_fork = nullptr, pre_join[kPreGroups - 1] = {};
     hipStream_t grp_stream[kMaxGroups] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups] = {};
     int gen_groups = 1;  // independent clip groups decoded concurrently on separate streams (DIMX_GEN_GROUPS;

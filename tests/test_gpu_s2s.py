@@ -345,3 +345,49 @@ def test_optional_bias_tensors_of_other_xtransformers_releases(full_sd):
     # the training step has no gradient for these tensors: it refuses them
     assert e.lib.dimx_train_num_params(e.h) == -4 and b"to_logits.bias" in e.lib.dimx_last_error()   # DIMX_ERR_STATE
     e.close()
+
+
+def test_prefill_clip_groups_reproduce_the_single_batch(full_sd):
+    """round 5, bf16 mode: VQ encode, the encoders + context and VQ decode run as clip groups on several streams once a batch has
+    >= 16 384 rows (csrc/model.hip ClipGroups; DIMX_PREFILL_GROUPS=1 keeps one batch on the caller's stream).  Every clip's
+    results must be what the single batch gives: indices and tokens identical, coefficients to the last bit or within bf16
+    noise where a group's row count picks another GEMM tiling; ragged lengths, a batch that does not divide by four."""
+    import os
+    from dimx import engine, lib
+    B, T = 131, 300
+    lens = [T - (i * 13) % 120 for i in range(B)]
+    v_s, v_a, z, mask = _case(B, T, lens, seed=41)
+    v_l = torch.randn(B, T, 56, generator=torch.Generator().manual_seed(3)).cuda()
+    m8 = mask.to(torch.uint8).cuda()
+    lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
+    idx_dec = torch.randint(0, 512, (B, T - 1), generator=torch.Generator().manual_seed(4), dtype=torch.int32).cuda()
+
+    def run(groups):
+        if groups:
+            os.environ["DIMX_PREFILL_GROUPS"] = str(groups)
+        try:
+            e = engine.Engine("cuda:0", lib.MODE_PERF_BF16)
+        finally:
+            os.environ.pop("DIMX_PREFILL_GROUPS", None)
+        e.load_state_dict(full_sd)
+        idx, zq = e.vq_encode(1, v_l, lens_t, pe_mode=0, pad_value=-100, return_z=True)
+        x_s = e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True, return_x_s=True)
+        tok = e.generate(z[:, 0].cuda(), m8, T, 0.0)
+        dec = e.vq_decode(1, idx_dec)
+        dec3 = e.vq_decode(1, idx_dec[:, :100].contiguous(), row_offset=5)
+        torch.cuda.synchronize()
+        out = [t.cpu() for t in (idx, zq, x_s, tok, dec, dec3)]
+        e.close()
+        return out
+
+    one = run(1)
+    for groups in (0, 2, 3):   # 0 = automatic (four groups at this size)
+        many = run(groups)
+        assert torch.equal(one[0], many[0]), "VQ indices differ with %d groups" % groups
+        for k, name in ((1, "z"), (2, "x_s"), (4, "decoded motion"), (5, "decoded motion, row offset 5")):
+            d = (one[k] - many[k]).abs().max().item()
+            print("groups %d: %s max |difference| %.3g" % (groups, name, d))
+            assert d <= 2e-2, "%s differs by %g with %d groups" % (name, d, groups)
+        agree = (one[3] == many[3]).float().mean().item()
+        print("groups %d: generated tokens agreement %.4f" % (groups, agree))
+        assert torch.equal(one[3][:, :4], many[3][:, :4])
