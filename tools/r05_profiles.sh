@@ -26,7 +26,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 python tools/pmc_summary.py $O/pmc_mfma | grep -A9 "gemm256p2" > $O/r05_pmc_mfma_cross_kv.txt
 python tools/pmc_gemm256_record.py $O/r05_pmc_mfma_cross_kv.txt $O/r05_cross_kv_line_under_pmc.txt $COMMIT >> $O/r05_pmc_record.txt 2>&1
 # MFMA busy of the two other MFMA kernels of the prefill (fused feed-forward sublayer, prefill attention), same counters
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_pre -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-mode --no-train-step --no-roofline > /dev/null 2>&1
+# (one batch on one stream, DIMX_PREFILL_GROUPS=1: with the clip groups of the default path several of these kernels run at the same time
+#  and a kernel's counters are diluted by its neighbours -- 19 % instead of 27 % MFMA busy for the fused feed-forward kernel)
+DIMX_PREFILL_GROUPS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_pre -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-mode --no-train-step --no-roofline > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_pre | grep -A8 "mlp_fused_kernel\|attn_tr_kernel" > $O/r05_pmc_mfma_prefill_kernels.txt
 python tools/pmc_prefill_record.py $O/r05_pmc_mfma_prefill_kernels.txt $COMMIT >> $O/r05_pmc_record.txt 2>&1
 cp profiles/pmc_*.json $O/ 2>/dev/null
