@@ -1203,7 +1203,8 @@ int legacy_encode_ctx(dimx_handle h, const float* v_speaker, const uint8_t* mask
 // tiles end the same way).  As G clip groups on G streams the tails of one group's kernels are filled by another group's blocks:
 // 15.8 -> 14.2 ms for the three stages at 256 x 300 with G = 4 (tools/r05_prefill_streams.py, profiles/r05_prefill_groups.txt).
 // Group 0 runs on the caller's stream, the others on the handle's side streams between a fork and a join event; every group
-// has its own scratch (the same arena, planned group by group).  bf16 perf mode only: the f32 parity mode stays one batch on one stream.
+// has its own scratch (the same arena, planned group by group).  Both numeric modes: a clip's results do not depend on the batch it is
+// computed in (the f32 mode by contract -- test_c3_batch_and_shard_invariance compares the grouped whole batch with its shards bit for bit).
 struct ClipGroups {
     int G;
     int b0[dimx_ctx::kPreGroups + 1];
@@ -1217,7 +1218,6 @@ static int clip_groups_fork(dimx_handle h, int B, int T, hipStream_t st, ClipGro
         const size_t rows = (size_t)B * T;
         G = rows > 196608 ? 1 : rows >= 32768 ? 4 : rows >= 16384 ? 2 : 1;
     }
-    if (h->at != DIMX_BF16) G = 1;
     if (G > B) G = B;
     cg.G = G;
     for (int g = 0; g <= G; ++g) cg.b0[g] = (int)((long)B * g / G);

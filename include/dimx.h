@@ -4,7 +4,7 @@
  * thread-local message.  All device work is enqueued asynchronously on the hipStream_t passed
  * in (as void*; NULL = the null stream).  A handle is bound to one device and is not
  * re-entrant across streams.  Two exceptions to "asynchronously": dimx_generate reads its chain kernels' fault word before it
- * returns (bf16 mode), and in the bf16 mode dimx_vq_encode / dimx_encode_ctx / dimx_vq_decode run batches of >= 16 384 rows as
+ * returns (bf16 mode), and dimx_vq_encode / dimx_encode_ctx / dimx_vq_decode run batches of >= 16 384 rows as
  * clip groups on the handle's own side streams (fork / join events around them: every result is complete in stream order when
  * the call's stream reaches the join) -- if the call's stream still has work in flight when such a call is made, the call waits
  * for it on the host before it forks (DIMX_PREFILL_GROUPS=1 keeps one batch on the caller's stream and never waits).
