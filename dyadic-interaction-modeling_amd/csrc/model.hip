@@ -1096,6 +1096,7 @@ static size_t workspace_bytes(const dimx_ctx* c, int B, int T, int S = 1) {
         Arena a(nullptr, 0);
         EncScratch s;
         plan_enc(c, a, B, T, s);
+        if (c->variant == 0) a.take((size_t)B * T * c->decg.ctx_dim * es_of(c));  // the shared context buffer of dimx_encode_ctx's clip groups
         if (c->variant == 1) {  // the speaker VQ-VAE runs inside encode_ctx, next to the encoder buffers
             VQScratch v;
             plan_vq(c, c->vqg[0], a, B, T, v);
