@@ -324,6 +324,10 @@ def main():
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--no-shard-check", action="store_true")
+    ap.add_argument("--gather", default="tokens+coeffs", choices=["tokens", "tokens+coeffs"],
+                    help="payload of the timed step's ONE all-gather (N > 1): the generated code indices (north_star's wording), or the "
+                         "indices + the decoded coefficients in one packed buffer -- what x_engine_pt.evaluate_test_epoch gathers for the "
+                         "metrics rank (17 MB per rank at C4 against 0.3 MB); the default times the real payload")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # launcher self-test on CPU / gloo, no kernels
     # rehearsal of the N-rank path with the REAL model on a 1-GPU box: every rank on cuda:0, collectives on gloo (RCCL refuses
     # two ranks on one device).  Its line says so and is not a measurement (tools/scale_check.sh rehearse).
@@ -365,8 +369,13 @@ def main():
         _, _, pred, tokens = model(v_s, v_l, v_a, mask, mode="val", seed=SEED + i + 1, return_tokens=True,
                                    n_samples=args.samples)
         tok = tokens.reshape(-1, T - 1).to(torch.int32)
-        gathered = ddist.all_gather_rows(tok, [tok.shape[0]] * world)   # equal shards: ONE collective, nothing synchronises first
-        return pred, gathered
+        # equal shards: ONE collective, nothing synchronises with the host first
+        if args.gather == "tokens":
+            return pred, ddist.all_gather_rows(tok, [tok.shape[0]] * world)
+        # the payload evaluate_test_epoch gathers (code/x_engine_pt.py:259-270 accumulates exactly these on the host): indices +
+        # decoded coefficients, packed into one buffer (dist.pack_rows)
+        buf = ddist.all_gather_rows(ddist.pack_rows(tok, pred.reshape(tok.shape[0], -1).float()), [tok.shape[0]] * world)
+        return pred, buf[:, :T - 1]      # the indices' columns of the gathered buffer (the metrics rank unpacks the rest)
 
     for i in range(args.warmup):
         step(i)
@@ -411,8 +420,10 @@ def main():
         "config": {"workload": "%s: B=%d/GPU synthetic dyad clips, T=%d, SLMFT.forward(mode='val'): listener VQ "
                                "encode + encoder + %d-step AR decode (top-k 52 sampling) + VQ decode"
                                % (tag, B, T, T - 1),
-                   "global_batch": world * B, "seq_len": T, "parallelism": "dp%d (clips sharded, all-gather of "
-                   "code indices)" % world},
+                   "global_batch": world * B, "seq_len": T, "parallelism": "dp%d (clips sharded, ONE all-gather of %s per batch)"
+                   % (world, "code indices" if args.gather == "tokens" else "code indices + decoded coefficients"),
+                   "gather": args.gather,
+                   "gather_bytes_per_rank": B * args.samples * (T - 1) * (4 + (56 * 4 if args.gather != "tokens" else 0))},
         "achieved_tflops_necessary_work": clips_s * GFLOP_PER_CLIP_T300 * (T / 300.0) / 1e3,
         "rccl_ranks": rccl_ranks,
     }

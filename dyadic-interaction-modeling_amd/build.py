@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdimx_hip.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attention.hip", "attention_tr.hip", "mlp_fused.hip", "decode_attn.hip", "vq.hip", "elementwise.hip", "chain.hip", "model.hip",
+SOURCES = ["gemm.hip", "gemm_x3.hip", "gemm256.hip", "norm.hip", "attention.hip", "attention_tr.hip", "mlp_fused.hip", "decode_attn.hip", "vq.hip", "elementwise.hip", "chain.hip", "model.hip",
            "train_kernels.hip", "train_attn.hip", "train.hip"]
 HEADERS = ["common.hpp", "model.hpp", "train.hpp", os.path.join("..", "..", "include", "dimx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -266,6 +266,8 @@ struct GemmArgs {
                        // contiguous KiB instead of 8 row segments (tools/ubench/cu_load_rate.hip: 122-143 vs 70-78 GB/s per CU).
                        // gemm_ws_kernel only.  Measured: -0.2 us per decode GEMM, nothing end to end (1467 vs 1467 clips/s) -- the
                        // model keeps row-major weights; the switch stays for tools/gemm_ab.py and the kernel test.
+    const void* w3;    // round 6, f32 parity mode: W as three bf16 planes [3][N][ldw] whose sum is W exactly (split_x3); with it a
+    long w3_plane;     // decode-sized f32 GEMM runs on the bf16 matrix cores, f32-equivalent (gemm_x3_kernel).  Elements between planes.
     int tile_map;      // set by the launcher (prefill): 1 = every XCD works on one half of the N tiles of a quarter of the
                        // M tiles, so that its share of W (N/2 x K) stays L2-resident while the A panels stream through
     int vt_pack4;      // set by the launcher: transposed (time-contiguous) segments take 4 packed rows per store
@@ -281,6 +283,13 @@ bool gemm_decode_has_ln_epilogue();
 bool gemm256_eligible(const GemmArgs& a);
 int launch_gemm256(const GemmArgs& a, hipStream_t s);
 int launch_gemm256_segs(const GemmArgs& a, const OutSeg* segs, int nseg, int seg_width, hipStream_t s);
+// the split-bf16 decode GEMM of the f32 parity mode (gemm_x3.hip): eligibility, tile / split plan (functions of N, K and the
+// slab flag only), launch
+bool gemm_use_x3(const GemmArgs& a);
+bool gemm_x3_plan(const GemmArgs& a, int* bn_out, int* sp_out);
+int launch_gemm_x3(const GemmArgs& a, hipStream_t s);
+// W [N][ldw] f32 -> three bf16 planes [3][N][ldw] with plane0 + plane1 + plane2 == W exactly
+int launch_split_x3(const float* w, void* planes, size_t n, hipStream_t s);
 // number of K splits launch_gemm will use for an out_slabs GEMM (the consumer needs it)
 int gemm_plan_splits(const GemmArgs& a);
 
@@ -333,6 +342,8 @@ struct DecodeAttnArgs {
     int nslab;
     long slab_stride;      // elements between slabs
     int force_nsplit;      // tests: waves per (clip, head) (0 = automatic)
+    int clip_blocks;       // round 6 (two-engine experiment): one 12-wave block per clip that owns its CU (LDS request > half a CU),
+                           // the layer kernel's attention shape as a launch of its own; bf16, H == 12, f32 slab q only
     int rows_per_clip;     // cross attention with several query rows per clip (multi-sample generation):
                            // rows r*S .. r*S+S-1 of q/out share clip r's K/V cache and mask (0/1 = one row)
     const void* knew;      // self-attn: this step's k/v rows [B, *] (nullptr for cross attention)

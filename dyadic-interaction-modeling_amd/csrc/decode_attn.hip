@@ -24,6 +24,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a
 }
 
 
+// Round 6, two-engine experiment (DIMX_GEN_EXCL=1): ONE 12-wave block per clip (a wave per head, no block barrier) whose LDS
+// request is more than half a CU's, so that a block owns its CU: B blocks occupy B CUs and the other engine's one-block-per-CU
+// kernels take the rest -- the placement a whole-XCD CU mask would have given, which this platform does not honour
+// (profiles/r06_xcdmask_probe.txt).
+template <bool SELF>
+__global__ __launch_bounds__(768) void decode_attn_clip_kernel(const DecodeAttnArgs a, int sc_stride) {
+    extern __shared__ __attribute__((aligned(16))) float sc_clip[];
+    decode_attn_body<bf16, SELF, true, 1, 12>(a, blockIdx.x, sc_clip, sc_stride, nullptr, nullptr, nullptr);
+}
+
 // Multi-sample cross attention: SQ query rows (independent samples of the same clip) share one pass over
 // the clip's K/V cache -- the reference's best-of-10 protocol (code/x_engine_pt.py:257) re-reads the same
 // context ten times; here the cache is streamed once per (clip, head) and every key is scored against all SQ
@@ -189,6 +199,22 @@ int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s) {
         else { if (a.q_f32) DM_S(float, true); else DM_S(float, false); }
 #undef DM_S
 #undef DM
+        DIMX_HIP(hipGetLastError());
+        return DIMX_OK;
+    }
+    if (a.clip_blocks && a.dtype == DIMX_BF16 && a.q_f32 && a.H == 12) {
+        const int nk = a.knew ? a.Tmax : a.n_keys;
+        const int sc_stride = (nk + 15) / 16 * 16;
+        size_t lds = (size_t)12 * sc_stride * sizeof(float);
+        if (lds < 84 * 1024) lds = 84 * 1024;   // two of these (or one and a 64 x 72 decode GEMM block) never share a CU
+        DIMX_REQUIRE(lds <= 160 * 1024, DIMX_ERR_ARG, "decode_attn: %d keys do not fit the one-block-per-clip form", nk);
+        if (a.knew) {
+            (void)hipFuncSetAttribute((const void*)decode_attn_clip_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((decode_attn_clip_kernel<true>), dim3(a.B), dim3(768), lds, s, a, sc_stride);
+        } else {
+            (void)hipFuncSetAttribute((const void*)decode_attn_clip_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((decode_attn_clip_kernel<false>), dim3(a.B), dim3(768), lds, s, a, sc_stride);
+        }
         DIMX_HIP(hipGetLastError());
         return DIMX_OK;
     }

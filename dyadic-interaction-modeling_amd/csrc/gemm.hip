@@ -1429,7 +1429,11 @@ __global__ __launch_bounds__(640) void gemm_ws72_kernel(const GemmArgs a) {
 
 template <typename OutT> static int launch_ws72(const GemmArgs& a, hipStream_t s) {
     const int tiles = ceil_div(a.M, 64) * ceil_div(a.N, 72);
-    static const int kt = getenv("DIMX_WS72_KT") ? atoi(getenv("DIMX_WS72_KT")) : 1;  // k-tiles per barrier; 2 measured SLOWER (1624 vs 1653 clips/s, profiles/r05_gemm_ws72.txt)
+    static const int kt_env = getenv("DIMX_WS72_KT") ? atoi(getenv("DIMX_WS72_KT")) : 1;  // k-tiles per barrier; 2 measured SLOWER (1624 vs 1653 clips/s, profiles/r05_gemm_ws72.txt)
+    // the deferred-LayerNorm epilogue writes ln_sm two stages before the last barrier: with two k-tiles per barrier a block
+    // needs at least two stages (4 k-tiles) for that barrier to exist (K = 128 raced); shorter blocks keep KT = 1
+    const int nk_blk = a.K / 64 / (a.splitk > 0 ? a.splitk : 1);
+    const int kt = (kt_env == 2 && !(a.ln_stats && nk_blk < 4)) ? 2 : 1;
     if (a.prof) {
         if (kt == 1) hipLaunchKernelGGL((gemm_ws72_kernel<OutT, true, 1>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
         else hipLaunchKernelGGL((gemm_ws72_kernel<OutT, true, 2>), dim3(tiles * a.splitk), dim3(640), 0, s, a);
@@ -1650,6 +1654,11 @@ template <typename T, typename OutT> static int launch_typed(const GemmArgs& a0,
 
 int gemm_plan_splits(const GemmArgs& a) {
     if (!a.out_slabs) return 1;
+    if (gemm_use_x3(a)) {
+        int bn = 0, sp = 1;
+        (void)gemm_x3_plan(a, &bn, &sp);
+        return sp;
+    }
     if (a.force_splitk > 0) return a.force_splitk;
     if (!a.allow_splitk) return 1;
     const int bk = a.in_dtype == DIMX_BF16 ? 64 : 32;
@@ -1777,6 +1786,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         return launch_typed<bf16, float>(a, s);
     }
     DIMX_REQUIRE(a.out_dtype == DIMX_F32, DIMX_ERR_ARG, "gemm: f32 inputs produce f32 outputs");
+    if (gemm_use_x3(a)) return launch_gemm_x3(a, s);   // round 6: decode-sized f32 GEMMs on the bf16 matrix cores, f32-equivalent (gemm_x3.hip)
     return launch_typed<float, float>(a, s);
 }
 

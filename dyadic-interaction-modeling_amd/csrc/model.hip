@@ -278,6 +278,21 @@ static int pack_linear(dimx_ctx* c, const std::vector<std::string>& parts, const
     return DIMX_OK;
 }
 
+// f32 parity mode: the three bf16 planes of a packed f32 Linear (gemm_x3.hip; DIMX_NO_X3=1 keeps the f32 MFMA kernel, for A/B runs)
+static int make_x3(dimx_ctx* c, Linear* L) {
+    static const bool off = getenv("DIMX_NO_X3") != nullptr;
+    L->w3 = nullptr;
+    if (off || c->at != DIMX_F32 || !L->w || L->Kp % 32 != 0) return DIMX_OK;
+    const size_t n = (size_t)L->N * L->Kp;
+    void* p = nullptr;
+    DIMX_HIP(hipMalloc(&p, 3 * n * 2));
+    c->dev_allocs.push_back(p);
+    DIMX_TRY(launch_split_x3((const float*)L->w, p, n, nullptr));
+    DIMX_HIP(hipStreamSynchronize(nullptr));
+    L->w3 = p;
+    return DIMX_OK;
+}
+
 // W' = gamma o W (columns scaled by the LayerNorm weight that precedes the projection) in bf16, plus the f32 row sums of
 // the ROUNDED W': LN(x) . W^T = rstd * (x . W'^T - mean * colsum(W')) (deferred LayerNorm of the decode step, bf16 mode)
 static int pack_linear_scaled(dimx_ctx* c, const std::string& wname, const std::string& gname, const std::string& bias,
@@ -498,6 +513,14 @@ static int ensure_packed(dimx_ctx* c, int need) {
                 DIMX_TRY(pack_xattn(c, xl(dp, 3 * i), false, &c->dec.self_[i]));
                 DIMX_TRY(pack_xattn(c, xl(dp, 3 * i + 1), true, &c->dec.cross[i]));
                 DIMX_TRY(pack_xff(c, xl(dp, 3 * i + 2), &c->dec.ff[i]));
+                // the projections of the decode step (M = clips) in the parity mode: bf16 planes for gemm_x3_kernel (the cross K/V
+                // projection, M = clips x frames, stays on the f32 MFMA kernel)
+                DIMX_TRY(make_x3(c, &c->dec.self_[i].qkv));
+                DIMX_TRY(make_x3(c, &c->dec.self_[i].out));
+                DIMX_TRY(make_x3(c, &c->dec.cross[i].qkv));
+                DIMX_TRY(make_x3(c, &c->dec.cross[i].out));
+                DIMX_TRY(make_x3(c, &c->dec.ff[i].f1));
+                DIMX_TRY(make_x3(c, &c->dec.ff[i].f2));
                 if (c->at == DIMX_BF16 && c->decg.dim % 64 == 0) {
                     const std::string cp = xl(dp, 3 * i + 1), fp = xl(dp, 3 * i + 2);
                     DIMX_TRY(pack_linear_scaled(c, cp + "1.to_q.weight", cp + "0.0.weight", "", &c->dec.cross[i].q_ln,
@@ -509,6 +532,7 @@ static int ensure_packed(dimx_ctx* c, int need) {
             DIMX_TRY(upload_f32(c, dp + "attn_layers.final_norm.weight", &c->dec.final_g));
             DIMX_TRY(pack_linear(c, {dp + "to_logits.weight"}, c->host.count(dp + "to_logits.bias") ? dp + "to_logits.bias" : "", false,
                                  &c->dec.logits));
+            DIMX_TRY(make_x3(c, &c->dec.logits));
             {
                 std::vector<std::string> parts;
                 for (int i = 0; i < c->decg.depth; ++i) {
@@ -548,6 +572,8 @@ static int gemm_lin(const dimx_ctx* c, const void* A, int lda, const Linear& L, 
     g.K = L.K;
     g.bias = L.bias;
     g.allow_splitk = c->at == DIMX_BF16 ? 1 : 0;  // parity mode keeps a fixed summation order
+    g.w3 = L.w3;
+    g.w3_plane = (long)L.N * L.Kp;
     return DIMX_OK;
 }
 
@@ -866,6 +892,7 @@ int dimx_destroy(dimx_handle h) {
     if (h->chain_err_ev) (void)hipEventDestroy(h->chain_err_ev);
     if (h->chain_err_dev) (void)hipFree(h->chain_err_dev);
     if (h->chain_stats_dev) (void)hipFree(h->chain_stats_dev);
+    if (h->layer_prof_dev) (void)hipFree(h->layer_prof_dev);
     if (h->chain_err_host) (void)hipHostFree(h->chain_err_host);
     free_packed(h);
     train_forget(h);   // the training plan cached for this handle (a later handle may reuse the address)
@@ -884,18 +911,43 @@ int dimx_set_shard(dimx_handle h, int row_offset, int rows_total) {
     return DIMX_OK;
 }
 
+// A new checkpoint begins: the OPTIONAL tensors an earlier checkpoint brought (project_in.bias / to_logits.bias, SURVEY A.2 [XT?])
+// are forgotten; required tensors stay until they are overwritten.  dimx_load_weights itself never drops a tensor (round 6, ADVICE
+// round 5: it used to forget a bias when a later call named the Linear's weight without it, which made a chunked or key-sorted
+// loader's result depend on the order of its calls).
+int dimx_begin_checkpoint(dimx_handle h) {
+    DIMX_REQUIRE(h, DIMX_ERR_ARG, "dimx_begin_checkpoint: null handle");
+    std::set<std::string> spec;
+    for (const auto& k : all_keys(h->d)) spec.insert(k.name);
+    bool dirty = false;
+    for (auto it = h->host.begin(); it != h->host.end();) {
+        if (!spec.count(it->first)) {
+            it = h->host.erase(it);
+            dirty = true;
+        } else {
+            ++it;
+        }
+    }
+    if (dirty) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        free_packed(h);
+        h->graph_valid = false;
+        h->ctx_ready = false;
+    }
+    return DIMX_OK;
+}
+
 int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n) {
     DIMX_REQUIRE(h && descs && n >= 0, DIMX_ERR_ARG, "dimx_load_weights: null argument");
     static thread_local std::map<std::string, std::vector<int64_t>> spec;
     spec.clear();
     for (const auto& k : all_keys(h->d)) spec[k.name] = k.shape;
     bool dirty = false;
-    std::set<std::string> seen;   // names of this call
     for (int i = 0; i < n; ++i) {
         const dimx_weight_desc& w = descs[i];
         DIMX_REQUIRE(w.name && w.data && w.ndim >= 1 && w.ndim <= 4, DIMX_ERR_ARG, "dimx_load_weights: bad desc %d", i);
         const std::string name(w.name);
-        seen.insert(name);
         auto it = spec.find(name);
         if (it == spec.end()) {
             std::vector<int64_t> oshape;
@@ -929,17 +981,6 @@ int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n) {
         t.shape.assign(w.shape, w.shape + w.ndim);
         t.data.assign(w.data, w.data + cnt);
         dirty = true;
-    }
-    // an optional bias belongs to the checkpoint that brought it: a call that replaces the Linear's weight without naming the bias
-    // again (another checkpoint) removes it
-    for (auto it = h->host.begin(); it != h->host.end();) {
-        const std::string& nm = it->first;
-        if (!spec.count(nm) && ends_with(nm, ".bias") && !seen.count(nm) && seen.count(nm.substr(0, nm.size() - 4) + "weight")) {
-            it = h->host.erase(it);
-            dirty = true;
-        } else {
-            ++it;
-        }
     }
     if (dirty) {  // re-pack lazily; device copies of the old tensors are released now
         (void)hipSetDevice(h->device);
@@ -1252,11 +1293,23 @@ static int clip_groups_fork(dimx_handle h, int B, int T, hipStream_t st, ClipGro
     return DIMX_OK;
 }
 static int clip_groups_join(dimx_handle h, const ClipGroups& cg) {
-    for (int g = 1; g < cg.G; ++g) {
-        DIMX_HIP(hipEventRecord(h->pre_join[g - 1], cg.st[g]));
-        DIMX_HIP(hipStreamWaitEvent(cg.st[0], h->pre_join[g - 1], 0));
+    hipError_t bad = hipSuccess;
+    for (int g = 1; g < cg.G; ++g) {   // every side stream is joined even when one of the calls fails
+        hipError_t e = hipEventRecord(h->pre_join[g - 1], cg.st[g]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cg.st[0], h->pre_join[g - 1], 0);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(cg.st[g]);   // last resort: the caller's stream cannot wait for it, the host does
+            bad = e;
+        }
     }
+    DIMX_HIP(bad);
     return DIMX_OK;
+}
+
+// join whatever the stage did: the stage's own error wins, the side streams are always folded back into the caller's stream
+static int clip_groups_close(dimx_handle h, const ClipGroups& cg, int rc) {
+    const int jrc = clip_groups_join(h, cg);
+    return rc != DIMX_OK ? rc : jrc;
 }
 
 static Arena scratch_arena(const dimx_ctx* c, void* ws, size_t ws_bytes, int B, int T, CtxPersist* cp) {
@@ -1303,14 +1356,19 @@ int dimx_vq_encode(dimx_handle h, int which, const float* x, const int32_t* lens
     DIMX_TRY(clip_groups_fork(h, B, T, st, cg));
     VQScratch s[dimx_ctx::kPreGroups];
     for (int g = 0; g < cg.G; ++g) plan_vq(h, vg, ar, cg.b0[g + 1] - cg.b0[g], T, s[g]);
-    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_encode: workspace overflow");
-    for (int g = 0; g < cg.G; ++g) {
-        const int b0 = cg.b0[g], nb = cg.b0[g + 1] - b0;
-        const size_t r0 = (size_t)b0 * T;
-        DIMX_TRY(run_vq_encode(h, which, x + r0 * vg.in_dim, lens ? lens + b0 : nullptr, nb, T, pe_mode, batch_row_offset + b0, s[g],
-                               z_out ? z_out + r0 * vg.out_dim : s[g].z, idx + r0 * vg.fqn, cg.st[g]));
-    }
-    DIMX_TRY(clip_groups_join(h, cg));
+    // from the fork on every return goes through the join (an error between the two left the side streams
+    // writing into a workspace the caller may free)
+    const int rc = [&]() -> int {
+        DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_encode: workspace overflow");
+        for (int g = 0; g < cg.G; ++g) {
+            const int b0 = cg.b0[g], nb = cg.b0[g + 1] - b0;
+            const size_t r0 = (size_t)b0 * T;
+            DIMX_TRY(run_vq_encode(h, which, x + r0 * vg.in_dim, lens ? lens + b0 : nullptr, nb, T, pe_mode, batch_row_offset + b0, s[g],
+                                   z_out ? z_out + r0 * vg.out_dim : s[g].z, idx + r0 * vg.fqn, cg.st[g]));
+        }
+        return DIMX_OK;
+    }();
+    DIMX_TRY(clip_groups_close(h, cg, rc));
     DIMX_TRY(launch_finalize_idx(idx, lens, B, T, pad_value, st, vg.fqn));
     return DIMX_OK;
 }
@@ -1340,8 +1398,9 @@ static int vq_decode_impl(dimx_handle h, int which, const int32_t* idx, const fl
     }
     VQScratch sg[dimx_ctx::kPreGroups];
     for (int g = 0; g < cg.G; ++g) plan_vq(h, vg, ar, cg.b0[g + 1] - cg.b0[g], L, sg[g]);
-    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_decode: workspace overflow");
     const int Hd = vg.hidden, zd = vg.zdim;
+    const int rc = [&]() -> int {
+    DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "vq_decode: workspace overflow");
     for (int gi = 0; gi < cg.G; ++gi) {
         VQScratch& s = sg[gi];
         hipStream_t gs = cg.st[gi];
@@ -1364,8 +1423,9 @@ static int vq_decode_impl(dimx_handle h, int which, const int32_t* idx, const fl
         gemm_set_plain_out(g, out + r0 * vg.in_dim, vg.in_dim);
         DIMX_TRY(launch_gemm(g, gs));
     }
-    DIMX_TRY(clip_groups_join(h, cg));
     return DIMX_OK;
+    }();
+    return clip_groups_close(h, cg, rc);
 }
 
 int dimx_vq_decode(dimx_handle h, int which, const int32_t* idx, int B, int L, int batch_row_offset, int rows_per_clip,
@@ -1425,6 +1485,7 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
         plan_enc(h, ar, cg.b0[g + 1] - cg.b0[g], T, sg[g]);
         if (cg.G > 1) sg[g].xa = (unsigned char*)xa_all + (size_t)cg.b0[g] * T * xa_row;   // the group's own `xa` stays unused
     }
+    const int grc = [&]() -> int {
     DIMX_REQUIRE(!ar.overflow, DIMX_ERR_WORKSPACE, "encode_ctx: workspace overflow");
     for (int gi = 0; gi < cg.G; ++gi) {
         EncScratch& s = sg[gi];
@@ -1441,7 +1502,9 @@ int dimx_encode_ctx(dimx_handle h, const float* v_speaker, const float* v_audio,
         DIMX_TRY(launch_layernorm(DIMX_F32, s.tmp, x_s, h->norm_s_g, h->norm_s_b, M, dim, gs));
         DIMX_TRY(launch_context_concat(h->at, x_s, h->patch_dec_s, v_audio + r0 * dim_a, s.xa, M, dim, dim_a, gs));
     }
-    DIMX_TRY(clip_groups_join(h, cg));
+    return DIMX_OK;
+    }();
+    DIMX_TRY(clip_groups_close(h, cg, grc));
     DIMX_TRY(project_cross_kv(h, sg[0].xa, cp, B, T, for_generate, st));
     h->ctx_ready = true;
     h->ctx_B = B;
@@ -1917,6 +1980,8 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         sa.H = heads;
         sa.step = s.step;
         sa.scale = scale;
+        static const bool gen_excl = getenv("DIMX_GEN_EXCL") != nullptr;   // round 6: CU-exclusive kernels for two engines
+        sa.clip_blocks = gen_excl && S == 1 ? 1 : 0;
         memset(&ca, 0, sizeof(ca));
         ca.dtype = h->at;
         ca.q = s.qc;
@@ -1936,6 +2001,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         ca.kmask = ctx_mask;
         ca.kmask_ld = T;
         ca.scale = scale;
+        ca.clip_blocks = sa.clip_blocks;
         if (defer && layer_kernel) {
             // round 5: self attention -> out-projection -> cross-q -> cross attention -> out-projection as ONE XCD-local launch
             LayerChainArgs lc;
@@ -2274,7 +2340,47 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
         g.conv_C = K / 5;
     }
     gemm_set_plain_out(g, C, ldc);
+    if ((flags >> 4) & 1) {   /* the f32 parity mode's split-bf16 kernel (gemm_x3.hip): W split into its three planes here; synchronises */
+        DIMX_REQUIRE(in_dtype == DIMX_F32 && out_dtype == DIMX_F32 && ldw == K && K % 32 == 0, DIMX_ERR_ARG, "op_gemm(x3): f32, ldw == K, K %% 32 == 0");
+        const size_t n = (size_t)N * K;
+        void* planes = nullptr;
+        DIMX_HIP(hipMalloc(&planes, 3 * n * 2));
+        int rc = launch_split_x3((const float*)W, planes, n, (hipStream_t)stream);
+        g.w3 = planes;
+        g.w3_plane = (long)n;
+        if (rc == DIMX_OK && !gemm_use_x3(g)) {
+            set_error("op_gemm(x3): shape M=%d N=%d K=%d is not taken by the split-bf16 kernel", M, N, K);
+            rc = DIMX_ERR_ARG;
+        }
+        if (rc == DIMX_OK) rc = launch_gemm(g, (hipStream_t)stream);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(planes);
+        return rc;
+    }
     return launch_gemm(g, (hipStream_t)stream);
+}
+
+/* number of split-K slabs an out_slabs dimx_op_gemm call with these arguments writes (tests: the f32 kernels plan it themselves) */
+int dimx_op_gemm_slabs(int in_dtype, int M, int N, int K, int flags) {
+    GemmArgs g;
+    gemm_args_init(g);
+    g.in_dtype = in_dtype;
+    g.out_dtype = DIMX_F32;
+    g.A = g.W = (const void*)16;
+    g.lda = g.ldw = K;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.allow_splitk = flags & 1;
+    g.out_slabs = 1;
+    g.force_splitk = (flags >> 16) & 0xff;
+    if ((flags >> 4) & 1) {
+        g.w3 = (const void*)16;
+        g.w3_plane = (long)N * K;
+    }
+    float dummy;
+    gemm_set_plain_out(g, &dummy, N);
+    return gemm_plan_splits(g);
 }
 
 int dimx_op_gemm_headmajor(int dtype, const void* A, int lda, const void* W, int ldw, void* out, int M, int N, int K,

@@ -12,6 +12,9 @@ struct Linear {
     void* w = nullptr;  // [N][Kp] in the handle's operand type (bf16 / f32)
     const float* bias = nullptr;
     int N = 0, K = 0, Kp = 0;
+    // round 6, f32 parity mode, decoder projections: W as three bf16 planes [3][N][Kp] whose sum is W exactly -- the decode-sized
+    // GEMMs then run on the bf16 matrix cores, f32-equivalent (gemm_x3.hip)
+    void* w3 = nullptr;
 };
 
 struct VQBlock {

@@ -46,9 +46,13 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------ weights
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, new_checkpoint=True):
         """Upload every tensor of a reference-shaped state dict (extra reference keys that
-        are not on the hot path are ignored by the library)."""
+        are not on the hot path are ignored by the library).  ``new_checkpoint`` (default): ``sd`` is a whole checkpoint, the
+        optional tensors an earlier one brought (``project_in.bias`` / ``to_logits.bias``) are forgotten first
+        (``dimx_begin_checkpoint``); pass False for the further chunks of a checkpoint loaded in pieces."""
+        if new_checkpoint:
+            L.check(self.lib.dimx_begin_checkpoint(self.h), "dimx_begin_checkpoint")
         keep, descs = [], []
         for name, t in sd.items():
             a = t.detach().to("cpu", torch.float32).contiguous().numpy()
@@ -269,6 +273,21 @@ def tile_weight(w_, bk):
     N, Kp = w_.shape
     assert N % 8 == 0 and Kp % bk == 0
     return w_.view(N // 8, 8, Kp // bk, bk).permute(0, 2, 1, 3).contiguous().view(N, Kp)
+
+
+def op_gemm_x3(a, w, bias=None, act=0, residual=None, slabs=False):
+    """The f32 parity mode's split-bf16 decode GEMM (csrc/gemm_x3.hip): epilogue(a[M,K] @ w[N,K]^T), f32 in and out, M <= 256,
+    K % 32 == 0.  ``slabs``: the split-K partial sums [splits, M, N] as the decode step's consumers get them (the kernel plans
+    the count from (N, K))."""
+    lib = L.load()
+    a_, w_ = a.float().contiguous(), w.float().contiguous()
+    (M, K), N = a_.shape, w_.shape[0]
+    flags = 16 | (5 if slabs else 0)
+    ns = lib.dimx_op_gemm_slabs(L.F32, M, N, K, flags) if slabs else 0
+    out = torch.full((ns, M, N) if slabs else (M, N), float("nan"), dtype=torch.float32, device=a.device)
+    L.check(lib.dimx_op_gemm(L.F32, L.F32, L.ptr(a_), K, L.ptr(w_), K, L.ptr(out), N, M, N, K, L.ptr(bias), act, L.ptr(residual),
+                             residual.shape[1] if residual is not None else 0, 0, None, flags, L.stream_ptr(a.device)), "dimx_op_gemm(x3)")
+    return out
 
 
 def op_gemm(a, w, bias=None, act=0, residual=None, bf16=False, out_bf16=False, conv_T=0, conv_lens=None,

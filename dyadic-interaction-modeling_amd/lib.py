@@ -46,6 +46,7 @@ SIGNATURES = {
     "dimx_destroy": (c_int, [c_void_p]),
     "dimx_numeric_mode": (c_int, [c_void_p]),
     "dimx_load_weights": (c_int, [c_void_p, POINTER(WeightDesc), c_int]),
+    "dimx_begin_checkpoint": (c_int, [c_void_p]),
     "dimx_missing_weights": (c_int, [c_void_p]),
     "dimx_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "dimx_workspace_bytes_samples": (c_size_t, [c_void_p, c_int, c_int, c_int]),
@@ -90,6 +91,7 @@ SIGNATURES = {
                                         c_void_p]),
     "dimx_chain_faults": (c_int, [c_void_p]),
     "dimx_debug_chain_fault": (c_int, [c_void_p, c_int]),
+    "dimx_op_gemm_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "dimx_op_gemm_headmajor": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,

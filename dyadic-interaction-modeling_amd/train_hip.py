@@ -99,6 +99,10 @@ class HipTrainer:
             for name, off, numel in self.layout:
                 st = optimizer.state.get(named[name])
                 if not st:
+                    # no state = a fresh AdamW for this parameter: ZERO moments, not whatever the arena held (a cleared
+                    # optimizer.state or a reload after an interrupted epoch resumed on stale moments)
+                    self.exp_avg[off:off + numel].zero_()
+                    self.exp_avg_sq[off:off + numel].zero_()
                     continue
                 self.exp_avg[off:off + numel].copy_(st["exp_avg"].reshape(-1).to(self.device, torch.float32))
                 self.exp_avg_sq[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1).to(self.device, torch.float32))

@@ -90,10 +90,13 @@ int dimx_numeric_mode(dimx_handle h);
  * that needs it.  Unknown keys that belong to the reference surface but not to the path
  * (encoder_l.*, norm_l.*, norm.*, patch_embed_l, patch_embed_dec_l, *.project_out.weight / .bias) are
  * accepted and ignored.  OPTIONAL tensors (SURVEY A.2 [XT?]: details of x-transformers that differ between releases):
- * <encoder>.project_in.bias and <decoder>.to_logits.bias are applied when supplied and forgotten again by a call that supplies the
- * Linear's weight without them; a LayerNorm bias under *.attn_layers.* must be all zero (DIMX_ERR_WEIGHT otherwise).  Any other
- * unknown key is DIMX_ERR_WEIGHT.  Synchronous. */
+ * <encoder>.project_in.bias and <decoder>.to_logits.bias are applied when supplied and stay until dimx_begin_checkpoint (a call never
+ * drops a tensor, so a chunked or key-sorted loader gives the same result in any order); a LayerNorm bias under *.attn_layers.* must
+ * be all zero (DIMX_ERR_WEIGHT otherwise).  Any other unknown key is DIMX_ERR_WEIGHT.  Synchronous. */
 int dimx_load_weights(dimx_handle h, const dimx_weight_desc* descs, int n);
+/* A new checkpoint begins (what nn.Module.load_state_dict of another checkpoint means, code/finetune_s2s_pretrain.py:57): the
+ * optional tensors of the previous one are forgotten; the required tensors stay until overwritten.  Synchronous. */
+int dimx_begin_checkpoint(dimx_handle h);
 /* number of hot-path tensors still missing (0 = ready) */
 int dimx_missing_weights(dimx_handle h);
 
@@ -103,7 +106,15 @@ size_t dimx_workspace_bytes(dimx_handle h, int B, int T);
 /* same, when dimx_generate will draw n_samples sequences per clip */
 size_t dimx_workspace_bytes_samples(dimx_handle h, int B, int T, int n_samples);
 
-/* which: 0 = speaker VQ-VAE, 1 = listener VQ-VAE.
+/* Stream behaviour of the three prefill-sized stages (dimx_vq_encode, dimx_vq_decode(_latent), dimx_encode_ctx): from 16 384
+ * rows (B x T) up they run as 2-4 clip groups, group 0 on `stream`, the others on side streams of the handle between a fork and a
+ * join event (DIMX_PREFILL_GROUPS=1: never).  Consequences a pipelining caller must know: (1) when `stream` still has work in flight
+ * the call WAITS FOR IT ON THE HOST before it forks (hipStreamSynchronize); (2) a `stream` that is being captured keeps one batch,
+ * and the hipStreamQuery the fork uses must not run while ANOTHER thread captures in the global capture mode (use
+ * hipStreamCaptureModeThreadLocal there, or DIMX_PREFILL_GROUPS=1); (3) on an error return the side streams have been joined:
+ * nothing of the call still writes into `ws` once `stream` has drained.
+ *
+ * which: 0 = speaker VQ-VAE, 1 = listener VQ-VAE.
  * x: [B,T,56] f32, valid frames left-aligned; lens: [B] int32 device (NULL = all T).
  * pe_mode 0: every clip gets positional row 0 (the reference's batch-1 calls in forward_vq);
  * pe_mode 1: clip b gets row b + batch_row_offset (public batched VQAutoEncoder.encode).
@@ -291,10 +302,15 @@ int dimx_op_train_attention(int mfma, const float* q, const float* k, const floa
  * optional.  conv_T > 0: A is [B*conv_T, C] and the GEMM is a k=5 replicate-padded temporal
  * convolution with K = 5*C, W tap-major [N][5][C]; conv_lens optional [B] int32.
  * flags: bit 0 = allow split-K with f32 atomics (only taken when residual == C, i.e. in-place accumulation
- * onto the residual stream, small M); bit 1 = force the register-staged (non LDS-DMA) kernel. */
+ * onto the residual stream, small M); bit 1 = force the register-staged (non LDS-DMA) kernel; bit 2 = C is [splits][M, ldc] f32
+ * split-K slabs (count: dimx_op_gemm_slabs); bit 4 (f32 only, M <= 256, ldw == K) = the parity mode's split-bf16 decode kernel
+ * (csrc/gemm_x3.hip: W is split into three bf16 planes by the call, which then synchronises). */
 int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void* W, int ldw, void* C,
                  int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
                  int ldr, int conv_T, const int32_t* conv_lens, int flags, void* stream);
+/* split-K slabs an out_slabs dimx_op_gemm call with these arguments writes (the f32 kernels plan the count from (N, K) themselves;
+ * flags as in dimx_op_gemm: bit 0 allow split-K, bit 4 the split-bf16 kernel of the f32 parity mode, bits 16..23 a forced count) */
+int dimx_op_gemm_slabs(int in_dtype, int M, int N, int K, int flags);
 /* The cross-attention K/V projection as dimx_encode_ctx(for_generate=1) launches it: [M = B*rowT, K] . W[N, K]^T, the
  * N columns being nlayers x (K | V) segments of H*64 columns; segment i goes to the i-th [B, H, Tp, 64] cache inside
  * `out`.  bf16 with nlayers = 4 is the fused all-layers launch of the 256 x 256 kernel; f32 supports nlayers = 1. */
