@@ -466,11 +466,17 @@ def main():
         dt = (time.perf_counter() - t0) / PM_STEPS
         out["parity_mode"] = {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "dtype": "f32", "steps": PM_STEPS,
                               "warmup": PM_WARM, "note": "same workload in DIMX_MODE_PARITY_F32 (the mode the oracle parity "
-                              "tests run in: indices bit-exact, coefficients <= 1e-4)"}
+                              "tests run in: indices bit-exact, coefficients <= 1e-4); round 6: its decode-step GEMMs run on the bf16 "
+                              "matrix cores as exact three-plane splits of both operands with f32 accumulation (csrc/gemm_x3.hip, "
+                              "f32-equivalent; DIMX_NO_X3=1 = the exact-f32 MFMA kernel)",
+                              "decode_gemm": "gemm_x3_kernel" if os.environ.get("DIMX_NO_X3") is None else "gemm_ws_kernel<float>"}
         eng = pm.engine(device)
     if not args.no_roofline:   # per-GPU kernel measurement on rank 0's device (for N > 1 the other ranks have left by now)
         from dimx import roofline
         out["roofline"] = roofline.dominant_kernel(eng, B, T, args.mode)
+        if args.mode == "bf16" and "parity_mode" in out and B <= 256:
+            # the parity mode's decode GEMMs (round 6: split-bf16 on the bf16 matrix cores, f32-equivalent) next to the bf16 mode's kernels
+            out["roofline"]["others"] += roofline.decode_gemm_x3(B, device)
         out["cross_attn_mfma"] = roofline.cross_kv_gemm(B, T, args.mode, device)
         if args.mode == "bf16":
             out["cross_attn_bundle"] = roofline.cross_attn_bundle(B, T, args.mode, device, out["roofline"], out["cross_attn_mfma"])

@@ -679,6 +679,7 @@ __global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerCha
     // ---- stage 1: self attention of this CU's clip; wave 12 requests the out-projection's weight slice meanwhile
     if (wave == kAttnWaves) {
         const int n0 = li * a.g_so.cols;
+        if (!(a.abl & 1))
         issue_panel_nw<AUX_PLAIN, 1>((const bf16*)a.g_so.W, a.g_so.ldw, n0, n0 + a.g_so.cols - 1, a.g_so.rows_pad, a.g_so.nkt, base + a.off_W1, 0,
                                      lane);
     } else if (has_clip) {
@@ -721,6 +722,7 @@ __global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerCha
     layer_barrier(ctr, target, a.err, [&] {  // the cross-q weight slice goes out between the arrival and the wait, from EVERY wave:
         // one wave issuing its 54 pieces kept the whole block at the closing block barrier for ~2.5 us (profiles/r05_layer_kernel.txt)
         const int n2 = li * a.g_cq.cols;
+        if (!(a.abl & 1))
         issue_panel_nw<AUX_PLAIN, kLayerWaves>((const bf16*)a.g_cq.W, a.g_cq.ldw, n2, n2 + a.g_cq.cols - 1, a.g_cq.rows_pad, a.g_cq.nkt,
                                                base + a.off_W2, wave, lane);
     });
@@ -769,6 +771,7 @@ __global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerCha
                                          // LDS traffic starts (behind a possibly pending one it would drain vmcnt in the key loop)
     if (wave == kAttnWaves) {
         const int n0 = li * a.g_co.cols;
+        if (!(a.abl & 1))
         issue_panel_nw<AUX_PLAIN, 1>((const bf16*)a.g_co.W, a.g_co.ldw, n0, n0 + a.g_co.cols - 1, a.g_co.rows_pad, a.g_co.nkt, base + a.off_W3, 0,
                                      lane);
     } else if (has_clip) {

@@ -436,6 +436,8 @@ struct LayerChainArgs {
     int fault;
     unsigned long long* prof;       // tuning only: [256][16] phase stamps
     int sc_stride;                  // floats per (clip, head) score row in LDS
+    int abl;                        // tuning only (DIMX_LAYER_ABL, dimx_op_layer_chain; results are then WRONG): bit 0 = the three weight
+                                    // slices are not fetched (round 6: what do the 8 x replicated slices cost the launch?)
     int off_base, off_A1, off_W1, off_A2, off_W2, off_W3, off_A3;  // LDS plan (bytes), set by the launcher
 };
 bool layer_chain_supported(const LayerChainArgs& a, int cu_count);

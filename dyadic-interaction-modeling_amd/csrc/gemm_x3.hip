@@ -7,10 +7,10 @@
 // whose only rounding is the accumulation's -- like any f32 GEMM.  The six leading cross products (i + j <= 2) are kept; the three
 // dropped ones are below 2^-24 |a| |w| each, the size of ONE f32 rounding.  6/16 of the f32-MFMA time.
 //   * W: three bf16 planes [3][N][ldw], split once when the weights are packed (split_x3_kernel below);
-//   * A: f32 rows, fetched by LDS-DMA as they are and split in registers by the consumer wave that owns the rows (one wave per
-//     32-row block and ALL the tile's column blocks: a row block is split exactly once per block);
+//   * A: f32 rows, fetched by LDS-DMA as they are and split in registers by the consumer waves (one wave per 32 x 32 output block,
+//     fragment reads one k-tile ahead of the MFMAs);
 //   * tile 128 x BN (BN = 36 / 64 / 72 / 96 columns = 2 or 3 MFMA column blocks, the last one partly valid), BK = 32 (a 128-byte
-//     f32 row piece, the parity mode's k-tile), 4 consumer + 4 loader waves in the loop of gemm_ws72_kernel (4-slot LDS-DMA ring, counted
+//     f32 row piece, the parity mode's k-tile), 8 or 12 consumer + 4 loader waves in the loop of gemm_ws72_kernel (4-slot LDS-DMA ring, counted
 //     vmcnt per loader, one s_barrier per k-tile); more than half a CU's LDS, so a block owns its CU;
 //   * a W plane's k-tile row is 64 bytes: two W rows share a 128-byte LDS row (row n -> LDS row n / 2, half n % 2), chunk c of an LDS
 //     row sits at slot c ^ ((row >> 1) & 7) -- the lanes of a fragment read (rows 2r, 2r + 1 -> chunks c, c + 4) cover all 64 banks once;
@@ -32,6 +32,14 @@ template <int OFF> __device__ __forceinline__ void ds_read128(u32x4_t& v, unsign
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
+// counted LDS waits that NAME the fragments they make valid: the registers pass through the asm, so no use of them can be
+// scheduled (or hoisted by an IR pass) above the wait -- a bare s_waitcnt has no data dependence on what it waits for
+template <int N> __device__ __forceinline__ void wait_lgkm_for(u32x4_t& a, u32x4_t& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lgkm_for(u32x4_t& a, u32x4_t& b, u32x4_t& c) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "i"(N) : "memory");
+}
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + (((kc ^ (row >> 1)) & 7) << 4); }
 
 // x = p0 + p1 + p2 exactly (bf16 planes by truncation); 8 values -> three bf16x8 fragments
@@ -69,9 +77,9 @@ __device__ __forceinline__ float x3_act(int act, float x) {
     return x;
 }
 
-template <int NCB, int BN>
+template <int NCB, int BN, int STAGES = 4>
 struct X3 {
-    static constexpr int BM = 128, BK = 32, STAGES = 4, NCONS = 4;
+    static constexpr int BM = 128, BK = 32, NCONS = 4 * NCB, THREADS = (NCONS + 4) * 64;
     static constexpr int A_BYTES = BM * 128;           // f32 rows of 32 k
     static constexpr int P_BYTES = NCB * 16 * 128;     // one W plane: NCB * 32 rows of 64 B, two per LDS row
     static constexpr int SLOT_BYTES = A_BYTES + 3 * P_BYTES;
@@ -80,12 +88,11 @@ struct X3 {
     static constexpr int RING_BYTES = STAGES * SLOT_BYTES;
     static constexpr int SMEM_BYTES = RING_BYTES > 84 * 1024 ? RING_BYTES : 84 * 1024;   // a block owns its CU
     static_assert(WP * 8 <= NCB * 16 && BN <= NCB * 32 && RING_BYTES <= 160 * 1024 - 1024, "tile");
-    static_assert(2 + 3 * NCB <= 15, "lgkmcnt is a 4-bit counter");
 
     template <int LW>  // W pieces of this loader wave per k-tile
     static __device__ __forceinline__ void loader(const GemmArgs& a, int lw, int lane, int m0, int n0, int kt0, int nk, unsigned char* smem) {
         constexpr int LA = 4, LPT = LA + LW;
-        static_assert(2 * LPT < 56, "ring depth");
+        static_assert((STAGES - 2) * LPT < 56, "ring depth");
         const float* __restrict__ A = (const float*)a.A;
         const bf16* __restrict__ W3 = (const bf16*)a.w3;
         const float* gA[LA];
@@ -122,12 +129,13 @@ struct X3 {
         for (; issued < STAGES - 1 && issued < nk; ++issued) issue(issued, issued);
         int slot_next = issued % STAGES;
         for (int st = 0; st < nk; ++st) {
-            const int y = issued - (st + 1);  // k-tiles issued behind slot st: 0, 1 or 2
+            const int y = issued - (st + 1);  // k-tiles issued behind slot st: 0 .. STAGES - 2
             if (y <= 0) wait_vmcnt<0>();
             else if (y == 1) wait_vmcnt<LPT>();
-            else wait_vmcnt<2 * LPT>();
+            else if (y == 2 || STAGES < 5) wait_vmcnt<2 * LPT>();
+            else wait_vmcnt<3 * LPT>();
             __builtin_amdgcn_s_barrier();
-            if (issued < nk) {
+            if (issued < nk && !(a.tile_map & 1)) {   // tile_map: ablation bits of tools (DIMX_X3_ABL; results are then wrong)
                 issue(issued, slot_next);
                 ++issued;
                 slot_next = slot_next + 1 == STAGES ? 0 : slot_next + 1;
@@ -163,100 +171,115 @@ struct X3 {
             else loader<L3>(a, lw, lane, m0, n0, kt0, nk, smem);
             return;
         }
-        // ---------------- consumer wave w: rows [32 w, 32 w + 32) x all NCB column blocks
+        // ---------------- consumer wave w: row block w % 4 x column block w / 4 (NCB consumer waves per SIMD).
+        // Forms measured on the decoder's shapes (profiles/r06_x3_gemm.txt): one wave per row block and all column blocks, without and
+        // with the read-ahead below (ff1 32.6 / 33.8 us), this form without and with it (31.4 / 31.5 us): all within 7 % -- the loop is
+        // bound by the consumers (no LDS-DMA in the loop: same time), and of their time the skeleton (barrier + fragment reads) is
+        // 0.26 us per k-tile, split + MFMAs 0.5 us.
+        const int rb = wave & 3, cb = wave >> 2;
         const int half = lane >> 5, l31 = lane & 31;
         const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
         unsigned aoff[2][2], woff[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            aoff[ks][0] = lds0 + lds_off(wave * 32 + l31, ks * 4 + half * 2);
-            aoff[ks][1] = lds0 + lds_off(wave * 32 + l31, ks * 4 + half * 2 + 1);
-            woff[ks] = lds0 + A_BYTES + lds_off(l31 >> 1, (l31 & 1) * 4 + ks * 2 + half);   // column block j: + j * 16 LDS rows
+            aoff[ks][0] = lds0 + lds_off(rb * 32 + l31, ks * 4 + half * 2);
+            aoff[ks][1] = lds0 + lds_off(rb * 32 + l31, ks * 4 + half * 2 + 1);
+            woff[ks] = lds0 + A_BYTES + cb * 2048 + lds_off(l31 >> 1, (l31 & 1) * 4 + ks * 2 + half);   // column block cb: 16 LDS rows in
         }
-        f32x16_t acc[NCB];
+        f32x16_t acc;
 #pragma unroll
-        for (int j = 0; j < NCB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         // everything the epilogue needs is requested now (the consumers wait for the first tile anyway)
         const int n_lim = n0 + BN;   // N % BN == 0
-        const int row_base = m0 + wave * 32 + 4 * half;
+        const int row_base = m0 + rb * 32 + 4 * half;
         const int mrem = a.M - row_base;
         const int ldc = (int)a.seg[0].st, ldr = a.ldr, act = a.act;
-        float bias_v[NCB];
-        bool col_ok[NCB];
-        float* cptr[NCB];
-        const float* rptr[NCB];
-#pragma unroll
-        for (int j = 0; j < NCB; ++j) {
-            const int ncol = n0 + j * 32 + l31;
-            col_ok[j] = ncol < n_lim;
-            const int ncl = col_ok[j] ? ncol : n_lim - 1;
-            bias_v[j] = (a.bias && split == 0) ? a.bias[ncl] : 0.f;
-            cptr[j] = (float*)a.seg[0].ptr + (a.out_slabs ? (size_t)split * a.slab_stride : 0) + (size_t)row_base * ldc + ncl;
-            rptr[j] = a.residual ? a.residual + (size_t)row_base * ldr + ncl : nullptr;
-        }
+        const int ncol = n0 + cb * 32 + l31;
+        const bool col_ok = ncol < n_lim;
+        const int ncl = col_ok ? ncol : n_lim - 1;
+        const float bias_v = (a.bias && split == 0) ? a.bias[ncl] : 0.f;
+        float* cptr = (float*)a.seg[0].ptr + (a.out_slabs ? (size_t)split * a.slab_stride : 0) + (size_t)row_base * ldc + ncl;
+        const float* rptr = a.residual ? a.residual + (size_t)row_base * ldr + ncl : nullptr;
+        // The fragment reads of tile t + 1 are issued BEFORE tile t is computed (two register sets).  A consumer arrives at barrier
+        // t + 1 with tile t's fragments in registers, so the loaders may refill tile t's slot right behind that barrier -- the
+        // hand-off protocol of the loop is unchanged.
+        struct Frag {
+            u32x4_t a[2][2], w[2][3];
+        };
         unsigned boff = 0;
-        for (int st = 0; st < nk; ++st) {
-            __builtin_amdgcn_s_barrier();
-            u32x4_t fa[2][2], fw[2][NCB][3];
-            // A of both k-steps first (4 reads), then the W fragments of k-step 0 (3 NCB reads): LDS returns in order
+        auto read_tile = [&](Frag& f) {   // A of both k-steps, then the W fragments (3 planes x 2 k-steps)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                ds_read128<0>(fa[ks][0], aoff[ks][0] + boff);
-                ds_read128<0>(fa[ks][1], aoff[ks][1] + boff);
+                ds_read128<0>(f.a[ks][0], aoff[ks][0] + boff);
+                ds_read128<0>(f.a[ks][1], aoff[ks][1] + boff);
             }
 #pragma unroll
-            for (int j = 0; j < NCB; ++j)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) ds_read128<0>(fw[0][j][p], woff[0] + boff + (unsigned)(j * 2048 + p * P_BYTES));
-            wait_lgkm<2 + 3 * NCB>();   // k-step 0's A pair has landed (behind it: the other pair + the W reads)
-            u32x4_t a0[2], a1[2], a2[2];
-            x3_split8(fa[0][0], fa[0][1], a0[0], a1[0], a2[0]);   // VALU work while the W fragments land
-            wait_lgkm<0>();
-            __builtin_amdgcn_sched_barrier(0);
-            // k-step 1's W fragments land while k-step 0's MFMAs run; its A pair is split in their shadow
-#pragma unroll
-            for (int j = 0; j < NCB; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) ds_read128<0>(fw[1][j][p], woff[1] + boff + (unsigned)(j * 2048 + p * P_BYTES));
-            x3_split8(fa[1][0], fa[1][1], a0[1], a1[1], a2[1]);
+                for (int p = 0; p < 3; ++p) ds_read128<0>(f.w[ks][p], woff[ks] + boff + (unsigned)(p * P_BYTES));
+            boff = boff + SLOT_BYTES == STAGES * SLOT_BYTES ? 0u : boff + SLOT_BYTES;
+        };
+        auto landed = [&](Frag& f) {   // every fragment of the set passes through the wait: no use of them can move above it (a bare
+                                       // s_waitcnt has no data dependence on what it waits for: hipcc hoisted the first uses above it)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]), "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[0][2]),
+                           "+v"(f.w[1][0]), "+v"(f.w[1][1]), "+v"(f.w[1][2])
+                         :
+                         : "memory");
+        };
+        auto compute = [&](const Frag& f) {
+            if (a.tile_map & 2) return;   // ablation: fragments read, nothing computed
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if (ks == 1) {
-                    wait_lgkm<0>();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const bf16x8_t A0 = __builtin_bit_cast(bf16x8_t, a0[ks]), A1 = __builtin_bit_cast(bf16x8_t, a1[ks]),
-                               A2 = __builtin_bit_cast(bf16x8_t, a2[ks]);
+                u32x4_t p0, p1, p2;
+                x3_split8(f.a[ks][0], f.a[ks][1], p0, p1, p2);
+                const bf16x8_t A0 = __builtin_bit_cast(bf16x8_t, p0), A1 = __builtin_bit_cast(bf16x8_t, p1), A2 = __builtin_bit_cast(bf16x8_t, p2);
                 // fixed order, smallest terms first: a2 w0, a1 w1, a0 w2 (2^-16), a1 w0, a0 w1 (2^-8), a0 w0
-#define DIMX_X3_MMA(AP, WPL)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < NCB; ++j) acc[j] =                                                   \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(AP, __builtin_bit_cast(bf16x8_t, fw[ks][j][WPL]), acc[j], 0, 0, 0)
-                DIMX_X3_MMA(A2, 0);
-                DIMX_X3_MMA(A1, 1);
-                DIMX_X3_MMA(A0, 2);
+#define DIMX_X3_MMA(AP, WPL) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AP, __builtin_bit_cast(bf16x8_t, f.w[ks][WPL]), acc, 0, 0, 0)
+                if (!(a.tile_map & 4)) {   // DIMX_X3_ABL=4 (measurement only, NOT a parity mode): the three 2^-16 terms dropped =
+                                           // two bf16 planes per operand, 16 significand bits -- what does "half the MFMAs" cost in tokens?
+                    DIMX_X3_MMA(A2, 0);
+                    DIMX_X3_MMA(A1, 1);
+                    DIMX_X3_MMA(A0, 2);
+                }
                 DIMX_X3_MMA(A1, 0);
                 DIMX_X3_MMA(A0, 1);
                 DIMX_X3_MMA(A0, 0);
 #undef DIMX_X3_MMA
             }
-            boff = boff + SLOT_BYTES == STAGES * SLOT_BYTES ? 0u : boff + SLOT_BYTES;
+        };
+        Frag f0, f1;
+        __builtin_amdgcn_s_barrier();   // tile 0
+        read_tile(f0);
+        int st = 0;
+        for (; st + 1 < nk; st += 2) {
+            landed(f0);
+            __builtin_amdgcn_s_barrier();   // tile st + 1 (and: this wave holds tile st in registers)
+            read_tile(f1);
+            compute(f0);
+            landed(f1);
+            if (st + 2 < nk) {
+                __builtin_amdgcn_s_barrier();   // tile st + 2
+                read_tile(f0);
+            }
+            compute(f1);
+        }
+        if (st < nk) {
+            landed(f0);
+            compute(f0);
         }
         // ---------------- epilogue: bias, activation (exact), residual, plain row-major f32 destination or split-K slab
-#pragma unroll
-        for (int j = 0; j < NCB; ++j) {
-            if (!col_ok[j]) continue;
+        if (col_ok) {
             float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = x3_act(act, acc[j][r] + bias_v[j]);
-            if (rptr[j]) {
+            for (int r = 0; r < 16; ++r) v[r] = x3_act(act, acc[r] + bias_v);
+            if (rptr) {
                 float rv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int off = (r & 3) + 8 * (r >> 2);
                     off = off < mrem ? off : (mrem > 0 ? mrem - 1 : 0);
-                    rv[r] = rptr[j][(size_t)off * ldr];
+                    rv[r] = rptr[(size_t)off * ldr];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] += rv[r];
@@ -264,16 +287,16 @@ struct X3 {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int off = (r & 3) + 8 * (r >> 2);
-                if (off < mrem) cptr[j][(size_t)off * ldc] = v[r];
+                if (off < mrem) cptr[(size_t)off * ldc] = v[r];
             }
         }
     }
 };
 
-template <int NCB, int BN>
-__global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[X3<NCB, BN>::SMEM_BYTES];
-    X3<NCB, BN>::body(a, blockIdx.x, gridDim.x, smem);
+template <int NCB, int BN, int STAGES>
+__global__ __launch_bounds__((X3<NCB, BN, STAGES>::THREADS)) void gemm_x3_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[X3<NCB, BN, STAGES>::SMEM_BYTES];
+    X3<NCB, BN, STAGES>::body(a, blockIdx.x, gridDim.x, smem);
 }
 
 // W f32 -> three bf16 planes (truncation splits: p0 + p1 + p2 == w exactly)
@@ -341,11 +364,20 @@ int launch_gemm_x3(const GemmArgs& a0, hipStream_t s) {
     a.splitk = sp;
     if (a.out_slabs) a.residual = nullptr;
     const int blocks = ceil_div(a.M, 128) * (a.N / bn) * sp;
+    static const int abl = getenv("DIMX_X3_ABL") ? atoi(getenv("DIMX_X3_ABL")) : 0;       // tuning: 1 no DMA in the loop, 2 no compute, 4 three products only
+    static const int stages = getenv("DIMX_X3_STAGES") ? atoi(getenv("DIMX_X3_STAGES")) : 4; // tuning: ring depth of the two-column-block tiles (5 measured no faster)
+    a.tile_map = abl;
     switch (bn) {
-        case 96: hipLaunchKernelGGL((gemm_x3_kernel<3, 96>), dim3(blocks), dim3(512), 0, s, a); break;
-        case 72: hipLaunchKernelGGL((gemm_x3_kernel<3, 72>), dim3(blocks), dim3(512), 0, s, a); break;
-        case 64: hipLaunchKernelGGL((gemm_x3_kernel<2, 64>), dim3(blocks), dim3(512), 0, s, a); break;
-        default: hipLaunchKernelGGL((gemm_x3_kernel<2, 36>), dim3(blocks), dim3(512), 0, s, a); break;
+        case 96: hipLaunchKernelGGL((gemm_x3_kernel<3, 96, 4>), dim3(blocks), dim3(1024), 0, s, a); break;
+        case 72: hipLaunchKernelGGL((gemm_x3_kernel<3, 72, 4>), dim3(blocks), dim3(1024), 0, s, a); break;
+        case 64:
+            if (stages == 5) hipLaunchKernelGGL((gemm_x3_kernel<2, 64, 5>), dim3(blocks), dim3(768), 0, s, a);
+            else hipLaunchKernelGGL((gemm_x3_kernel<2, 64, 4>), dim3(blocks), dim3(768), 0, s, a);
+            break;
+        default:
+            if (stages == 5) hipLaunchKernelGGL((gemm_x3_kernel<2, 36, 5>), dim3(blocks), dim3(768), 0, s, a);
+            else hipLaunchKernelGGL((gemm_x3_kernel<2, 36, 4>), dim3(blocks), dim3(768), 0, s, a);
+            break;
     }
     DIMX_HIP(hipGetLastError());
     return DIMX_OK;

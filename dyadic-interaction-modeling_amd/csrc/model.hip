@@ -2340,24 +2340,43 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
         g.conv_C = K / 5;
     }
     gemm_set_plain_out(g, C, ldc);
-    if ((flags >> 4) & 1) {   /* the f32 parity mode's split-bf16 kernel (gemm_x3.hip): W split into its three planes here; synchronises */
-        DIMX_REQUIRE(in_dtype == DIMX_F32 && out_dtype == DIMX_F32 && ldw == K && K % 32 == 0, DIMX_ERR_ARG, "op_gemm(x3): f32, ldw == K, K %% 32 == 0");
-        const size_t n = (size_t)N * K;
-        void* planes = nullptr;
-        DIMX_HIP(hipMalloc(&planes, 3 * n * 2));
-        int rc = launch_split_x3((const float*)W, planes, n, (hipStream_t)stream);
-        g.w3 = planes;
-        g.w3_plane = (long)n;
-        if (rc == DIMX_OK && !gemm_use_x3(g)) {
-            set_error("op_gemm(x3): shape M=%d N=%d K=%d is not taken by the split-bf16 kernel", M, N, K);
-            rc = DIMX_ERR_ARG;
-        }
-        if (rc == DIMX_OK) rc = launch_gemm(g, (hipStream_t)stream);
-        (void)hipStreamSynchronize((hipStream_t)stream);
-        (void)hipFree(planes);
-        return rc;
-    }
     return launch_gemm(g, (hipStream_t)stream);
+}
+
+/* the f32 parity mode's split-bf16 decode GEMM alone (csrc/gemm_x3.hip): dimx_op_split_x3 makes the three bf16 planes of an f32 matrix
+ * (what the weight packing does once per Linear), dimx_op_gemm_x3 multiplies f32 activations with them */
+int dimx_op_split_x3(const float* w, void* planes, long n, void* stream) {
+    DIMX_REQUIRE(n > 0, DIMX_ERR_ARG, "op_split_x3: empty matrix");
+    return launch_split_x3(w, planes, (size_t)n, (hipStream_t)stream);
+}
+
+int dimx_op_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K, const float* bias, int act,
+                    const float* residual, int ldr, int flags, void* stream) {
+    GemmArgs g;
+    gemm_args_init(g);
+    g.in_dtype = DIMX_F32;
+    g.out_dtype = DIMX_F32;
+    g.A = A;
+    g.lda = lda;
+    g.W = planes;   /* the f32 matrix itself is not needed by this kernel */
+    g.w3 = planes;
+    g.w3_plane = (long)N * K;
+    g.ldw = K;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.bias = bias;
+    g.act = act;
+    g.residual = residual;
+    g.ldr = ldr;
+    g.allow_splitk = 1;
+    g.out_slabs = (flags >> 2) & 1;
+    g.slab_stride = (long)M * ldc;
+    g.force_splitk = (flags >> 16) & 0xff;
+    gemm_set_plain_out(g, C, ldc);
+    DIMX_REQUIRE(planes && gemm_use_x3(g), DIMX_ERR_ARG, "op_gemm_x3: M=%d N=%d K=%d is not a shape of the split-bf16 kernel (M <= 256, K %% 32 == 0, "
+                 "N a multiple of 36 / 64 / 72 / 96)", M, N, K);
+    return launch_gemm_x3(g, (hipStream_t)stream);
 }
 
 /* number of split-K slabs an out_slabs dimx_op_gemm call with these arguments writes (tests: the f32 kernels plan it themselves) */
@@ -2730,6 +2749,8 @@ int dimx_op_layer_chain(const float* qkv, int nslab, long slab_stride, void* sk,
     lc.step = nullptr;          // the counters' epoch is the call index; the self-attention reads its own step pointer (sa.step)
     lc.epoch_add = call_index;
     lc.prof = (unsigned long long*)prof;
+    static const int layer_abl = getenv("DIMX_LAYER_ABL") ? atoi(getenv("DIMX_LAYER_ABL")) : 0;   // tuning: results are wrong then
+    lc.abl = layer_abl;
     lc.sc_stride = ((T > n_keys ? T : n_keys) + 15) / 16 * 16;
     int cu = 0, dev = 0;
     DIMX_HIP(hipGetDevice(&dev));

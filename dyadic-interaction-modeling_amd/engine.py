@@ -275,18 +275,29 @@ def tile_weight(w_, bk):
     return w_.view(N // 8, 8, Kp // bk, bk).permute(0, 2, 1, 3).contiguous().view(N, Kp)
 
 
-def op_gemm_x3(a, w, bias=None, act=0, residual=None, slabs=False):
+def op_split_x3(w):
+    """f32 [..] -> the three bf16 planes [3, ..] whose sum is ``w`` exactly (csrc/gemm_x3.hip split_x3_kernel)."""
+    lib = L.load()
+    w_ = w.float().contiguous()
+    planes = torch.empty((3,) + tuple(w_.shape), dtype=torch.bfloat16, device=w.device)
+    L.check(lib.dimx_op_split_x3(L.ptr(w_), L.ptr(planes), w_.numel(), L.stream_ptr(w.device)), "dimx_op_split_x3")
+    return planes
+
+
+def op_gemm_x3(a, w, bias=None, act=0, residual=None, slabs=False, planes=None):
     """The f32 parity mode's split-bf16 decode GEMM (csrc/gemm_x3.hip): epilogue(a[M,K] @ w[N,K]^T), f32 in and out, M <= 256,
     K % 32 == 0.  ``slabs``: the split-K partial sums [splits, M, N] as the decode step's consumers get them (the kernel plans
-    the count from (N, K))."""
+    the count from (N, K)).  ``planes``: the pre-split weight (op_split_x3), as the model keeps it."""
     lib = L.load()
-    a_, w_ = a.float().contiguous(), w.float().contiguous()
-    (M, K), N = a_.shape, w_.shape[0]
-    flags = 16 | (5 if slabs else 0)
-    ns = lib.dimx_op_gemm_slabs(L.F32, M, N, K, flags) if slabs else 0
+    a_ = a.float().contiguous()
+    if planes is None:
+        planes = op_split_x3(w)
+    (M, K), N = a_.shape, planes.shape[1]
+    flags = 4 if slabs else 0
+    ns = lib.dimx_op_gemm_slabs(L.F32, M, N, K, 16 | 5) if slabs else 0
     out = torch.full((ns, M, N) if slabs else (M, N), float("nan"), dtype=torch.float32, device=a.device)
-    L.check(lib.dimx_op_gemm(L.F32, L.F32, L.ptr(a_), K, L.ptr(w_), K, L.ptr(out), N, M, N, K, L.ptr(bias), act, L.ptr(residual),
-                             residual.shape[1] if residual is not None else 0, 0, None, flags, L.stream_ptr(a.device)), "dimx_op_gemm(x3)")
+    L.check(lib.dimx_op_gemm_x3(L.ptr(a_), K, L.ptr(planes), L.ptr(out), N, M, N, K, L.ptr(bias), act, L.ptr(residual),
+                                residual.shape[1] if residual is not None else 0, flags, L.stream_ptr(a.device)), "dimx_op_gemm_x3")
     return out
 
 

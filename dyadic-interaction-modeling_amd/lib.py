@@ -92,6 +92,9 @@ SIGNATURES = {
     "dimx_chain_faults": (c_int, [c_void_p]),
     "dimx_debug_chain_fault": (c_int, [c_void_p, c_int]),
     "dimx_op_gemm_slabs": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "dimx_op_split_x3": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_void_p]),
+    "dimx_op_gemm_x3": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                c_void_p]),
     "dimx_op_gemm": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "dimx_op_gemm_headmajor": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,

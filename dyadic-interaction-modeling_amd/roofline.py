@@ -270,6 +270,38 @@ def decode_gemm(B, mode, device, iters=40):
             "algorithmic_flops_per_launch": flops, "avg_launch_us": sec * 1e6}
 
 
+def decode_gemm_x3(B, device, iters=60):
+    """Round 6: the f32 parity mode's decode GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip: three bf16 planes per operand, six
+    products, f32 accumulation = an f32 GEMM) -- the three chip-wide shapes of a decoder layer, launched as dimx_generate launches
+    them (pre-split weight planes, split-K slabs where the step uses them), rotating over four layers' weights.  `achieved` counts
+    the f32 GEMM's flops (2 M N K) against the f32 MFMA peak the mode would otherwise be bound by; `bf16_mfma_tflops` the six bf16
+    products actually issued against the bf16 peak."""
+    from . import lib as L
+    lib = L.load()
+    M = B
+    shapes = [("fused q/k/v", 2304, 1152, True, 0), ("ff1 + erf-GELU", 4608, 1152, False, 3), ("ff2", 1152, 4608, True, 0)]
+    out = []
+    for name, N, K, slabs, act in shapes:
+        a = torch.randn(M, K, device=device)
+        planes = [E.op_split_x3(torch.randn(N, K, device=device) / K ** 0.5) for _ in range(4)]
+        bias = torch.randn(N, device=device)
+        flags = 4 if slabs else 0
+        ns = lib.dimx_op_gemm_slabs(L.F32, M, N, K, 16 | 5) if slabs else 1
+        c = torch.empty(ns, M, N, device=device)
+
+        def run(i):
+            L.check(lib.dimx_op_gemm_x3(L.ptr(a), K, L.ptr(planes[i % 4]), L.ptr(c), N, M, N, K, None if slabs else L.ptr(bias), act, None, 0,
+                                        flags, L.stream_ptr(device)), "gemm_x3")
+        sec = _time_launches(run, 10, iters)
+        flops = 2.0 * M * N * K
+        out.append({"kernel": "gemm_x3_kernel M=%d N=%d K=%d (%s; f32 parity mode, %s)" % (M, N, K, name, "%d split-K slabs" % ns if slabs else "one pass over K"),
+                    "bound": "mfma", "achieved": flops / sec / 1e12, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                    "frac": flops / sec / 1e12 / MFMA_PEAK_TFLOPS["f32"], "traffic": None, "algorithmic_flops_per_launch": flops,
+                    "bf16_mfma_tflops": 6 * flops / sec / 1e12, "bf16_mfma_frac": 6 * flops / sec / 1e12 / MFMA_PEAK_TFLOPS["bf16"],
+                    "avg_launch_us": sec * 1e6})
+    return out
+
+
 def cross_kv_gemm(B, T, mode, device, iters=12):
     """The MFMA GEMM of the cross-attention bundle as dimx_encode_ctx launches it: the K/V projection of the speaker
     context, [B*T, 1152] x [N, 1152]^T into head-major [B,12,Tp,64] caches.  bf16: all four decoder layers in one launch
@@ -479,4 +511,6 @@ def dominant_kernel(eng, B, T, mode):
     first["others"] = [decode_self_attention(B, T, mode, dev), decode_layernorm(B, mode, dev)]
     if mode == "bf16":
         first["others"] += prefill_mlp_fused(B, T, dev)
+    elif B <= 256:
+        first["others"] += decode_gemm_x3(B, dev)
     return first

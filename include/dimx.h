@@ -303,11 +303,19 @@ int dimx_op_train_attention(int mfma, const float* q, const float* k, const floa
  * convolution with K = 5*C, W tap-major [N][5][C]; conv_lens optional [B] int32.
  * flags: bit 0 = allow split-K with f32 atomics (only taken when residual == C, i.e. in-place accumulation
  * onto the residual stream, small M); bit 1 = force the register-staged (non LDS-DMA) kernel; bit 2 = C is [splits][M, ldc] f32
- * split-K slabs (count: dimx_op_gemm_slabs); bit 4 (f32 only, M <= 256, ldw == K) = the parity mode's split-bf16 decode kernel
- * (csrc/gemm_x3.hip: W is split into three bf16 planes by the call, which then synchronises). */
+ * split-K slabs (count: dimx_op_gemm_slabs). */
 int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void* W, int ldw, void* C,
                  int ldc, int M, int N, int K, const float* bias, int act, const float* residual,
                  int ldr, int conv_T, const int32_t* conv_lens, int flags, void* stream);
+/* The f32 parity mode's decode GEMM alone (csrc/gemm_x3.hip; reference arithmetic: the fp32 Linear layers of the decoder,
+ * code/seq2seq_pretrain.py:413-418): an f32 number is the exact sum of three bf16 numbers, so C = A . W^T is computed on the bf16
+ * matrix cores from the three planes of each operand with f32 accumulation -- an f32 GEMM at 6/16 of the f32-MFMA cost.
+ * dimx_op_split_x3: w [n] f32 (device) -> planes [3][n] bf16 (device), plane0 + plane1 + plane2 == w exactly.
+ * dimx_op_gemm_x3: A [M, lda] f32, planes of W [N, K] (K % 32 == 0, N a multiple of 36 / 64 / 72 / 96, M <= 256), C [M, ldc] f32 or,
+ * with flags bit 2, the split-K slabs [dimx_op_gemm_slabs(.., flags | 16)][M, ldc]; bias / act / residual as in dimx_op_gemm. */
+int dimx_op_split_x3(const float* w, void* planes, long n, void* stream);
+int dimx_op_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K, const float* bias, int act,
+                    const float* residual, int ldr, int flags, void* stream);
 /* split-K slabs an out_slabs dimx_op_gemm call with these arguments writes (the f32 kernels plan the count from (N, K) themselves;
  * flags as in dimx_op_gemm: bit 0 allow split-K, bit 4 the split-bf16 kernel of the f32 parity mode, bits 16..23 a forced count) */
 int dimx_op_gemm_slabs(int in_dtype, int M, int N, int K, int flags);
