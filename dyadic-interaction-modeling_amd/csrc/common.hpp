@@ -362,7 +362,7 @@ struct DecodeAttnArgs {
     float scale;
 };
 int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s);
-// attention / GEMM co-residency probe (gemm.hip fused_probe_kernel; tools/fuse_probe.py)
+// attention / GEMM co-residency probe (gemm.hip fused_probe_kernel; tools/attic/fuse_probe.py)
 int launch_fused_probe(const GemmArgs& g, const DecodeAttnArgs& d, int which, unsigned* hw_id, hipStream_t s);
 
 int launch_vq_argmin(const float* z, int N, const float* Et /*[128][512]*/, const float* ee /*[512]*/,

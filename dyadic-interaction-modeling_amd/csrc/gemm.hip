@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // gemm_ws72_kernel (round 5): the loader/consumer decode GEMM on 64 x 72 tiles -- ONE block per CU, exactly.
-// Measured (tools/r05_gemm_blocks.py, profiles/r05_gemm_blocks.txt): the three chip-wide decode GEMMs launch 288 blocks of
+// Measured (tools/attic/r05_gemm_blocks.py, profiles/r05_gemm_blocks.txt): the three chip-wide decode GEMMs launch 288 blocks of
 // 64 x 64 tiles on 256 CUs; a CU that hosts two blocks pulls twice the operand bytes through its LDS-DMA path (55-67 GB/s
 // per CU whatever the block count) and the launch lasts as long as those 32 CUs: the same kernel at a column count that gives
 // 256 blocks runs 7.7 instead of 11.1 us (K = 4608, 4 slabs), 9.2 instead of 10.8 (ff1), 6.3 instead of 6.6 (qkv).  No
@@ -1289,7 +1289,7 @@ struct Ws72 {
         // Everything the epilogue needs is fetched NOW -- the consumers wait ~1.5 us for the first tile anyway: the lane's bias and
         // (deferred LayerNorm) column sum (as dependent loads behind the main loop they cost 0.5 us per launch), and the kernel
         // arguments of the store (destination, row stride, slab offset, activation: behind the loop their scalar loads were another
-        // 0.4 us, tools/r05_gemm_stamps.py).  The kernel only takes plain row-major destinations (gemm_use_ws72), so the epilogue is
+        // 0.4 us, tools/attic/r05_gemm_stamps.py).  The kernel only takes plain row-major destinations (gemm_use_ws72), so the epilogue is
         // 16 stores per lane and nothing else.
         const int n_lim = n0 + BN < a.N ? n0 + BN : a.N;
         const int ncol = n0 + wn * 32 + l31;
@@ -1446,7 +1446,7 @@ template <typename OutT> static int launch_ws72(const GemmArgs& a, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention / GEMM co-residency probe (tools/fuse_probe.py; VERDICT round 2, item 2: "hide the decode step's GEMM chain
+// Attention / GEMM co-residency probe (tools/attic/fuse_probe.py; VERDICT round 2, item 2: "hide the decode step's GEMM chain
 // under its attention: horizontal fusion over two half-batches").  Streams do not overlap the decode kernels and CU masks
 // starve the HBM stream (round 2); what is left to try is ONE launch whose blocks take either role: blocks of role 0 run the
 // loader/consumer decode GEMM (gemm_ws_body, 8 waves, 64 KiB of LDS), blocks of role 1 the one-query decode attention

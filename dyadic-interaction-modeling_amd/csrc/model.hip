@@ -1243,7 +1243,7 @@ int legacy_encode_ctx(dimx_handle h, const float* v_speaker, const uint8_t* mask
 // The prefill-sized stages of a forward are independent per clip, and their kernels leave CUs idle at the end of every launch (the
 // fused feed-forward kernel runs 600 blocks of 128 rows on 256 CUs: the third round is a third full; 128 x 128 and 256 x 256 GEMM
 // tiles end the same way).  As G clip groups on G streams the tails of one group's kernels are filled by another group's blocks:
-// 15.8 -> 14.2 ms for the three stages at 256 x 300 with G = 4 (tools/r05_prefill_streams.py, profiles/r05_prefill_groups.txt).
+// 15.8 -> 14.2 ms for the three stages at 256 x 300 with G = 4 (tools/attic/r05_prefill_streams.py, profiles/r05_prefill_groups.txt).
 // Group 0 runs on the caller's stream, the others on the handle's side streams between a fork and a join event; every group
 // has its own scratch (the same arena, planned group by group).  Both numeric modes: a clip's results do not depend on the batch it is
 // computed in (the f32 mode by contract -- test_c3_batch_and_shard_invariance compares the grouped whole batch with its shards bit for bit).

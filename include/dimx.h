@@ -347,7 +347,7 @@ int dimx_op_attention_rowv(const void* q, const void* k, const void* v, void* ou
 int dimx_op_decode_attn(int dtype, const void* q, const void* kcache, const void* vcache, void* out, int B, int H,
                         int Tmax, int n_keys, float scale, const uint8_t* kmask, int nsplit, int q_is_f32,
                         void* stream);
-/* Tuning probe (tools/fuse_probe.py): ONE launch whose blocks run either the decode GEMM C[M,N] = act(A[M,K] . W[N,K]^T + bias)
+/* Tuning probe (tools/attic/fuse_probe.py): ONE launch whose blocks run either the decode GEMM C[M,N] = act(A[M,K] . W[N,K]^T + bias)
  * (bf16 operands, the loader/consumer kernel of the decode step) or the cross-attention form of the decode attention over
  * [B,H,Tmax,64] bf16 caches (q f32 [B,H*64]), so that both kinds are co-resident on every CU.  which: 0 both, 1 GEMM blocks only,
  * 2 attention blocks only.  hw_id (optional, [grid] uint32): per block HW_REG_HW_ID[23:0] | XCC id << 24 | role << 28. */

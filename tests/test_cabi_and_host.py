@@ -165,3 +165,17 @@ def test_train_epoch_never_changes_backend_behind_the_caller():
     logs = []
     out = x_engine_pt.train_epoch(f, [], torch.optim.SGD(f.parameters(), lr=0.1), torch.device("cpu"), log=logs.append)
     assert out != out and any("not a dimx model" in ln for ln in logs)    # empty loader: nan mean, and the route was announced
+
+
+def test_split_count_of_the_parity_modes_decode_gemms_depends_on_the_projection_only():
+    """a rank's shard of a batch must reproduce the rows of the whole batch bit for bit in the f32 parity mode, and the
+    number of split-K slabs decides the summation order -- so it may depend on (N, K) only, never on the rows M (host logic of
+    csrc/gemm.hip gemm_plan_splits / csrc/gemm_x3.hip gemm_x3_plan, no GPU needed); at most 8 slabs (the consumers' limit)."""
+    from dimx import lib as L
+    lib = L.load()
+    F32 = L.F32
+    for N, K in ((2304, 1152), (1152, 768), (768, 1152), (1152, 4608), (512, 1152), (1536, 512), (512, 2048)):
+        for flags in (5, 16 | 5):                     # exact-f32 MFMA kernel, split-bf16 kernel
+            counts = {lib.dimx_op_gemm_slabs(F32, M, N, K, flags) for M in (1, 4, 32, 64, 128, 200, 256)}
+            assert len(counts) == 1 and 1 <= next(iter(counts)) <= 8, (N, K, flags, counts)
+        assert lib.dimx_op_gemm_slabs(F32, 256, N, K, 16 | 5 | (3 << 16)) == 3        # a forced count is honoured

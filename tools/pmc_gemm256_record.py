@@ -1,4 +1,4 @@
-"""Fold the MFMA / TCC counter passes over the fused cross-attention K/V projection (tools/r03_profiles.sh step 4) into
+"""Fold the MFMA / TCC counter passes over the fused cross-attention K/V projection (tools/attic/r03_profiles.sh step 4) into
 profiles/pmc_gemm256_<kernel-source-hash>.json, the file dimx.roofline.cross_kv_gemm reads `pmc_mfma_busy_pct` from.
     python tools/pmc_gemm256_record.py <pmc_summary text> <line file of the same run> <commit>"""
 import json

@@ -61,9 +61,9 @@ DIMX_NO_LAYER_CHAIN=1 DIMX_NO_WS72=1 python bench.py --steps 5 --warmup 2 --no-c
 DIMX_LAYER_PROF=1 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity-mode --no-train-step 2>&1 | grep -A13 "layer-kernel stamps" > $O/r05_layer_kernel_stamps_last_step.txt
 python bench.py --steps 2 --warmup 1 --samples 10 --no-cpu-baseline --no-parity-mode --no-roofline --no-train-step > $O/r05_bench_samples10.json 2>/dev/null
 # 6. decode GEMM shapes per kernel (64 x 64 / 288 blocks vs 64 x 72 / 256 blocks), in-kernel stamps
-rocprofv3 --kernel-trace --output-format csv -d $O/ktg -o g -- python tools/r05_gemm_blocks.py $O/plan.json ws72 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/ktg -o g -- python tools/attic/r05_gemm_blocks.py $O/plan.json ws72 > /dev/null 2>&1
 python tools/bench_gemm.py --parse $O/ktg $O/plan.json > $O/r05_decode_gemm_kernels.txt 2>&1
-for args in "34 1152 4608 4 0" "72 1152 4608 4 0" "34 4608 1152 0 3" "72 4608 1152 0 3" "34 2304 1152 2 0" "72 2304 1152 2 0"; do python tools/r05_gemm_stamps.py $args 2>&1 | grep -v amdgpu.ids; done > $O/r05_decode_gemm_stamps.txt
+for args in "34 1152 4608 4 0" "72 1152 4608 4 0" "34 4608 1152 0 3" "72 4608 1152 0 3" "34 2304 1152 2 0" "72 2304 1152 2 0"; do python tools/attic/r05_gemm_stamps.py $args 2>&1 | grep -v amdgpu.ids; done > $O/r05_decode_gemm_stamps.txt
 # 7. training step (unchanged kernels; the line's train_step object) and the N = 1 leg of the scale check
 python tools/bench_train.py 16 300 5 all 2>&1 | grep -v amdgpu > $O/r05_train_step.txt
 bash tools/scale_check.sh 1 > $O/r05_scale_check_n1.txt 2>&1
