@@ -267,7 +267,9 @@ struct GemmArgs {
                        // gemm_ws_kernel only.  Measured: -0.2 us per decode GEMM, nothing end to end (1467 vs 1467 clips/s) -- the
                        // model keeps row-major weights; the switch stays for tools/gemm_ab.py and the kernel test.
     const void* w3;    // round 6, f32 parity mode: W as three bf16 planes [3][N][ldw] whose sum is W exactly (split_x3); with it a
-    long w3_plane;     // decode-sized f32 GEMM runs on the bf16 matrix cores, f32-equivalent (gemm_x3_kernel).  Elements between planes.
+    long w3_plane;     // GEMM of the DECODE STEP (x3_decode) runs on the bf16 matrix cores, f32-equivalent (gemm_x3_kernel).  Elements between planes.
+    int x3_decode;     // set by the decode step (dimx_generate) and by dimx_op_gemm_x3 only: the kernel choice must not depend on M -- a
+                       // rank's shard of a batch reproduces the rows of the whole batch bit for bit whatever the batch size
     int tile_map;      // set by the launcher (prefill): 1 = every XCD works on one half of the N tiles of a quarter of the
                        // M tiles, so that its share of W (N/2 x K) stays L2-resident while the A panels stream through
     int vt_pack4;      // set by the launcher: transposed (time-contiguous) segments take 4 packed rows per store

@@ -346,10 +346,10 @@ bool gemm_x3_plan(const GemmArgs& a, int* bn_out, int* sp_out) {
     return true;
 }
 
-// the kernel takes: f32 operands with the three W planes at hand, a decode-sized M, a plain row-major f32 destination
+// the kernel takes: the decode step's GEMMs (whatever their M) with f32 operands, the three W planes at hand and a plain row-major f32 destination
 bool gemm_use_x3(const GemmArgs& a) {
     static const bool off = getenv("DIMX_NO_X3") != nullptr;
-    if (off || !a.w3 || a.in_dtype != DIMX_F32 || a.out_dtype != DIMX_F32 || a.M > 256) return false;
+    if (off || !a.w3 || !a.x3_decode || a.in_dtype != DIMX_F32 || a.out_dtype != DIMX_F32) return false;   // any M: see GemmArgs.x3_decode
     if (a.conv_T != 0 || a.kloop != 0 || a.K != a.ldw || a.K % 32 != 0 || a.force_simple || a.w_tiled || a.ln_stats || a.cfg != 0) return false;
     if (a.nseg != 1 || a.seg[0].sd != 1 || a.seg[0].sh != 0 || a.seg[0].sb != a.seg[0].st * (long)a.rowT || a.rowadd_mode != 0) return false;
     if (((uintptr_t)a.w3 % 16) != 0 || (a.w3_plane * 2) % 16 != 0) return false;

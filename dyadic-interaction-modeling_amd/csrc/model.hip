@@ -1858,6 +1858,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
     auto slab_gemm = [&](const void* A, int lda, const Linear& L, float* out, long stride, int* nsl) -> int {
         GemmArgs g;
         gemm_lin(h, A, lda, L, B, g);
+        g.x3_decode = 1;   // f32 parity mode: the split-bf16 kernel, whatever B is
         g.out_dtype = DIMX_F32;
         g.out_slabs = 1;
         // round 4: the f32 parity mode splits K too.  Slabs are plain stores added in slab order by the consumer -- deterministic,
@@ -2035,6 +2036,7 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         }
     feed_forward:
         gemm_lin(h, s.y, DD, defer ? h->dec.ff[l].f1_ln : h->dec.ff[l].f1, B, g);
+        g.x3_decode = 1;
         if (defer) {
             g.ln_stats = h->chain_stats_dev;
             g.ln_err = h->chain_err_dev;
@@ -2361,6 +2363,7 @@ int dimx_op_gemm_x3(const float* A, int lda, const void* planes, float* C, int l
     g.W = planes;   /* the f32 matrix itself is not needed by this kernel */
     g.w3 = planes;
     g.w3_plane = (long)N * K;
+    g.x3_decode = 1;
     g.ldw = K;
     g.M = M;
     g.N = N;
@@ -2374,7 +2377,7 @@ int dimx_op_gemm_x3(const float* A, int lda, const void* planes, float* C, int l
     g.slab_stride = (long)M * ldc;
     g.force_splitk = (flags >> 16) & 0xff;
     gemm_set_plain_out(g, C, ldc);
-    DIMX_REQUIRE(planes && gemm_use_x3(g), DIMX_ERR_ARG, "op_gemm_x3: M=%d N=%d K=%d is not a shape of the split-bf16 kernel (M <= 256, K %% 32 == 0, "
+    DIMX_REQUIRE(planes && gemm_use_x3(g), DIMX_ERR_ARG, "op_gemm_x3: M=%d N=%d K=%d is not a shape of the split-bf16 kernel (K %% 32 == 0, "
                  "N a multiple of 36 / 64 / 72 / 96)", M, N, K);
     return launch_gemm_x3(g, (hipStream_t)stream);
 }
@@ -2396,6 +2399,7 @@ int dimx_op_gemm_slabs(int in_dtype, int M, int N, int K, int flags) {
     if ((flags >> 4) & 1) {
         g.w3 = (const void*)16;
         g.w3_plane = (long)N * K;
+        g.x3_decode = 1;
     }
     float dummy;
     gemm_set_plain_out(g, &dummy, N);

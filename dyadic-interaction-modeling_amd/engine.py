@@ -285,7 +285,7 @@ def op_split_x3(w):
 
 
 def op_gemm_x3(a, w, bias=None, act=0, residual=None, slabs=False, planes=None):
-    """The f32 parity mode's split-bf16 decode GEMM (csrc/gemm_x3.hip): epilogue(a[M,K] @ w[N,K]^T), f32 in and out, M <= 256,
+    """The f32 parity mode's split-bf16 decode GEMM (csrc/gemm_x3.hip): epilogue(a[M,K] @ w[N,K]^T), f32 in and out,
     K % 32 == 0.  ``slabs``: the split-K partial sums [splits, M, N] as the decode step's consumers get them (the kernel plans
     the count from (N, K)).  ``planes``: the pre-split weight (op_split_x3), as the model keeps it."""
     lib = L.load()

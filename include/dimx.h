@@ -311,7 +311,7 @@ int dimx_op_gemm(int in_dtype, int out_dtype, const void* A, int lda, const void
  * code/seq2seq_pretrain.py:413-418): an f32 number is the exact sum of three bf16 numbers, so C = A . W^T is computed on the bf16
  * matrix cores from the three planes of each operand with f32 accumulation -- an f32 GEMM at 6/16 of the f32-MFMA cost.
  * dimx_op_split_x3: w [n] f32 (device) -> planes [3][n] bf16 (device), plane0 + plane1 + plane2 == w exactly.
- * dimx_op_gemm_x3: A [M, lda] f32, planes of W [N, K] (K % 32 == 0, N a multiple of 36 / 64 / 72 / 96, M <= 256), C [M, ldc] f32 or,
+ * dimx_op_gemm_x3: A [M, lda] f32, planes of W [N, K] (K % 32 == 0, N a multiple of 36 / 64 / 72 / 96; planned for M = 256, any M runs), C [M, ldc] f32 or,
  * with flags bit 2, the split-K slabs [dimx_op_gemm_slabs(.., flags | 16)][M, ldc]; bias / act / residual as in dimx_op_gemm. */
 int dimx_op_split_x3(const float* w, void* planes, long n, void* stream);
 int dimx_op_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K, const float* bias, int act,

@@ -74,7 +74,8 @@ def test_x3_gemm_is_an_f32_gemm(dev, M, N, K, act, use_bias, use_res):
     assert e_x3 < 4 * e_f32 + 2e-8, (e_x3, e_f32)              # and no worse than the f32 MFMA kernel
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 2304, 1152), (256, 1152, 4608), (256, 1152, 768), (130, 512, 1152), (256, 768, 1152)])
+@pytest.mark.parametrize("M,N,K", [(256, 2304, 1152), (256, 1152, 4608), (256, 1152, 768), (130, 512, 1152), (256, 768, 1152),
+                                   (600, 1152, 768)])   # more rows than the design point: the decode step of a batch > 256 takes the same kernel
 def test_x3_slabs_sum_to_the_product_and_rows_do_not_depend_on_the_batch(dev, M, N, K):
     from dimx import engine as E
     a, w = _rand((M, K), dev, 7 + N), _rand((N, K), dev, 8 + K, K ** -0.5)
