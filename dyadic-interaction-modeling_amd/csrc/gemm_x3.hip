@@ -232,7 +232,13 @@ struct X3 {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4_t p0, p1, p2;
-                x3_split8(f.a[ks][0], f.a[ks][1], p0, p1, p2);
+                if (a.tile_map & 8) {   // ablation: no operand split (the raw fragment registers stand in for the planes; wrong results)
+                    p0 = f.a[ks][0];
+                    p1 = f.a[ks][1];
+                    p2 = f.a[ks][0];
+                } else {
+                    x3_split8(f.a[ks][0], f.a[ks][1], p0, p1, p2);
+                }
                 const bf16x8_t A0 = __builtin_bit_cast(bf16x8_t, p0), A1 = __builtin_bit_cast(bf16x8_t, p1), A2 = __builtin_bit_cast(bf16x8_t, p2);
                 // fixed order, smallest terms first: a2 w0, a1 w1, a0 w2 (2^-16), a1 w0, a0 w1 (2^-8), a0 w0
 #define DIMX_X3_MMA(AP, WPL) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AP, __builtin_bit_cast(bf16x8_t, f.w[ks][WPL]), acc, 0, 0, 0)
@@ -364,7 +370,7 @@ int launch_gemm_x3(const GemmArgs& a0, hipStream_t s) {
     a.splitk = sp;
     if (a.out_slabs) a.residual = nullptr;
     const int blocks = ceil_div(a.M, 128) * (a.N / bn) * sp;
-    static const int abl = getenv("DIMX_X3_ABL") ? atoi(getenv("DIMX_X3_ABL")) : 0;       // tuning: 1 no DMA in the loop, 2 no compute, 4 three products only
+    static const int abl = getenv("DIMX_X3_ABL") ? atoi(getenv("DIMX_X3_ABL")) : 0;       // tuning: 1 no DMA in the loop, 2 no compute, 4 three products only, 8 no operand split
     static const int stages = getenv("DIMX_X3_STAGES") ? atoi(getenv("DIMX_X3_STAGES")) : 4; // tuning: ring depth of the two-column-block tiles (5 measured no faster)
     a.tile_map = abl;
     switch (bn) {

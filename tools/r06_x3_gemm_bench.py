@@ -18,18 +18,20 @@ M = 256
 
 
 def run(name, N, K, slabs, x3, iters=200):
+    from dimx import engine as E
     a = torch.randn(M, K, device=dev)
     ws = [torch.randn(N, K, device=dev) / K ** 0.5 for _ in range(4)]
-    flags = (16 if x3 else 0) | (5 if slabs else 0)
-    ns = lib.dimx_op_gemm_slabs(L.F32, M, N, K, flags) if slabs else 1
+    planes = [E.op_split_x3(w) for w in ws] if x3 else None
+    ns = lib.dimx_op_gemm_slabs(L.F32, M, N, K, (16 if x3 else 0) | 5) if slabs else 1
     out = torch.empty(ns, M, N, device=dev)
     bias = torch.zeros(N, device=dev)
-    # the op entry splits W per call for x3 (and synchronises): time the kernel alone through pre-split planes is not exposed, so the
-    # model path is timed instead: a GemmArgs with w3 needs the handle; here the op's own launch is timed with events around the call
-    # minus the split -- simpler: measure via rocprofv3 kernel trace (tools/runs/r06_x3_abl.sh)
     for i in range(iters):
-        L.check(lib.dimx_op_gemm(L.F32, L.F32, L.ptr(a), K, L.ptr(ws[i % 4]), K, L.ptr(out), N, M, N, K, None if slabs else L.ptr(bias),
-                                 0 if slabs else 3, None, 0, 0, None, flags, L.stream_ptr(dev)), "gemm")
+        if x3:
+            L.check(lib.dimx_op_gemm_x3(L.ptr(a), K, L.ptr(planes[i % 4]), L.ptr(out), N, M, N, K, None if slabs else L.ptr(bias),
+                                        0 if slabs else 3, None, 0, 4 if slabs else 0, L.stream_ptr(dev)), "gemm_x3")
+        else:
+            L.check(lib.dimx_op_gemm(L.F32, L.F32, L.ptr(a), K, L.ptr(ws[i % 4]), K, L.ptr(out), N, M, N, K, None if slabs else L.ptr(bias),
+                                     0 if slabs else 3, None, 0, 0, None, 5 if slabs else 0, L.stream_ptr(dev)), "gemm")
     torch.cuda.synchronize()
 
 
