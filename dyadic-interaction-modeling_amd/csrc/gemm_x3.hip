@@ -31,15 +31,6 @@ template <int OFF> __device__ __forceinline__ void ds_read128(u32x4_t& v, unsign
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
-// counted LDS waits that NAME the fragments they make valid: the registers pass through the asm, so no use of them can be
-// scheduled (or hoisted by an IR pass) above the wait -- a bare s_waitcnt has no data dependence on what it waits for
-template <int N> __device__ __forceinline__ void wait_lgkm_for(u32x4_t& a, u32x4_t& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_lgkm_for(u32x4_t& a, u32x4_t& b, u32x4_t& c) {
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "i"(N) : "memory");
-}
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + (((kc ^ (row >> 1)) & 7) << 4); }
 
 // x = p0 + p1 + p2 exactly (bf16 planes by truncation); 8 values -> three bf16x8 fragments

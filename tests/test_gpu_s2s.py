@@ -327,6 +327,18 @@ def test_optional_bias_tensors_of_other_xtransformers_releases(full_sd):
     e.load_state_dict(full_sd)                      # names the weights, not the biases: they go
     x2, lg2, tok2 = run(e)
     assert torch.equal(x2, x0) and torch.equal(lg2, lg0) and torch.equal(tok2, tok0)
+    # round 6: a checkpoint loaded in pieces gives the same result in ANY order -- dimx_load_weights never drops a
+    # tensor, only dimx_begin_checkpoint (a new checkpoint) forgets the optional ones.  Biases first, weights afterwards:
+    opt = {k: v for k, v in sd.items() if k.endswith("project_in.bias") or k.endswith("to_logits.bias")}
+    rest = {k: v for k, v in sd.items() if k not in opt}
+    e.load_state_dict(opt, new_checkpoint=True)          # begins the checkpoint with the optional tensors only
+    e.load_state_dict(rest, new_checkpoint=False)        # ... the weights arrive later and name no bias
+    x3, lg3, tok3 = run(e)
+    assert torch.equal(x3, x1) and torch.equal(lg3, lg1) and torch.equal(tok3, tok1)
+    e.load_state_dict(rest, new_checkpoint=False)        # the same weights again: still nothing is dropped
+    assert torch.equal(run(e)[1], lg1)
+    e.load_state_dict(full_sd)                           # a NEW checkpoint without the tensors: gone
+    assert torch.equal(run(e)[1], lg0)
     e.close()
 
     # bf16 decode step: the logits of generate() move by the bias (the rest of the step is the chain path it always was)
