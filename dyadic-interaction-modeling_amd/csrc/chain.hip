@@ -683,7 +683,8 @@ __global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerCha
         issue_panel_nw<AUX_PLAIN, 1>((const bf16*)a.g_so.W, a.g_so.ldw, n0, n0 + a.g_so.cols - 1, a.g_so.rows_pad, a.g_so.nkt, base + a.off_W1, 0,
                                      lane);
     } else if (has_clip) {
-        decode_attn_body<bf16, true, true, 1, kAttnWaves>(a.sa, clip, sc, a.sc_stride, nullptr, nullptr, nullptr);
+        const int aclip = (a.perm && nrows == kGroupRows) ? row0 + ((li + wave) & (kGroupRows - 1)) : clip;
+        decode_attn_body<bf16, true, true, 1, kAttnWaves>(a.sa, aclip, sc, a.sc_stride, nullptr, nullptr, nullptr);
     }
     LAYER_STAMP(1);
     target += kGroupCUs;
@@ -775,7 +776,8 @@ __global__ __launch_bounds__(kLayerThreads) void xcd_layer_kernel(const LayerCha
         issue_panel_nw<AUX_PLAIN, 1>((const bf16*)a.g_co.W, a.g_co.ldw, n0, n0 + a.g_co.cols - 1, a.g_co.rows_pad, a.g_co.nkt, base + a.off_W3, 0,
                                      lane);
     } else if (has_clip) {
-        decode_attn_body<bf16, false, true, 1, kAttnWaves, true>(a.ca, clip, sc, a.sc_stride, nullptr, nullptr, nullptr);
+        const int aclip = (a.perm && nrows == kGroupRows) ? row0 + ((li + wave) & (kGroupRows - 1)) : clip;
+        decode_attn_body<bf16, false, true, 1, kAttnWaves, true>(a.ca, aclip, sc, a.sc_stride, nullptr, nullptr, nullptr);
     }
     LAYER_STAMP(9);
     target += kGroupCUs;

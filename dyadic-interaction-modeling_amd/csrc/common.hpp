@@ -438,6 +438,8 @@ struct LayerChainArgs {
     int fault;
     unsigned long long* prof;       // tuning only: [256][16] phase stamps
     int sc_stride;                  // floats per (clip, head) score row in LDS
+    int perm;                       // round 6 experiment (DIMX_LAYER_PERM=1): wave w of CU slot i streams head w of clip (i + w) % 32 instead of
+                                    // clip i -- a static spread of every clip's 12 heads over 12 CUs of its XCD (full groups only)
     int abl;                        // tuning only (DIMX_LAYER_ABL, dimx_op_layer_chain; results are then WRONG): bit 0 = the three weight
                                     // slices are not fetched (round 6: what do the 8 x replicated slices cost the launch?)
     int off_base, off_A1, off_W1, off_A2, off_W2, off_W3, off_A3;  // LDS plan (bytes), set by the launcher

@@ -1950,6 +1950,8 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         lc.fault = h->chain_fault_inject > 0 ? 1 : 0;
         lc.sc_stride = (T + 15) / 16 * 16;
         lc.prof = h->layer_prof_dev ? h->layer_prof_dev + (size_t)l * 256 * 16 : nullptr;
+        static const int layer_perm = getenv("DIMX_LAYER_PERM") ? atoi(getenv("DIMX_LAYER_PERM")) : 0;
+        lc.perm = layer_perm;
         return true;
     };
     int pending = 0;  // slabs of the previous residual projection not yet folded into x
@@ -2755,6 +2757,8 @@ int dimx_op_layer_chain(const float* qkv, int nslab, long slab_stride, void* sk,
     lc.prof = (unsigned long long*)prof;
     static const int layer_abl = getenv("DIMX_LAYER_ABL") ? atoi(getenv("DIMX_LAYER_ABL")) : 0;   // tuning: results are wrong then
     lc.abl = layer_abl;
+    static const int layer_perm_op = getenv("DIMX_LAYER_PERM") ? atoi(getenv("DIMX_LAYER_PERM")) : 0;
+    lc.perm = layer_perm_op;
     lc.sc_stride = ((T > n_keys ? T : n_keys) + 15) / 16 * 16;
     int cu = 0, dev = 0;
     DIMX_HIP(hipGetDevice(&dev));
