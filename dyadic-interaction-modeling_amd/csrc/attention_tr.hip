@@ -470,6 +470,16 @@ __global__ __launch_bounds__(256, kRing == 2 ? 3 : 2) void attn_tr_kernel(const 
 
 }  // namespace
 
+int launch_pack_key_words(const uint8_t* kmask, int kmask_ld, const int32_t* lens, int B, int Lk, unsigned long long* words, size_t cap,
+                          hipStream_t s) {
+    const int nwords = ceil_div(Lk, 64);
+    const size_t need = (size_t)B * nwords;
+    DIMX_REQUIRE(kmask && words && cap >= need, DIMX_ERR_ARG, "pack_key_words: %zu words needed, %zu given", need, cap);
+    hipLaunchKernelGGL(pack_key_words_kernel, dim3(ceil_div((int)need * 64, 256)), dim3(256), 0, s, kmask, kmask_ld, lens, B, Lk, nwords, words);
+    DIMX_HIP(hipGetLastError());
+    return DIMX_OK;
+}
+
 // bf16, D in {48, 64}, q / k / v row-major with 16-byte aligned rows.  Returns DIMX_OK after launching.
 int launch_attention_tr(const AttnArgs& a_in, hipStream_t s) {
     static const int dbg = getenv("DIMX_ATTN_DBG") ? atoi(getenv("DIMX_ATTN_DBG")) : 0;   // ablations (tools/bench_attn.py)
@@ -498,8 +508,9 @@ int launch_attention_tr(const AttnArgs& a_in, hipStream_t s) {
         const size_t need = (size_t)a.B * nwords;
         DIMX_REQUIRE(a.kwords && a.kwords_cap >= need, DIMX_ERR_ARG,
                      "attention_tr: a key mask needs %zu words of caller scratch (AttnArgs.kwords), got %zu", need, a.kwords ? a.kwords_cap : (size_t)0);
-        hipLaunchKernelGGL(pack_key_words_kernel, dim3(ceil_div((int)need * 64, 256)), dim3(256), 0, s, a.kmask, a.kmask_ld, a.lens, a.B, a.Lk,
-                           nwords, a.kwords);
+        if (!a.kwords_ready)
+            hipLaunchKernelGGL(pack_key_words_kernel, dim3(ceil_div((int)need * 64, 256)), dim3(256), 0, s, a.kmask, a.kmask_ld, a.lens, a.B, a.Lk,
+                               nwords, a.kwords);
         kwords = a.kwords;
     }
     // persistent blocks, 2 per CU (80 KiB of LDS each): each walks (clip, head) pairs g, g + grid, ...

@@ -326,7 +326,12 @@ struct AttnArgs {
     // nothing is allocated inside a launch or a stream capture -- ADVICE round 4)
     unsigned long long* kwords;
     size_t kwords_cap;     // in words
+    int kwords_ready;      // the words in `kwords` are already packed for this kmask (launch_pack_key_words): no pack launch -- the decode
+                           // loop packs its context mask once per generation, not once per step and layer
 };
+// key validity words of attention_tr.hip: word[b][t] bit j <-> key 64 t + j of clip b is a key; words [B][ceil(Lk / 64)]
+int launch_pack_key_words(const uint8_t* kmask, int kmask_ld, const int32_t* lens, int B, int Lk, unsigned long long* words, size_t cap,
+                          hipStream_t s);
 int launch_attention(const AttnArgs& a, hipStream_t s);
 int launch_attention_tr(const AttnArgs& a, hipStream_t s);
 // mlp_fused.hip: x <- x + W2 . gelu(W1 . LayerNorm(x) + b1) + b2 in one launch (bf16 operands, C = 384); the weights are packed once

@@ -848,6 +848,7 @@ int dimx_create(dimx_handle* h, int device_id, const dimx_dims* dims, int numeri
     c->use_chain = (nc && nc[0] == '1') ? 0 : 1;
     c->defer_ln = getenv("DIMX_NO_DEFER_LN") ? 0 : 1;
     c->use_layer_chain = getenv("DIMX_NO_LAYER_CHAIN") ? 0 : 1;
+    c->multi_tr = getenv("DIMX_NO_MULTI_TR") ? 0 : 1;
     if (getenv("DIMX_LAYER_PROF")) {
         void* p = nullptr;
         if (hipMalloc(&p, (size_t)8 * 256 * 16 * 8) == hipSuccess) {
@@ -1031,6 +1032,9 @@ struct GenScratch {
     long st_qkv, st_qc, st_xr, st_lg;  // slab strides (elements)
     int32_t* step;
     unsigned* chain_ctr;  // [kChainSites][8][16] per-XCD arrival counters of the chain launch sites
+    void* qcb;                 // several samples per clip, bf16: the cross-attention queries [rows, inner] in the operand type
+    unsigned long long* kw;    // ... and the context mask as 64-bit validity words [clips][ceil(T / 64)] (attention_tr.hip)
+    size_t kw_cap;
 };
 constexpr int kChainSites = 32;
 constexpr int kChainSiteWords = 8 * 16 + 8 * 32;  // arrival counters [8][16] + claim stamps [8][32]
@@ -1103,6 +1107,9 @@ static void plan_gen(const dimx_ctx* c, Arena& ar, int B, int T, GenScratch& s) 
     s.logits = (float*)ar.take((size_t)kMaxSlabs * B * c->decg.num_tokens * 4);
     s.step = (int32_t*)ar.take(64 * dimx_ctx::kMaxGroups);  // one counter per clip group, 64 B apart
     s.chain_ctr = (unsigned*)ar.take((size_t)kChainSites * kChainSiteWords * 4);
+    s.qcb = ar.take((size_t)B * inner * es);
+    s.kw_cap = (size_t)B * ((T + 63) / 64);
+    s.kw = (unsigned long long*)ar.take(s.kw_cap * 8);
 }
 
 // SLM.forward_encoder: the encoder scratch is sized for the joint 2T pass; xs / xl keep the two first-stage
@@ -1813,6 +1820,11 @@ static bool gen_use_chain(dimx_handle h, int B, int S, int grp) {
     return chain_supported(c, h->cu_count) && 3 * dg.depth + 1 <= kChainSites;
 }
 
+// several samples per clip in the bf16 mode: the decode cross attention runs on attention_tr.hip (64-wide heads)
+static bool gen_multi_tr(dimx_handle h, int S) {
+    return S > 1 && h->multi_tr && h->at == DIMX_BF16 && h->decg.dim_head == 64;
+}
+
 // one decoder step for the clip group [row0, row0 + B) of a batch of Btot clips:
 // x = emb(token) -> 4 x {self, cross, ff} -> logits -> sample -> step += 1
 static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, const int32_t* start,
@@ -2026,10 +2038,36 @@ static int gen_step(dimx_handle h, const CtxPersist& cp, const GenScratch& s0, c
         } else {
             DIMX_TRY(slab_gemm(s.o, inner, h->dec.self_[l].out, s.xr, s0.st_xr, &pending));
             DIMX_TRY(launch_add_slabs_layernorm(h->at, s.x, s.xr, pending, s0.st_xr, s.y, h->dec.cross[l].ln_g, B, DD, st));
+            if (gen_multi_tr(h, S)) {
+                // round 6, best-of-N in one pass (code/x_engine_pt.py:257), bf16: the S queries of a clip against its context K/V on the
+                // matrix cores -- the prefill attention kernel with Lq = S (one 128-query item per (clip, head), K / V streamed once),
+                // queries in the operand type from a plain projection (rows = clips x S: no split-K needed).  The VALU multi-query
+                // kernel it replaces ran 118 us per launch at 256 clips x 10 samples, 3 x its HBM floor (profiles/r06_samples10.txt).
+                gemm_lin(h, s.y, DD, h->dec.cross[l].qkv, B, g);
+                g.out_dtype = h->at;
+                gemm_set_plain_out(g, (unsigned char*)s0.qcb + (size_t)row0 * inner * es, inner);
+                DIMX_TRY(launch_gemm(g, st));
+                AttnArgs ta;
+                memset(&ta, 0, sizeof(ta));
+                ta.dtype = h->at;
+                ta.q = (unsigned char*)s0.qcb + (size_t)row0 * inner * es;
+                ta.q_sb = (long)S * inner; ta.q_st = inner; ta.q_sh = D;
+                ta.k = ca.kcache; ta.k_sb = (long)heads * Tp * D; ta.k_sh = (long)Tp * D; ta.k_st = D;
+                ta.vt = ca.vcache; ta.v_rows = 1; ta.v_sb = (long)heads * Tp * D; ta.v_sh = (long)Tp * D; ta.v_st = D;
+                ta.o = s.o; ta.o_sb = (long)S * inner; ta.o_st = inner; ta.o_sh = D;
+                ta.B = nclip; ta.H = heads; ta.Lq = S; ta.Lk = T; ta.D = D;
+                ta.scale = scale;
+                ta.kmask = ctx_mask; ta.kmask_ld = T;
+                ta.kwords = s0.kw + (size_t)clip0 * ((T + 63) / 64); ta.kwords_cap = s0.kw_cap - (size_t)clip0 * ((T + 63) / 64);
+                ta.kwords_ready = 1;   // packed once per generation (generate_impl)
+                DIMX_TRY(launch_attention_tr(ta, st));
+                goto cross_out;
+            }
             DIMX_TRY(slab_gemm(s.y, DD, h->dec.cross[l].qkv, s.qc, s0.st_qc, &ns));
         }
         ca.nslab = ns;
         DIMX_TRY(launch_decode_attn(ca, st));
+    cross_out:
         if (chain) {  // cross out-projection -> x += . -> LayerNorm (feed-forward input)
             DIMX_TRY(chain_site(3 * l + 1, s.o, inner, &h->dec.cross[l].out, 0, h->dec.ff[l].ln_g, nullptr, nullptr, 0));
         } else {
@@ -2102,6 +2140,7 @@ static int generate_impl(dimx_handle h, const int32_t* start, const uint8_t* ctx
     // the captured step graph is independent of them
     DIMX_TRY(launch_gen_params(s.step, dimx_ctx::kMaxGroups, temperature, seed, h->shard_row_off * S,
                                h->shard_rows_total * S, st));
+    if (gen_multi_tr(h, S)) DIMX_TRY(launch_pack_key_words(ctx_mask, T, nullptr, B, T, s.kw, s.kw_cap, st));
     // Independent clip groups run as separate step graphs on separate streams: every decode kernel is
     // latency-bound at these sizes, so two groups in flight let one group's GEMM/LayerNorm chain overlap the
     // other group's HBM-bound attention.  Results do not depend on the grouping (per-clip state only; the

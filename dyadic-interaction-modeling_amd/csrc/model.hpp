@@ -171,6 +171,8 @@ struct dimx_ctx {
     float* chain_stats_dev = nullptr;   // [8][32][32][2] partial row sums of the deferred-LayerNorm chain kernels
     int defer_ln = 1;                   // DIMX_NO_DEFER_LN=1 keeps the row-phase LayerNorm inside the chain kernels
     unsigned long long* layer_prof_dev = nullptr;  // DIMX_LAYER_PROF=1 (tuning): [8 layers][256 blocks][16] phase stamps of xcd_layer_kernel
+    int multi_tr = 1;                   // round 6: several samples per clip (best-of-N), bf16: the decode cross attention on the MFMA prefill
+                                        // attention kernel (attention_tr.hip) instead of the VALU multi-query kernel (DIMX_NO_MULTI_TR=1: the latter)
     int use_layer_chain = 1;            // DIMX_NO_LAYER_CHAIN=1 keeps the attention half of a layer as four launches (round 5)
     unsigned* chain_err_dev = nullptr;  // bit 0: two blocks claimed one (XCD, CU slot), bit 1: a group barrier timed out
     unsigned* chain_err_host = nullptr; // pinned copy, refreshed at the end of every generate call

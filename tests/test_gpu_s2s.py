@@ -403,3 +403,40 @@ def test_prefill_clip_groups_reproduce_the_single_batch(full_sd):
         agree = (one[3] == many[3]).float().mean().item()
         print("groups %d: generated tokens agreement %.4f" % (groups, agree))
         assert torch.equal(one[3][:, :4], many[3][:, :4])
+
+
+def test_multi_sample_cross_attention_on_the_matrix_cores_matches_the_multi_query_kernel(full_sd):
+    """Round 6, the reference's best-of-N protocol in one pass (code/x_engine_pt.py:257), bf16 mode: the S queries of a clip attend
+    over its context K/V on the MFMA prefill attention kernel (attention_tr.hip with Lq = S) instead of the VALU multi-query
+    kernel (DIMX_NO_MULTI_TR=1 keeps the latter).  Same softmax, same masks (ragged context lengths), bf16 operand rounding of q and
+    of the probabilities: the first step's logits of the two paths agree to bf16 level and pick the same token almost everywhere; the
+    f32 parity mode is untouched (its multi-sample pass equals independent runs token for token, test_gpu_module)."""
+    import os
+    from dimx import engine, lib, prng
+    B, T, S, lens = 5, 72, 10, [72, 65, 40, 9, 72]
+    v_s, v_a, z, mask = _case(B, T, lens, seed=23)
+    m8 = mask.to(torch.uint8).cuda()
+    noise = torch.from_numpy(prng.exponential(9, "s2s.multi", (T - 1, B * S, 512))).cuda()
+    out = {}
+    for name, env in (("tr", None), ("valu", "1")):
+        if env is None:
+            os.environ.pop("DIMX_NO_MULTI_TR", None)
+        else:
+            os.environ["DIMX_NO_MULTI_TR"] = env
+        try:
+            e = engine.Engine("cuda:0", lib.MODE_PERF_BF16)       # the switch is read when the handle is created
+        finally:
+            os.environ.pop("DIMX_NO_MULTI_TR", None)
+        e.load_state_dict(full_sd)
+        e.encode_ctx(v_s.cuda(), v_a.cuda(), m8, True, n_samples=S)
+        tok, lg = e.generate(z[:, 0].cuda(), m8, T, 1.0, noise=noise, return_logits=True, n_samples=S)
+        out[name] = (tok.cpu(), lg.cpu())
+        e.close()
+    (t_tr, l_tr), (t_va, l_va) = out["tr"], out["valu"]
+    assert torch.isfinite(l_tr).all() and t_tr.shape == (B * S, T - 1)
+    d0 = (l_tr[:, 0] - l_va[:, 0]).abs().max().item()            # step 0: same inputs on both paths
+    agree0 = (t_tr[:, 0] == t_va[:, 0]).float().mean().item()
+    print("multi-sample cross attention, MFMA vs VALU kernel: step-0 logits differ by %.3g, step-0 tokens agree %.3f" % (d0, agree0))
+    assert d0 < 3e-2 and agree0 >= 0.9
+    # samples of a clip differ (the noise differs) and a padded context never leaks: clip 3 has 9 valid frames
+    assert not torch.equal(t_tr[0], t_tr[1])
