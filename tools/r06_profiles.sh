@@ -30,7 +30,7 @@ python tools/pmc_gemm256_record.py $O/r06_pmc_mfma_cross_kv.txt $O/r06_cross_kv_
 # MFMA busy of the two other MFMA kernels of the prefill (fused feed-forward sublayer, prefill attention), same counters
 # (one batch on one stream, DIMX_PREFILL_GROUPS=1: with the clip groups of the default path several of these kernels run at the same time
 #  and a kernel's counters are diluted by its neighbours -- 19 % instead of 27 % MFMA busy for the fused feed-forward kernel)
-DIMX_PREFILL_GROUPS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_pre -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-mode --no-train-step --no-roofline > /dev/null 2>&1
+DIMX_PREFILL_GROUPS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_pre -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity-mode --no-train-step --no-roofline --no-best-of-n > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_pre | grep -A8 "mlp_fused_kernel\|attn_tr_kernel" > $O/r06_pmc_mfma_prefill_kernels.txt
 python tools/pmc_prefill_record.py $O/r06_pmc_mfma_prefill_kernels.txt $COMMIT >> $O/r06_pmc_record.txt 2>&1
 cp profiles/pmc_*.json $O/ 2>/dev/null
@@ -49,12 +49,12 @@ PY
 # 3. headline line (value, parity_mode, bf16_vs_f32, roofline incl. phases, cross_attn_mfma, cross_attn_bundle, train_step, cpu_baseline)
 python bench.py --steps 10 --warmup 2 > $O/r06_bench_line.json 2> $O/r06_bench_line.err
 # 4. kernel traces: the headline workload, the f32 parity mode, the C5 shard
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode --no-train-step > $O/r06_bench_line_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode --no-train-step --no-best-of-n > $O/r06_bench_line_under_rocprof.json 2>/dev/null
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/r06_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt32 -- python bench.py --mode f32 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/r06_parity_line_under_rocprof.json 2>/dev/null
 cp $(ls $O/kt32/*/*kernel_stats.csv | head -1) $O/r06_parity_kernel_stats.csv
 python bench.py --steps 2 --warmup 1 --batch 64 --frames 1500 --no-cpu-baseline --no-parity-mode --no-train-step > $O/r06_bench_c5_shard.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktc5 -- python bench.py --steps 2 --warmup 1 --batch 64 --frames 1500 --no-cpu-baseline --no-parity-mode --no-train-step --no-roofline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktc5 -- python bench.py --steps 2 --warmup 1 --batch 64 --frames 1500 --no-cpu-baseline --no-parity-mode --no-train-step --no-roofline --no-best-of-n > /dev/null 2>&1
 cp $(ls $O/ktc5/*/*kernel_stats.csv | head -1) $O/r06_c5_kernel_stats.csv
 # 5. variants (same box): the parity mode with the exact-f32 MFMA decode GEMMs, the bf16 mode without the layer kernel
 DIMX_NO_X3=1 python bench.py --mode f32 --steps 5 --warmup 2 --no-cpu-baseline --no-train-step --no-roofline --no-mode-compare > $O/r06_parity_line_no_x3.json 2>/dev/null

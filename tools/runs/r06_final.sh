@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, last call: PMC records + bench lines of the final kernel sources (tools/r06_profiles.sh), the whole GPU suite, smoke, and the
 # driver's own command line
-bash tools/r06_profiles.sh b384f28 > gpurun_out/r06_profiles.log 2>&1; echo "profiles rc $?"; tail -3 gpurun_out/r06_profiles.log | cut -c1-300
+bash tools/r06_profiles.sh be9cf8f > gpurun_out/r06_profiles.log 2>&1; echo "profiles rc $?"; tail -3 gpurun_out/r06_profiles.log | cut -c1-300
 timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r06/gpu_tests_final.txt 2>&1; tail -4 gpurun_out/r06/gpu_tests_final.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 ( time python bench.py ) > gpurun_out/r06/driver_style_bench.json 2> gpurun_out/r06/driver_style_bench.err; tail -4 gpurun_out/r06/driver_style_bench.err; python -c "
